@@ -1,0 +1,196 @@
+/* za_amd -- C ABI of the MI355X-native Groth16/BN254 prover hot path for adria0/za.
+ *
+ * This is the drop-in boundary a Rust (or cgo / ctypes) caller binds instead of the bellman_ce
+ * calls za makes today.  Every entry point cites the reference interface it replaces; paths are
+ * relative to the za repository.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - Fr / Fq element, "Montgomery LE": x*2^256 mod p as 4 x u64 little-endian limbs (32 bytes) --
+ *     the in-memory form of pairing_ce::bn256::{Fr,Fq}.
+ *   - scalar, "canonical LE": the integer itself, 32 bytes little-endian (FrRepr, i.e. what
+ *     `into_repr()` yields and what bellman's multiexp consumes).
+ *   - G1 affine base: x||y Montgomery LE, 64 bytes; G2 affine base: x.c0||x.c1||y.c0||y.c1, 128 bytes;
+ *     the identity is all-zero bytes.
+ *   - Jacobian result: X||Y||Z Montgomery LE (G1 96 bytes, G2 192 bytes); Z = 0 is the identity,
+ *     otherwise the library returns Z = 1 (normalised).
+ *   - proof: 256 bytes, canonical BIG-endian field elements A.x A.y B.x.c0 B.x.c1 B.y.c0 B.y.c1 C.x C.y
+ *     (the numbers proof.json prints, prover/src/groth16/format.rs:46-52,69-78).
+ *   - All functions return 0 on success or a ZG_E_* code; no exception crosses the boundary.
+ *   - One zg_ctx per process and GPU; calls on one ctx must be serialised by the caller (the
+ *     reference is synchronous too).  Handles are freed by their *_free function.
+ *   - `d_` pointers are device (HBM) addresses on the ctx's GPU; others are host addresses.
+ */
+#ifndef ZA_AMD_H
+#define ZA_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error codes.  1..8 mirror bellman::SynthesisError as wrapped by za's Error::Synthesis
+ * (prover/src/groth16/error.rs:4,20-24). */
+#define ZG_OK 0
+#define ZG_E_ASSIGNMENT_MISSING 1
+#define ZG_E_DIVISION_BY_ZERO 2
+#define ZG_E_UNSATISFIABLE 3
+#define ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE 4
+#define ZG_E_UNEXPECTED_IDENTITY 5
+#define ZG_E_IO 6
+#define ZG_E_MALFORMED_VERIFYING_KEY 7
+#define ZG_E_UNCONSTRAINED_VARIABLE 8
+#define ZG_E_BAD_FORMAT 20      /* za Error::BadFormat (error.rs) */
+#define ZG_E_QUERY_SIZE 21      /* multiexp's `query_size == density total` assertion */
+#define ZG_E_INVALID_ARG 22
+#define ZG_E_BUFFER_TOO_SMALL 23
+#define ZG_E_HIP 30
+#define ZG_E_NO_DEVICE 31
+
+typedef struct zg_ctx zg_ctx;
+typedef struct zg_params zg_params;
+typedef struct zg_r1cs zg_r1cs;
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces bellman's `Worker::new()` thread pool (implicit in create_random_proof,
+ * prover/src/groth16/prover.rs:173).  `device` is the HIP device ordinal.  Fails with
+ * ZG_E_NO_DEVICE when no GPU is visible: there is no CPU fallback. */
+int zg_init(int device, zg_ctx** out);
+void zg_free(zg_ctx* ctx);
+const char* zg_strerror(int code);
+/* Last detailed message recorded on this ctx (never NULL). */
+const char* zg_last_error(const zg_ctx* ctx);
+/* Use an existing HIP stream (hipStream_t cast to void*) for every launch; NULL = the ctx's own. */
+int zg_set_stream(zg_ctx* ctx, void* hip_stream);
+int zg_sync(zg_ctx* ctx);
+
+/* ---- device memory plumbing ---------------------------------------------------------------- */
+int zg_dev_alloc(zg_ctx* ctx, size_t bytes, void** d_ptr);
+int zg_dev_free(zg_ctx* ctx, void* d_ptr);
+int zg_h2d(zg_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- multi-scalar multiplication -----------------------------------------------------------
+ * Replaces bellman_ce::multiexp::multiexp(pool, (bases, skip), density_map, exponents) for
+ * G = G1 and G = G2 (8 calls inside create_proof; call site prover/src/groth16/prover.rs:173).
+ *
+ * Host form (bellman semantics): `scalars` has n_scalars entries; `density_bits` (nullable = full
+ * density) is an LSB-first bitmap over the scalars; `bases` holds exactly popcount(density)
+ * points, consumed sequentially for set bits.  Mismatch -> ZG_E_QUERY_SIZE. */
+int zg_msm_g1(zg_ctx* ctx, const uint8_t* bases64, size_t n_bases, const uint8_t* scalars32,
+              const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[96]);
+int zg_msm_g2(zg_ctx* ctx, const uint8_t* bases128, size_t n_bases, const uint8_t* scalars32,
+              const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[192]);
+/* Device form: n bases resident in HBM; base i is multiplied by d_scalars[d_scalar_index[i]]
+ * (or d_scalars[i] when d_scalar_index is NULL). */
+int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars,
+                  const uint32_t* d_scalar_index, size_t n, uint8_t out_jac[96]);
+int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars,
+                  const uint32_t* d_scalar_index, size_t n, uint8_t out_jac[192]);
+
+/* ---- Fr number-theoretic transform ---------------------------------------------------------
+ * Replaces bellman_ce::domain::EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} (inside
+ * create_proof).  m = 2^log_m Montgomery-LE elements, natural order in and out, in place.
+ * inverse != 0 applies omega^-1 and the 1/m factor; coset != 0 applies the g^i (forward) or
+ * g^-i (inverse) distribution with g = Fr::multiplicative_generator() = 7.
+ * log_m >= 28 -> ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE (Fr::S = 28). */
+int zg_ntt_fr(zg_ctx* ctx, uint8_t* inout, uint32_t log_m, int inverse, int coset);
+int zg_ntt_fr_dev(zg_ctx* ctx, void* d_inout, uint32_t log_m, int inverse, int coset);
+
+/* ---- H polynomial ----------------------------------------------------------------------------
+ * Replaces the block of create_proof that turns the a, b, c evaluation vectors into the
+ * coefficients of H = (A*B - C)/Z: from_coeffs, ifft x3, coset_fft x3, mul_assign, sub_assign,
+ * divide_by_z_on_coset, icoset_fft, into_coeffs, truncate, into_repr.
+ * a, b, c: n_rows Montgomery-LE values (n_rows <= m, zero-padded internally);
+ * h_out: m-1 canonical-LE scalars. */
+int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t n_rows,
+                 uint32_t log_m, uint8_t* h_out);
+
+/* ---- R1CS ------------------------------------------------------------------------------------
+ * Replaces what bellman's ProvingAssignment receives through Circuit::synthesize /
+ * ConstraintSystem::{alloc_input, alloc, enforce} (za side: prover/src/groth16/prover.rs:45-103,
+ * LC conversion prover/src/groth16/format.rs:207-221).  Variables are flat: index 0 is ONE, then
+ * the other public inputs, then the aux variables (ordering rule: prover.rs:55-88).  The three
+ * matrices are CSR: row_ptr[k] has n_constraints+1 u64 entries, col[k] u32 variable indices,
+ * coeff[k] 32-byte canonical-LE Fr coefficients; k = 0,1,2 for A, B, C with <A,w>*<B,w> = <C,w>
+ * (za's QEQ a*b+c=0 is passed as a*b = -c, prover.rs:98).  The `input_i * 0 = 0` rows bellman
+ * appends are added internally.  Density maps are derived here by MENTION, as bellman does. */
+int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
+                 const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                 const uint8_t* const coeff[3], zg_r1cs** out);
+void zg_r1cs_free(zg_r1cs* r);
+/* n_inputs, n_aux, n_constraints, log_m, a_aux_density_total, b_input_density_total,
+ * b_aux_density_total */
+int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]);
+/* Evaluate a = A*w, b = B*w, c = C*w on the GPU (n_constraints + n_inputs rows each, Montgomery LE). */
+int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint8_t* a_out,
+                 uint8_t* b_out, uint8_t* c_out);
+
+/* ---- proving key -----------------------------------------------------------------------------
+ * zg_params_load replaces bellman_ce::groth16::Parameters::<Bn256>::read(reader, checked)
+ * (prover/src/groth16/format.rs:285): vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
+ * delta_g2, u32be |ic|, ic[]), then u32be-length-prefixed h, l, a, b_g1, b_g2, points uncompressed
+ * big-endian.  `checked` enables the on-curve test; identity inside h/l/a/b_* is rejected.
+ * rank/world shard every query into `world` contiguous chunks and keep chunk `rank` in HBM
+ * (world = 1: everything).  *consumed receives the number of bytes read. */
+int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank,
+                   int world, zg_params** out, size_t* consumed);
+/* Same, from Montgomery-LE arrays already in memory (what a Rust caller holding a
+ * Parameters<Bn256> has).  vk5 = alpha_g1(64) beta_g1(64) beta_g2(128) delta_g1(64) delta_g2(128). */
+int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const uint8_t* h, size_t n_h,
+                        const uint8_t* l, size_t n_l, const uint8_t* a, size_t n_a,
+                        const uint8_t* b_g1, size_t n_b_g1, const uint8_t* b_g2, size_t n_b_g2,
+                        int rank, int world, zg_params** out);
+void zg_params_free(zg_params* p);
+/* Skip za's proving-key container header (u32be-len AST blob, constraints, ignore_signals;
+ * prover/src/groth16/format.rs:223-247) and return the offset of the bellman Parameters body. */
+int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
+
+/* ---- prove -----------------------------------------------------------------------------------
+ * Replaces bellman_ce::groth16::create_proof(circuit, params, r, s) -- the deterministic core of
+ * create_random_proof (prover/src/groth16/prover.rs:173).  witness32 = (n_inputs + n_aux)
+ * canonical-LE scalars, witness[0] must be 1.  r, s canonical LE.
+ * Errors: ZG_E_UNEXPECTED_IDENTITY (delta = 0 or an identity proof element),
+ * ZG_E_QUERY_SIZE (key does not match the circuit's densities), ZG_E_ASSIGNMENT_MISSING (NULL witness),
+ * ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE. */
+int zg_prove(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const uint8_t* witness32,
+             const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
+/* Same with the witness already resident in HBM (the timed form in bench.py). */
+int zg_prove_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
+                 const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
+/* create_random_proof: r, s from the OS entropy source. */
+int zg_prove_random(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs,
+                    const uint8_t* witness32, uint8_t proof_out[256]);
+
+/* Phases of zg_prove_dev for one-process-per-GPU sharding:
+ *   rank 0:     zg_prove_h_dev         -> m canonical-LE H scalars in HBM (last one is zero)
+ *   every rank: zg_prove_partials_dev  -> its partial sums over its shard of h, l, a, b_g1, b_g2
+ *   rank 0:     zg_prove_combine       -> adds the gathered partials, applies r, s, normalises.
+ * partial layout (ZG_PARTIALS_BYTES): h(96) l(96) a(96) b_g1(96) b_g2(192), Jacobian Montgomery LE.
+ * d_h points at the H scalars of THIS rank's h-shard (zg_params_shard_range(.., 0, ..)). */
+#define ZG_PARTIALS_BYTES 576
+int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_h_out);
+int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs,
+                          const void* d_witness, const void* d_h_shard,
+                          uint8_t partials[ZG_PARTIALS_BYTES]);
+int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partials_all, int world,
+                     const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
+/* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */
+int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi);
+
+/* ---- formats ---------------------------------------------------------------------------------
+ * proof.json exactly as JsonProofAndInput::write emits it (prover/src/groth16/format.rs:80-128):
+ * {"a":[x,y],"b":[[x.c0,x.c1],[y.c0,y.c1]],"c":[x,y],"public_inputs":[...]} with 0x-prefixed
+ * 64-digit lowercase hex coordinates and decimal public inputs (n_public canonical-LE scalars,
+ * ONE excluded).  Returns ZG_E_BUFFER_TOO_SMALL if cap is insufficient (cf. binding/c/native/src/lib.rs:22-30). */
+int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public,
+                  char* out, size_t cap);
+
+/* ---- timing of the last zg_prove* call on this ctx (milliseconds, GPU events + host clock):
+ * [0] witness upload, [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
+int zg_last_timings(const zg_ctx* ctx, double ms[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,319 @@
+"""za_amd -- MI355X-native Groth16/BN254 prover hot path for adria0/za.
+
+The product is `libza_amd.so` (HIP kernels + the C ABI in include/za_amd.h).  This package is the
+thin ctypes binding that tests, bench.py and a Python host use; it mirrors the shape of the
+reference's Python binding (binding/python3/native/src/lib.rs: setup / prove / verify taking
+strings and returning strings) one level lower, at the create_proof boundary.
+
+There is no CPU fallback: every compute entry point needs a GPU and raises ZaAmdError otherwise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libza_amd.so")
+
+ZG_OK = 0
+ZG_E_ASSIGNMENT_MISSING = 1
+ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE = 4
+ZG_E_UNEXPECTED_IDENTITY = 5
+ZG_E_IO = 6
+ZG_E_QUERY_SIZE = 21
+ZG_E_INVALID_ARG = 22
+ZG_E_BUFFER_TOO_SMALL = 23
+ZG_E_HIP = 30
+ZG_E_NO_DEVICE = 31
+ZG_PARTIALS_BYTES = 576
+
+# every symbol include/za_amd.h declares (tests/test_abi.py checks the library exports them all)
+ABI_SYMBOLS = [
+    "zg_init", "zg_free", "zg_strerror", "zg_last_error", "zg_set_stream", "zg_sync",
+    "zg_dev_alloc", "zg_dev_free", "zg_h2d", "zg_d2h",
+    "zg_msm_g1", "zg_msm_g2", "zg_msm_g1_dev", "zg_msm_g2_dev",
+    "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
+    "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
+    "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
+    "zg_prove", "zg_prove_dev", "zg_prove_random",
+    "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range",
+    "zg_proof_json", "zg_last_timings",
+]
+
+
+class ZaAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("za_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libza_amd.so; raises if it has not been built (python -m za_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZaAmdError(-1, "libza_amd.so is missing: build it with `python za_amd/build.py` "
+                                 "(there is no Python/CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        lib.zg_strerror.restype = C.c_char_p
+        lib.zg_last_error.restype = C.c_char_p
+        lib.zg_free.restype = None
+        lib.zg_r1cs_free.restype = None
+        lib.zg_params_free.restype = None
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(x):
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        x = np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def density_bitmap(flags):
+    """bool/0-1 sequence -> LSB-first u64 bitmap (the C ABI's density_bits form)."""
+    f = np.asarray(flags, dtype=np.uint8) != 0
+    pad = (-len(f)) % 64
+    if pad or len(f) == 0:
+        f = np.concatenate([f, np.zeros(pad if len(f) else 64, dtype=bool)])
+    return np.packbits(f, bitorder="little").view("<u8").copy()
+
+
+class Context:
+    """One per process and GPU (zg_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.zg_init(C.c_int(device), C.byref(h))
+        if rc:
+            raise ZaAmdError(rc, self.lib.zg_strerror(rc).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zg_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            detail = self.lib.zg_last_error(self.h).decode()
+            raise ZaAmdError(rc, "%s: %s" % (self.lib.zg_strerror(rc).decode(), detail))
+
+    # ---- plumbing
+    def set_stream(self, stream_handle):
+        self._check(self.lib.zg_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        self._check(self.lib.zg_sync(self.h))
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.lib.zg_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self._check(self.lib.zg_dev_free(self.h, C.c_void_p(dptr)))
+
+    def h2d(self, dptr, data):
+        a = _u8(data)
+        self._check(self.lib.zg_h2d(self.h, C.c_void_p(dptr), _ptr(a), C.c_size_t(a.size)))
+
+    def d2h(self, dptr, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._check(self.lib.zg_d2h(self.h, _ptr(out), C.c_void_p(dptr), C.c_size_t(nbytes)))
+        return out
+
+    def upload(self, data):
+        a = _u8(data)
+        d = self.alloc(a.size)
+        self.h2d(d, a)
+        return d
+
+    # ---- MSM
+    def msm_g1(self, bases, scalars, density=None):
+        b, s = _u8(bases), _u8(scalars)
+        out = np.zeros(96, dtype=np.uint8)
+        dm = None if density is None else density_bitmap(density)
+        self._check(self.lib.zg_msm_g1(self.h, _ptr(b), C.c_size_t(b.size // 64), _ptr(s),
+                                       None if dm is None else _ptr(dm), C.c_size_t(s.size // 32), _ptr(out)))
+        return out.tobytes()
+
+    def msm_g2(self, bases, scalars, density=None):
+        b, s = _u8(bases), _u8(scalars)
+        out = np.zeros(192, dtype=np.uint8)
+        dm = None if density is None else density_bitmap(density)
+        self._check(self.lib.zg_msm_g2(self.h, _ptr(b), C.c_size_t(b.size // 128), _ptr(s),
+                                       None if dm is None else _ptr(dm), C.c_size_t(s.size // 32), _ptr(out)))
+        return out.tobytes()
+
+    def msm_g1_dev(self, d_bases, d_scalars, n, d_index=None):
+        out = np.zeros(96, dtype=np.uint8)
+        self._check(self.lib.zg_msm_g1_dev(self.h, C.c_void_p(d_bases), C.c_void_p(d_scalars),
+                                           C.c_void_p(d_index), C.c_size_t(n), _ptr(out)))
+        return out.tobytes()
+
+    def msm_g2_dev(self, d_bases, d_scalars, n, d_index=None):
+        out = np.zeros(192, dtype=np.uint8)
+        self._check(self.lib.zg_msm_g2_dev(self.h, C.c_void_p(d_bases), C.c_void_p(d_scalars),
+                                           C.c_void_p(d_index), C.c_size_t(n), _ptr(out)))
+        return out.tobytes()
+
+    # ---- NTT / H
+    def ntt(self, data, log_m, inverse=False, coset=False):
+        a = np.array(_u8(data), copy=True)
+        assert a.size == 32 << log_m
+        self._check(self.lib.zg_ntt_fr(self.h, _ptr(a), C.c_uint32(log_m), C.c_int(int(inverse)), C.c_int(int(coset))))
+        return a
+
+    def ntt_dev(self, dptr, log_m, inverse=False, coset=False):
+        self._check(self.lib.zg_ntt_fr_dev(self.h, C.c_void_p(dptr), C.c_uint32(log_m), C.c_int(int(inverse)),
+                                           C.c_int(int(coset))))
+
+    def h_scalars(self, a, b, c, n_rows, log_m):
+        a, b, c = _u8(a), _u8(b), _u8(c)
+        out = np.zeros(32 * ((1 << log_m) - 1), dtype=np.uint8)
+        self._check(self.lib.zg_h_scalars(self.h, _ptr(a), _ptr(b), _ptr(c), C.c_size_t(n_rows), C.c_uint32(log_m),
+                                          _ptr(out)))
+        return out
+
+    # ---- R1CS / params / prove
+    def r1cs_load(self, n_inputs, n_aux, n_constraints, row_ptr, col, coeff):
+        rp = [np.ascontiguousarray(x, dtype=np.uint64) for x in row_ptr]
+        cl = [np.ascontiguousarray(x, dtype=np.uint32) for x in col]
+        cf = [_u8(x) for x in coeff]
+        arr3 = C.c_void_p * 3
+        h = C.c_void_p()
+        self._check(self.lib.zg_r1cs_load(self.h, C.c_uint32(n_inputs), C.c_uint32(n_aux), C.c_uint64(n_constraints),
+                                          arr3(*[x.ctypes.data for x in rp]), arr3(*[x.ctypes.data for x in cl]),
+                                          arr3(*[x.ctypes.data for x in cf]), C.byref(h)))
+        return R1CS(self, h)
+
+    def params_from_mont(self, vk5, h, l, a, b_g1, b_g2, rank=0, world=1):
+        vk5, h, l, a, b_g1, b_g2 = (_u8(x) for x in (vk5, h, l, a, b_g1, b_g2))
+        assert vk5.size == 448
+        hd = C.c_void_p()
+        self._check(self.lib.zg_params_from_mont(
+            self.h, _ptr(vk5), _ptr(h), C.c_size_t(h.size // 64), _ptr(l), C.c_size_t(l.size // 64),
+            _ptr(a), C.c_size_t(a.size // 64), _ptr(b_g1), C.c_size_t(b_g1.size // 64),
+            _ptr(b_g2), C.c_size_t(b_g2.size // 128), C.c_int(rank), C.c_int(world), C.byref(hd)))
+        return Params(self, hd)
+
+    def params_load(self, bellman_bytes, checked=True, rank=0, world=1):
+        b = _u8(bellman_bytes)
+        hd = C.c_void_p()
+        used = C.c_size_t()
+        self._check(self.lib.zg_params_load(self.h, _ptr(b), C.c_size_t(b.size), C.c_int(int(checked)), C.c_int(rank),
+                                            C.c_int(world), C.byref(hd), C.byref(used)))
+        return Params(self, hd), used.value
+
+    def prove(self, params, r1cs, witness, r, s):
+        """witness: (n_inputs+n_aux) x 32 B canonical LE; r, s: ints.  Returns the 256-byte proof."""
+        w = _u8(witness)
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(int(r).to_bytes(32, "little")), _u8(int(s).to_bytes(32, "little"))
+        self._check(self.lib.zg_prove(self.h, params.h, r1cs.h, _ptr(w), _ptr(rb), _ptr(sb), _ptr(out)))
+        return out.tobytes()
+
+    def prove_dev(self, params, r1cs, d_witness, r, s):
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(int(r).to_bytes(32, "little")), _u8(int(s).to_bytes(32, "little"))
+        self._check(self.lib.zg_prove_dev(self.h, params.h, r1cs.h, C.c_void_p(d_witness), _ptr(rb), _ptr(sb),
+                                          _ptr(out)))
+        return out.tobytes()
+
+    def prove_h_dev(self, r1cs, d_witness, d_h_out):
+        self._check(self.lib.zg_prove_h_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
+
+    def prove_partials_dev(self, params, r1cs, d_witness, d_h_shard):
+        out = np.zeros(ZG_PARTIALS_BYTES, dtype=np.uint8)
+        self._check(self.lib.zg_prove_partials_dev(self.h, params.h, r1cs.h, C.c_void_p(d_witness),
+                                                   C.c_void_p(d_h_shard), _ptr(out)))
+        return out
+
+    def prove_combine(self, params, partials_all, world, r, s):
+        pa = _u8(partials_all)
+        assert pa.size == world * ZG_PARTIALS_BYTES
+        out = np.zeros(256, dtype=np.uint8)
+        rb, sb = _u8(int(r).to_bytes(32, "little")), _u8(int(s).to_bytes(32, "little"))
+        self._check(self.lib.zg_prove_combine(self.h, params.h, _ptr(pa), C.c_int(world), _ptr(rb), _ptr(sb),
+                                              _ptr(out)))
+        return out.tobytes()
+
+    def last_timings(self):
+        t = (C.c_double * 6)()
+        self._check(self.lib.zg_last_timings(self.h, t))
+        return dict(zip(("upload_ms", "r1cs_eval_ms", "h_ms", "msm_ms", "combine_ms", "total_ms"), list(t)))
+
+
+class R1CS:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        info = (C.c_uint64 * 7)()
+        ctx._check(ctx.lib.zg_r1cs_info(h, info))
+        (self.n_inputs, self.n_aux, self.n_constraints, self.log_m, self.a_aux_total, self.b_input_total,
+         self.b_aux_total) = list(info)
+
+    def eval(self, witness):
+        w = _u8(witness)
+        rows = self.n_constraints + self.n_inputs
+        a, b, c = (np.zeros(rows * 32, dtype=np.uint8) for _ in range(3))
+        self.ctx._check(self.ctx.lib.zg_r1cs_eval(self.ctx.h, self.h, _ptr(w), _ptr(a), _ptr(b), _ptr(c)))
+        return a, b, c
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zg_r1cs_free(self.h)
+            self.h = None
+
+
+class Params:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def shard_range(self, which):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.ctx.lib.zg_params_shard_range(self.h, C.c_int(which), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zg_params_free(self.h)
+            self.h = None
+
+
+def pk_params_offset(pk_bytes):
+    lib = load_library()
+    b = _u8(pk_bytes)
+    off = C.c_size_t()
+    rc = lib.zg_pk_params_offset(_ptr(b), C.c_size_t(b.size), C.byref(off))
+    if rc:
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return off.value
+
+
+def proof_json(proof, public_inputs):
+    """proof: 256 bytes; public_inputs: list of ints (ONE excluded).  Returns the proof.json text."""
+    lib = load_library()
+    p = _u8(proof)
+    pi = _u8(b"".join(int(x).to_bytes(32, "little") for x in public_inputs)) if public_inputs else np.zeros(1, np.uint8)
+    cap = 1024 + 80 * len(public_inputs)
+    buf = C.create_string_buffer(cap)
+    rc = lib.zg_proof_json(_ptr(p), _ptr(pi), C.c_size_t(len(public_inputs)), buf, C.c_size_t(cap))
+    if rc:
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return buf.value.decode()

@@ -1,0 +1,97 @@
+// Internal declarations shared by the HIP translation units of libza_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/za_amd.h"
+#include "ec.h"
+
+namespace zg {
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // stream every kernel is launched on
+    hipStream_t own_stream = nullptr;   // created by zg_init
+    int num_cu = 256;
+    std::string last_error;
+    double timings[6] = {0, 0, 0, 0, 0, 0};
+    // cached NTT tables per log_m (device pointers), see ntt.hip
+    struct NttTables* ntt[28] = {nullptr};
+    // reusable MSM scratch, see msm.hip
+    struct MsmScratch* msm_scratch = nullptr;
+};
+
+int fail(Ctx* ctx, int code, const char* fmt, ...);
+
+#define ZG_HIP(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::zg::fail((ctx), ZG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                              __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define ZG_TRY(expr)                \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != ZG_OK) return _rc; \
+    } while (0)
+
+// RAII device buffer on the ctx's device
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    // grow-only
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        return alloc(n);
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- msm.hip
+int msm_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index,
+           size_t n, G1XYZZ* out);
+int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index,
+           size_t n, G2XYZZ* out);
+void msm_scratch_free(Ctx* ctx);
+
+// ---- ntt.hip
+int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
+// a,b,c: m Montgomery elements each in HBM (already zero padded); d_h_out: m canonical scalars
+// (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
+int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
+void ntt_tables_free(Ctx* ctx);
+
+// ---- host helpers (field element <-> bytes)
+template <class F>
+inline void store_bytes(uint8_t* dst, const F& v) { memcpy(dst, &v, sizeof(F)); }
+template <class F>
+inline F load_bytes(const uint8_t* src) {
+    F v;
+    memcpy(&v, src, sizeof(F));
+    return v;
+}
+
+}  // namespace zg

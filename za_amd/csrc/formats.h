@@ -1,0 +1,31 @@
+// Wire formats on the za side of the boundary (host only).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace zg {
+
+// Parsed bellman Parameters<Bn256> body, points converted to Montgomery affine.
+struct ParsedParams {
+    G1Affine alpha_g1, beta_g1, delta_g1;
+    G2Affine beta_g2, gamma_g2, delta_g2;
+    std::vector<G1Affine> ic, h, l, a, b_g1;
+    std::vector<G2Affine> b_g2;
+};
+
+// Parameters::read(reader, checked) -- reference call site prover/src/groth16/format.rs:285.
+int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed);
+// Parameters::write -- reference call site prover/src/groth16/format.rs:250.
+void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out);
+// za proving-key container header (format.rs:223-247): returns offset of the Parameters body.
+int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
+// proof.json (format.rs:80-128)
+int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, std::string* out);
+
+Fq2 g2_coeff_b();                       // 3/(9+u), Montgomery
+void fq_to_be(uint8_t out[32], const Fq& mont);
+bool fq_from_be(const uint8_t in[32], Fq* mont);  // false if >= q
+
+}  // namespace zg

@@ -1,0 +1,304 @@
+// Wire formats on the za side of the boundary: bellman Parameters body, za's proving-key container
+// header and proof.json.  Host code only (compiled by hipcc with the rest of the library).
+#include "formats.h"
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace zg {
+
+Fq2 g2_coeff_b() {
+    Fq2 three{Fq::from_u64(3), Fq::zero()};
+    Fq2 xi{Fq::from_u64(9), Fq::from_u64(1)};
+    return three * xi.inv();
+}
+
+void fq_to_be(uint8_t out[32], const Fq& mont) {
+    Fq c = mont.from_mont();
+    for (int i = 0; i < 32; i++) out[i] = (uint8_t)(c.l[(31 - i) >> 2] >> (8 * ((31 - i) & 3)));
+}
+
+bool fq_from_be(const uint8_t in[32], Fq* mont) {
+    Fq c = Fq::zero();
+    for (int i = 0; i < 32; i++) c.l[(31 - i) >> 2] |= (uint32_t)in[i] << (8 * ((31 - i) & 3));
+    // canonical check: c < q
+    bool lt = false;
+    for (int i = 7; i >= 0; i--) {
+        if (c.l[i] < FqParams::MOD[i]) { lt = true; break; }
+        if (c.l[i] > FqParams::MOD[i]) { lt = false; break; }
+    }
+    if (!lt) return false;
+    *mont = c.to_mont();
+    return true;
+}
+
+namespace {
+
+enum PointStatus { PT_OK = 0, PT_COMPRESSED, PT_BAD_INFINITY, PT_NOT_IN_FIELD, PT_NOT_ON_CURVE };
+
+// pairing_ce bn256 G1Uncompressed: x || y big-endian; byte0 bit7 = compression flag (must be clear),
+// bit6 = identity (then everything else must be zero).
+PointStatus read_g1(const uint8_t* b, bool checked, G1Affine* out) {
+    if (b[0] & 0x80) return PT_COMPRESSED;
+    if (b[0] & 0x40) {
+        if (b[0] & 0x3f) return PT_BAD_INFINITY;
+        for (int i = 1; i < 64; i++)
+            if (b[i]) return PT_BAD_INFINITY;
+        *out = G1Affine::inf();
+        return PT_OK;
+    }
+    G1Affine p;
+    if (!fq_from_be(b, &p.x) || !fq_from_be(b + 32, &p.y)) return PT_NOT_IN_FIELD;
+    if (checked && !on_curve(p, Fq::from_u64(3))) return PT_NOT_ON_CURVE;
+    *out = p;
+    return PT_OK;
+}
+// G2Uncompressed: x.c1 || x.c0 || y.c1 || y.c0 big-endian
+PointStatus read_g2(const uint8_t* b, bool checked, const Fq2& coeff_b, G2Affine* out) {
+    if (b[0] & 0x80) return PT_COMPRESSED;
+    if (b[0] & 0x40) {
+        if (b[0] & 0x3f) return PT_BAD_INFINITY;
+        for (int i = 1; i < 128; i++)
+            if (b[i]) return PT_BAD_INFINITY;
+        *out = G2Affine::inf();
+        return PT_OK;
+    }
+    G2Affine p;
+    if (!fq_from_be(b, &p.x.c1) || !fq_from_be(b + 32, &p.x.c0) || !fq_from_be(b + 64, &p.y.c1) ||
+        !fq_from_be(b + 96, &p.y.c0))
+        return PT_NOT_IN_FIELD;
+    if (checked && !on_curve(p, coeff_b)) return PT_NOT_ON_CURVE;
+    *out = p;
+    return PT_OK;
+}
+
+const char* status_str(PointStatus s) {
+    switch (s) {
+        case PT_COMPRESSED: return "unexpected compression mode";
+        case PT_BAD_INFINITY: return "unexpected information in infinity encoding";
+        case PT_NOT_IN_FIELD: return "coordinate is not in the field";
+        case PT_NOT_ON_CURVE: return "point is not on the curve";
+        default: return "ok";
+    }
+}
+
+template <class Fn>
+void parallel_chunks(size_t n, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = hw ? hw : 4;
+    if (nt > 32) nt = 32;
+    if (n < 4096 || nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    size_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        size_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo >= hi) break;
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+struct Reader {
+    const uint8_t* p;
+    size_t len, pos = 0;
+    bool take(size_t n, const uint8_t** out) {
+        if (pos + n > len || pos + n < pos) return false;
+        *out = p + pos;
+        pos += n;
+        return true;
+    }
+    bool u32be(uint32_t* v) {
+        const uint8_t* b;
+        if (!take(4, &b)) return false;
+        *v = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        return true;
+    }
+};
+
+}  // namespace
+
+int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed) {
+    Reader rd{buf, len};
+    const Fq2 b2 = g2_coeff_b();
+    const uint8_t* b;
+    PointStatus st;
+#define RD_G1(dst, what)                                                                              \
+    do {                                                                                              \
+        if (!rd.take(64, &b)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading " what); \
+        if ((st = read_g1(b, checked, &(dst))) != PT_OK)                                              \
+            return fail(ctx, ZG_E_IO, what ": %s", status_str(st));                                   \
+    } while (0)
+#define RD_G2(dst, what)                                                                              \
+    do {                                                                                              \
+        if (!rd.take(128, &b)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading " what); \
+        if ((st = read_g2(b, checked, b2, &(dst))) != PT_OK)                                          \
+            return fail(ctx, ZG_E_IO, what ": %s", status_str(st));                                   \
+    } while (0)
+    RD_G1(out->alpha_g1, "vk.alpha_g1");
+    RD_G1(out->beta_g1, "vk.beta_g1");
+    RD_G2(out->beta_g2, "vk.beta_g2");
+    RD_G2(out->gamma_g2, "vk.gamma_g2");
+    RD_G1(out->delta_g1, "vk.delta_g1");
+    RD_G2(out->delta_g2, "vk.delta_g2");
+    uint32_t n;
+    if (!rd.u32be(&n)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading |ic|");
+    if ((size_t)n * 64 > len - rd.pos) return fail(ctx, ZG_E_IO, "ic length %u exceeds the buffer", n);
+    out->ic.resize(n);
+    for (uint32_t i = 0; i < n; i++) RD_G1(out->ic[i], "vk.ic");
+
+    auto read_vec_g1 = [&](std::vector<G1Affine>& v, const char* what) -> int {
+        uint32_t cnt;
+        if (!rd.u32be(&cnt)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading |%s|", what);
+        const uint8_t* base;
+        if (!rd.take((size_t)cnt * 64, &base)) return fail(ctx, ZG_E_IO, "unexpected end of parameters inside %s", what);
+        v.resize(cnt);
+        std::atomic<int> bad{0};
+        parallel_chunks(cnt, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                PointStatus s = read_g1(base + 64 * i, checked, &v[i]);
+                if (s != PT_OK) bad.store((int)s);
+                else if (v[i].is_inf()) bad.store(100);
+            }
+        });
+        int bs = bad.load();
+        if (bs == 100) return fail(ctx, ZG_E_IO, "%s: point at infinity", what);
+        if (bs) return fail(ctx, ZG_E_IO, "%s: %s", what, status_str((PointStatus)bs));
+        return ZG_OK;
+    };
+    ZG_TRY(read_vec_g1(out->h, "h"));
+    ZG_TRY(read_vec_g1(out->l, "l"));
+    ZG_TRY(read_vec_g1(out->a, "a"));
+    ZG_TRY(read_vec_g1(out->b_g1, "b_g1"));
+    {
+        uint32_t cnt;
+        if (!rd.u32be(&cnt)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading |b_g2|");
+        const uint8_t* base;
+        if (!rd.take((size_t)cnt * 128, &base)) return fail(ctx, ZG_E_IO, "unexpected end of parameters inside b_g2");
+        out->b_g2.resize(cnt);
+        std::atomic<int> bad{0};
+        parallel_chunks(cnt, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                PointStatus s = read_g2(base + 128 * i, checked, b2, &out->b_g2[i]);
+                if (s != PT_OK) bad.store((int)s);
+                else if (out->b_g2[i].is_inf()) bad.store(100);
+            }
+        });
+        int bs = bad.load();
+        if (bs == 100) return fail(ctx, ZG_E_IO, "b_g2: point at infinity");
+        if (bs) return fail(ctx, ZG_E_IO, "b_g2: %s", status_str((PointStatus)bs));
+    }
+    if (consumed) *consumed = rd.pos;
+    return ZG_OK;
+#undef RD_G1
+#undef RD_G2
+}
+
+static void put_g1(std::vector<uint8_t>* o, const G1Affine& p) {
+    size_t at = o->size();
+    o->resize(at + 64, 0);
+    if (p.is_inf()) { (*o)[at] = 0x40; return; }
+    fq_to_be(o->data() + at, p.x);
+    fq_to_be(o->data() + at + 32, p.y);
+}
+static void put_g2(std::vector<uint8_t>* o, const G2Affine& p) {
+    size_t at = o->size();
+    o->resize(at + 128, 0);
+    if (p.is_inf()) { (*o)[at] = 0x40; return; }
+    fq_to_be(o->data() + at, p.x.c1);
+    fq_to_be(o->data() + at + 32, p.x.c0);
+    fq_to_be(o->data() + at + 64, p.y.c1);
+    fq_to_be(o->data() + at + 96, p.y.c0);
+}
+static void put_u32be(std::vector<uint8_t>* o, uint32_t v) {
+    o->push_back((uint8_t)(v >> 24)); o->push_back((uint8_t)(v >> 16));
+    o->push_back((uint8_t)(v >> 8)); o->push_back((uint8_t)v);
+}
+
+void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out) {
+    put_g1(out, p.alpha_g1); put_g1(out, p.beta_g1); put_g2(out, p.beta_g2); put_g2(out, p.gamma_g2);
+    put_g1(out, p.delta_g1); put_g2(out, p.delta_g2);
+    put_u32be(out, (uint32_t)p.ic.size());
+    for (auto& x : p.ic) put_g1(out, x);
+    for (const std::vector<G1Affine>* v : {&p.h, &p.l, &p.a, &p.b_g1}) {
+        put_u32be(out, (uint32_t)v->size());
+        for (auto& x : *v) put_g1(out, x);
+    }
+    put_u32be(out, (uint32_t)p.b_g2.size());
+    for (auto& x : p.b_g2) put_g2(out, x);
+}
+
+// za container: u32be len || bincode(asts); u32be n_constraints, each u32be len || bincode(QEQ);
+// u32be n_ignore, each u32be id; then the bellman Parameters body (format.rs:223-252).
+int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) {
+    Reader rd{pk, len};
+    uint32_t n;
+    const uint8_t* b;
+    if (!rd.u32be(&n) || !rd.take(n, &b)) return ZG_E_IO;
+    uint32_t nc;
+    if (!rd.u32be(&nc)) return ZG_E_IO;
+    for (uint32_t i = 0; i < nc; i++) {
+        if (!rd.u32be(&n) || !rd.take(n, &b)) return ZG_E_IO;
+    }
+    uint32_t ni;
+    if (!rd.u32be(&ni) || !rd.take((size_t)ni * 4, &b)) return ZG_E_IO;
+    *offset = rd.pos;
+    return ZG_OK;
+}
+
+// decimal string of a 256-bit little-endian integer
+static std::string dec_of_le32(const uint8_t* le) {
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++)
+        w[i] = (uint32_t)le[4 * i] | ((uint32_t)le[4 * i + 1] << 8) | ((uint32_t)le[4 * i + 2] << 16) |
+               ((uint32_t)le[4 * i + 3] << 24);
+    std::string rev;
+    for (;;) {
+        bool nz = false;
+        uint64_t rem = 0;
+        for (int i = 7; i >= 0; i--) {
+            uint64_t cur = (rem << 32) | w[i];
+            w[i] = (uint32_t)(cur / 1000000000ull);
+            rem = cur % 1000000000ull;
+            if (w[i]) nz = true;
+        }
+        if (!nz) {
+            // last group without zero padding
+            std::string g = std::to_string(rem);
+            for (auto it = g.rbegin(); it != g.rend(); ++it) rev.push_back(*it);
+            break;
+        }
+        for (int k = 0; k < 9; k++) {
+            rev.push_back((char)('0' + rem % 10));
+            rem /= 10;
+        }
+    }
+    return std::string(rev.rbegin(), rev.rend());
+}
+
+int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, std::string* out) {
+    auto hex = [&](int k) {
+        static const char* d = "0123456789abcdef";
+        std::string s = "\"0x";
+        for (int i = 0; i < 32; i++) {
+            s.push_back(d[proof[32 * k + i] >> 4]);
+            s.push_back(d[proof[32 * k + i] & 15]);
+        }
+        s.push_back('"');
+        return s;
+    };
+    std::string j = "{\"a\":[" + hex(0) + "," + hex(1) + "],\"b\":[[" + hex(2) + "," + hex(3) + "],[" + hex(4) + "," +
+                    hex(5) + "]],\"c\":[" + hex(6) + "," + hex(7) + "],\"public_inputs\":[";
+    for (size_t i = 0; i < n_public; i++) {
+        if (i) j.push_back(',');
+        j += "\"" + dec_of_le32(public_inputs32 + 32 * i) + "\"";
+    }
+    j += "]}";
+    *out = j;
+    return ZG_OK;
+}
+
+}  // namespace zg

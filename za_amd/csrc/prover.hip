@@ -1,0 +1,695 @@
+// Groth16 create_proof on one MI355X plus the C ABI (include/za_amd.h).
+//
+// Mirrors bellman_ce::groth16::create_proof as called by za through create_random_proof
+// (prover/src/groth16/prover.rs:173): R1CS evaluation (ProvingAssignment::enforce/eval), the H
+// polynomial, the multiexps over h / l / a / b_g1 / b_g2 and the final combination with r, s.
+// Everything heavy runs in HIP kernels; the host only sequences launches and does the O(1)
+// final group arithmetic.  There is no CPU fallback: zg_init fails without a GPU.
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <cstdarg>
+#include <cstring>
+#include <random>
+
+#include "common.h"
+#include "formats.h"
+
+namespace zg {
+
+int fail(Ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->last_error = buf;
+    }
+    return code;
+}
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+// coefficient c (canonical) -> c * 2^512 mod r, so that mont_mul(coeff, w_canonical) = c*w in Montgomery form
+__global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = c[i].to_mont().to_mont();
+}
+
+// out[row] = sum_e coeff[e] * w[col[e]]  for one CSR matrix; one thread per row
+__global__ void __launch_bounds__(256) k_r1cs_eval(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                   const Fr* __restrict__ coeff, const Fr* __restrict__ w,
+                                                   uint64_t n_rows, Fr* __restrict__ out) {
+    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    Fr acc = Fr::zero();
+    for (uint64_t e = row_ptr[row], end = row_ptr[row + 1]; e < end; e++) acc = acc + coeff[e] * w[col[e]];
+    out[row] = acc;
+}
+// the `input_i * 0 = 0` rows: a[n + i] = w_i (Montgomery); b, c stay zero
+__global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, Fr* __restrict__ a_tail) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inputs) a_tail[i] = w[i].to_mont();
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+struct zg_ctx : public zg::Ctx {};
+
+struct zg_r1cs {
+    uint32_t n_inputs = 0, n_aux = 0;
+    uint64_t n_constraints = 0;
+    uint32_t log_m = 0;
+    DevBuf row_ptr[3], col[3], coeff[3];
+    // dense position -> flat variable index for the a and b queries
+    DevBuf a_index, b_index;
+    uint64_t n_a = 0, n_b = 0;
+    uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
+};
+
+struct zg_params {
+    G1Affine alpha_g1, beta_g1, delta_g1;
+    G2Affine beta_g2, delta_g2;
+    struct Query {
+        DevBuf buf;
+        uint64_t total = 0, lo = 0, hi = 0;
+    } q[5];  // h, l, a, b_g1, b_g2
+    int rank = 0, world = 1;
+};
+
+// ------------------------------------------------------------------------------------------------ ctx
+extern "C" int zg_init(int device, zg_ctx** out) {
+    if (!out) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZG_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZG_E_NO_DEVICE;
+    zg_ctx* c = new zg_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZG_E_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return ZG_OK;
+}
+extern "C" void zg_free(zg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ntt_tables_free(ctx);
+    msm_scratch_free(ctx);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+extern "C" const char* zg_strerror(int code) {
+    switch (code) {
+        case ZG_OK: return "ok";
+        case ZG_E_ASSIGNMENT_MISSING: return "AssignmentMissing";
+        case ZG_E_DIVISION_BY_ZERO: return "DivisionByZero";
+        case ZG_E_UNSATISFIABLE: return "Unsatisfiable";
+        case ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE: return "PolynomialDegreeTooLarge";
+        case ZG_E_UNEXPECTED_IDENTITY: return "UnexpectedIdentity";
+        case ZG_E_IO: return "IoError";
+        case ZG_E_MALFORMED_VERIFYING_KEY: return "MalformedVerifyingKey";
+        case ZG_E_UNCONSTRAINED_VARIABLE: return "UnconstrainedVariable";
+        case ZG_E_BAD_FORMAT: return "BadFormat";
+        case ZG_E_QUERY_SIZE: return "query size does not match density";
+        case ZG_E_INVALID_ARG: return "invalid argument";
+        case ZG_E_BUFFER_TOO_SMALL: return "buffer too small";
+        case ZG_E_HIP: return "HIP runtime error";
+        case ZG_E_NO_DEVICE: return "no MI355X/HIP device available (no CPU fallback)";
+        default: return "unknown error";
+    }
+}
+extern "C" const char* zg_last_error(const zg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+extern "C" int zg_set_stream(zg_ctx* ctx, void* hip_stream) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ZG_OK;
+}
+extern "C" int zg_sync(zg_ctx* ctx) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+extern "C" int zg_dev_alloc(zg_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
+    return ZG_OK;
+}
+extern "C" int zg_dev_free(zg_ctx* ctx, void* d_ptr) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZG_HIP(ctx, hipFree(d_ptr));
+    return ZG_OK;
+}
+extern "C" int zg_h2d(zg_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+extern "C" int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) {
+    if (!ctx || !ms) return ZG_E_INVALID_ARG;
+    for (int i = 0; i < 6; i++) ms[i] = ctx->timings[i];
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ point <-> bytes
+template <class F>
+static void jac_bytes(uint8_t* out, const XYZZ<F>& p) {
+    constexpr size_t FB = sizeof(F);
+    if (p.is_inf()) {
+        memset(out, 0, 3 * FB);
+        return;
+    }
+    Affine<F> a = p.to_affine();
+    F one = F::one();
+    memcpy(out, &a.x, FB);
+    memcpy(out + FB, &a.y, FB);
+    memcpy(out + 2 * FB, &one, FB);
+}
+template <class F>
+static XYZZ<F> jac_from_bytes(const uint8_t* in) {
+    constexpr size_t FB = sizeof(F);
+    F x, y, z;
+    memcpy(&x, in, FB);
+    memcpy(&y, in + FB, FB);
+    memcpy(&z, in + 2 * FB, FB);
+    if (z.is_zero()) return XYZZ<F>::inf();
+    // general Jacobian (X, Y, Z) -> XYZZ (X, Y, Z^2, Z^3)
+    F zz = z.sqr();
+    return XYZZ<F>{x, y, zz, zz * z};
+}
+
+// ------------------------------------------------------------------------------------------------ MSM API
+template <class F>
+static int msm_host(zg_ctx* ctx, const uint8_t* bases, size_t n_bases, const uint8_t* scalars,
+                    const uint64_t* density_bits, size_t n_scalars, uint8_t* out_jac) {
+    if (!ctx || !out_jac || (n_bases && !bases) || (n_scalars && !scalars)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> index;
+    if (density_bits) {
+        index.reserve(n_bases);
+        for (size_t i = 0; i < n_scalars; i++)
+            if ((density_bits[i >> 6] >> (i & 63)) & 1) index.push_back((uint32_t)i);
+        if (index.size() != n_bases)
+            return fail(ctx, ZG_E_QUERY_SIZE, "density total %zu != number of bases %zu", index.size(), n_bases);
+    } else if (n_bases != n_scalars) {
+        return fail(ctx, ZG_E_QUERY_SIZE, "full density: %zu scalars but %zu bases", n_scalars, n_bases);
+    }
+    DevBuf db, ds, di;
+    ZG_HIP(ctx, db.alloc(n_bases * sizeof(Affine<F>)));
+    ZG_HIP(ctx, ds.alloc(n_scalars * 32));
+    ZG_HIP(ctx, hipMemcpyAsync(db.p, bases, n_bases * sizeof(Affine<F>), hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipMemcpyAsync(ds.p, scalars, n_scalars * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (density_bits) {
+        ZG_HIP(ctx, di.alloc(index.size() * 4));
+        ZG_HIP(ctx, hipMemcpyAsync(di.p, index.data(), index.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    XYZZ<F> r;
+    int rc;
+    if constexpr (sizeof(F) == sizeof(Fq))
+        rc = msm_g1(ctx, db.as<G1Affine>(), ds.as<uint32_t>(), density_bits ? di.as<uint32_t>() : nullptr, n_bases, &r);
+    else
+        rc = msm_g2(ctx, db.as<G2Affine>(), ds.as<uint32_t>(), density_bits ? di.as<uint32_t>() : nullptr, n_bases, &r);
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (rc) return rc;
+    jac_bytes(out_jac, r);
+    return ZG_OK;
+}
+extern "C" int zg_msm_g1(zg_ctx* ctx, const uint8_t* bases64, size_t n_bases, const uint8_t* scalars32,
+                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[96]) {
+    return msm_host<Fq>(ctx, bases64, n_bases, scalars32, density_bits, n_scalars, out_jac);
+}
+extern "C" int zg_msm_g2(zg_ctx* ctx, const uint8_t* bases128, size_t n_bases, const uint8_t* scalars32,
+                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[192]) {
+    return msm_host<Fq2>(ctx, bases128, n_bases, scalars32, density_bits, n_scalars, out_jac);
+}
+extern "C" int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars, const uint32_t* d_scalar_index,
+                             size_t n, uint8_t out_jac[96]) {
+    if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    G1XYZZ r;
+    ZG_TRY(msm_g1(ctx, (const G1Affine*)d_bases, (const uint32_t*)d_scalars, d_scalar_index, n, &r));
+    jac_bytes(out_jac, r);
+    return ZG_OK;
+}
+extern "C" int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars, const uint32_t* d_scalar_index,
+                             size_t n, uint8_t out_jac[192]) {
+    if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    G2XYZZ r;
+    ZG_TRY(msm_g2(ctx, (const G2Affine*)d_bases, (const uint32_t*)d_scalars, d_scalar_index, n, &r));
+    jac_bytes(out_jac, r);
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NTT / H API
+extern "C" int zg_ntt_fr_dev(zg_ctx* ctx, void* d_inout, uint32_t log_m, int inverse, int coset) {
+    if (!ctx || !d_inout) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    return ntt_fr_dev(ctx, (Fr*)d_inout, log_m, inverse != 0, coset != 0);
+}
+extern "C" int zg_ntt_fr(zg_ctx* ctx, uint8_t* inout, uint32_t log_m, int inverse, int coset) {
+    if (!ctx || !inout) return ZG_E_INVALID_ARG;
+    if (log_m >= 28) return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u >= 2^28", log_m);
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)32 << log_m;
+    DevBuf d;
+    ZG_HIP(ctx, d.alloc(bytes));
+    ZG_HIP(ctx, hipMemcpyAsync(d.p, inout, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(ntt_fr_dev(ctx, d.as<Fr>(), log_m, inverse != 0, coset != 0));
+    ZG_HIP(ctx, hipMemcpyAsync(inout, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t n_rows,
+                            uint32_t log_m, uint8_t* h_out) {
+    if (!ctx || !a || !b || !c || !h_out) return ZG_E_INVALID_ARG;
+    if (log_m >= 28) return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u >= 2^28", log_m);
+    const size_t m = (size_t)1 << log_m;
+    if (n_rows > m) return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "%zu rows do not fit a 2^%u domain", n_rows, log_m);
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d[3], dh;
+    const uint8_t* src[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) {
+        ZG_HIP(ctx, d[k].alloc(m * 32));
+        ZG_HIP(ctx, hipMemsetAsync(d[k].p, 0, m * 32, ctx->stream));
+        ZG_HIP(ctx, hipMemcpyAsync(d[k].p, src[k], n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ZG_HIP(ctx, dh.alloc(m * 32));
+    ZG_TRY(h_poly_dev(ctx, d[0].as<Fr>(), d[1].as<Fr>(), d[2].as<Fr>(), log_m, dh.as<Fr>()));
+    if (m > 1) ZG_HIP(ctx, hipMemcpyAsync(h_out, dh.p, (m - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ R1CS
+extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
+                            const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                            const uint8_t* const coeff[3], zg_r1cs** out) {
+    if (!ctx || !out || !row_ptr || !col || !coeff || n_inputs == 0) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t rows = n_constraints + n_inputs;
+    uint32_t log_m = 0;
+    while (((uint64_t)1 << log_m) < rows) log_m++;
+    if (log_m >= 28)
+        return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "%llu constraints + %u inputs need a domain >= 2^28",
+                    (unsigned long long)n_constraints, n_inputs);
+    const uint64_t nvars = (uint64_t)n_inputs + n_aux;
+    for (int k = 0; k < 3; k++) {
+        if (!row_ptr[k]) return ZG_E_INVALID_ARG;
+        uint64_t nnz = row_ptr[k][n_constraints];
+        if (nnz && (!col[k] || !coeff[k])) return ZG_E_INVALID_ARG;
+        for (uint64_t e = 0; e < nnz; e++)
+            if (col[k][e] >= nvars) return fail(ctx, ZG_E_INVALID_ARG, "matrix %d: variable index %u out of range", k, col[k][e]);
+    }
+    std::unique_ptr<zg_r1cs> r(new zg_r1cs());
+    r->n_inputs = n_inputs;
+    r->n_aux = n_aux;
+    r->n_constraints = n_constraints;
+    r->log_m = log_m;
+    // densities by MENTION (bellman's DensityTracker::inc in ProvingAssignment::eval)
+    std::vector<uint8_t> a_aux(n_aux, 0), b_in(n_inputs, 0), b_aux(n_aux, 0);
+    for (uint64_t e = 0, nnz = row_ptr[0][n_constraints]; e < nnz; e++) {
+        uint32_t v = col[0][e];
+        if (v >= n_inputs) a_aux[v - n_inputs] = 1;
+    }
+    for (uint64_t e = 0, nnz = row_ptr[1][n_constraints]; e < nnz; e++) {
+        uint32_t v = col[1][e];
+        if (v >= n_inputs) b_aux[v - n_inputs] = 1;
+        else b_in[v] = 1;
+    }
+    std::vector<uint32_t> a_index, b_index;
+    for (uint32_t i = 0; i < n_inputs; i++) a_index.push_back(i);  // A inputs: full density
+    for (uint32_t i = 0; i < n_aux; i++)
+        if (a_aux[i]) { a_index.push_back(n_inputs + i); r->a_aux_total++; }
+    for (uint32_t i = 0; i < n_inputs; i++)
+        if (b_in[i]) { b_index.push_back(i); r->b_in_total++; }
+    for (uint32_t i = 0; i < n_aux; i++)
+        if (b_aux[i]) { b_index.push_back(n_inputs + i); r->b_aux_total++; }
+    r->n_a = a_index.size();
+    r->n_b = b_index.size();
+    hipStream_t st = ctx->stream;
+    ZG_HIP(ctx, r->a_index.alloc(a_index.size() * 4));
+    ZG_HIP(ctx, r->b_index.alloc(b_index.size() * 4));
+    ZG_HIP(ctx, hipMemcpyAsync(r->a_index.p, a_index.data(), a_index.size() * 4, hipMemcpyHostToDevice, st));
+    if (!b_index.empty())
+        ZG_HIP(ctx, hipMemcpyAsync(r->b_index.p, b_index.data(), b_index.size() * 4, hipMemcpyHostToDevice, st));
+    for (int k = 0; k < 3; k++) {
+        uint64_t nnz = row_ptr[k][n_constraints];
+        ZG_HIP(ctx, r->row_ptr[k].alloc((n_constraints + 1) * 8));
+        ZG_HIP(ctx, r->col[k].alloc(nnz * 4));
+        ZG_HIP(ctx, r->coeff[k].alloc(nnz * 32));
+        ZG_HIP(ctx, hipMemcpyAsync(r->row_ptr[k].p, row_ptr[k], (n_constraints + 1) * 8, hipMemcpyHostToDevice, st));
+        if (nnz) {
+            ZG_HIP(ctx, hipMemcpyAsync(r->col[k].p, col[k], nnz * 4, hipMemcpyHostToDevice, st));
+            ZG_HIP(ctx, hipMemcpyAsync(r->coeff[k].p, coeff[k], nnz * 32, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_coeff_prepare, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
+                               r->coeff[k].as<Fr>(), (size_t)nnz);
+        }
+    }
+    ZG_HIP(ctx, hipStreamSynchronize(st));
+    ZG_HIP(ctx, hipGetLastError());
+    *out = r.release();
+    return ZG_OK;
+}
+extern "C" void zg_r1cs_free(zg_r1cs* r) { delete r; }
+extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) {
+    if (!r || !info) return ZG_E_INVALID_ARG;
+    info[0] = r->n_inputs; info[1] = r->n_aux; info[2] = r->n_constraints; info[3] = r->log_m;
+    info[4] = r->a_aux_total; info[5] = r->b_in_total; info[6] = r->b_aux_total;
+    return ZG_OK;
+}
+
+// d_abc[k]: m Montgomery elements (zero padded), rows = n_constraints + n_inputs
+static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3]) {
+    const size_t m = (size_t)1 << r->log_m;
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < 3; k++) {
+        // only the padding and the input rows need clearing, but a full memset is one cheap launch
+        ZG_HIP(ctx, hipMemsetAsync(d_abc[k] + r->n_constraints, 0, (m - r->n_constraints) * sizeof(Fr), st));
+        if (r->n_constraints)
+            hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, st,
+                               r->row_ptr[k].as<uint64_t>(), r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), d_w,
+                               r->n_constraints, d_abc[k]);
+    }
+    hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
+                       d_abc[0] + r->n_constraints);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+extern "C" int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint8_t* a_out, uint8_t* b_out,
+                            uint8_t* c_out) {
+    if (!ctx || !r || !a_out || !b_out || !c_out) return ZG_E_INVALID_ARG;
+    if (!witness32) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)1 << r->log_m, nv = (size_t)r->n_inputs + r->n_aux, rows = r->n_constraints + r->n_inputs;
+    DevBuf dw, d[3];
+    ZG_HIP(ctx, dw.alloc(nv * 32));
+    ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    Fr* abc[3];
+    for (int k = 0; k < 3; k++) {
+        ZG_HIP(ctx, d[k].alloc(m * 32));
+        abc[k] = d[k].as<Fr>();
+    }
+    ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc));
+    uint8_t* outs[3] = {a_out, b_out, c_out};
+    for (int k = 0; k < 3; k++)
+        ZG_HIP(ctx, hipMemcpyAsync(outs[k], d[k].p, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ params
+static void shard_range(uint64_t total, int rank, int world, uint64_t* lo, uint64_t* hi) {
+    uint64_t chunk = (total + world - 1) / world;
+    uint64_t l = std::min<uint64_t>(total, (uint64_t)rank * chunk);
+    *lo = l;
+    *hi = std::min<uint64_t>(total, l + chunk);
+}
+
+static int params_upload(zg_ctx* ctx, zg_params* p, int which, const void* host, uint64_t total, size_t elem) {
+    auto& q = p->q[which];
+    q.total = total;
+    shard_range(total, p->rank, p->world, &q.lo, &q.hi);
+    ZG_HIP(ctx, q.buf.alloc((q.hi - q.lo) * elem));
+    if (q.hi > q.lo)
+        ZG_HIP(ctx, hipMemcpyAsync(q.buf.p, (const uint8_t*)host + q.lo * elem, (q.hi - q.lo) * elem,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    return ZG_OK;
+}
+
+extern "C" int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const uint8_t* h, size_t n_h, const uint8_t* l,
+                                   size_t n_l, const uint8_t* a, size_t n_a, const uint8_t* b_g1, size_t n_b_g1,
+                                   const uint8_t* b_g2, size_t n_b_g2, int rank, int world, zg_params** out) {
+    if (!ctx || !vk5 || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<zg_params> p(new zg_params());
+    p->rank = rank;
+    p->world = world;
+    memcpy(&p->alpha_g1, vk5, 64);
+    memcpy(&p->beta_g1, vk5 + 64, 64);
+    memcpy(&p->beta_g2, vk5 + 128, 128);
+    memcpy(&p->delta_g1, vk5 + 256, 64);
+    memcpy(&p->delta_g2, vk5 + 320, 128);
+    ZG_TRY(params_upload(ctx, p.get(), 0, h, n_h, 64));
+    ZG_TRY(params_upload(ctx, p.get(), 1, l, n_l, 64));
+    ZG_TRY(params_upload(ctx, p.get(), 2, a, n_a, 64));
+    ZG_TRY(params_upload(ctx, p.get(), 3, b_g1, n_b_g1, 64));
+    ZG_TRY(params_upload(ctx, p.get(), 4, b_g2, n_b_g2, 128));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = p.release();
+    return ZG_OK;
+}
+
+extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank, int world,
+                              zg_params** out, size_t* consumed) {
+    if (!ctx || !bellman_params || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ParsedParams pp;
+    ZG_TRY(parse_bellman_params(ctx, bellman_params, len, checked != 0, &pp, consumed));
+    std::unique_ptr<zg_params> p(new zg_params());
+    p->rank = rank;
+    p->world = world;
+    p->alpha_g1 = pp.alpha_g1; p->beta_g1 = pp.beta_g1; p->delta_g1 = pp.delta_g1;
+    p->beta_g2 = pp.beta_g2; p->delta_g2 = pp.delta_g2;
+    ZG_TRY(params_upload(ctx, p.get(), 0, pp.h.data(), pp.h.size(), 64));
+    ZG_TRY(params_upload(ctx, p.get(), 1, pp.l.data(), pp.l.size(), 64));
+    ZG_TRY(params_upload(ctx, p.get(), 2, pp.a.data(), pp.a.size(), 64));
+    ZG_TRY(params_upload(ctx, p.get(), 3, pp.b_g1.data(), pp.b_g1.size(), 64));
+    ZG_TRY(params_upload(ctx, p.get(), 4, pp.b_g2.data(), pp.b_g2.size(), 128));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = p.release();
+    return ZG_OK;
+}
+extern "C" void zg_params_free(zg_params* p) { delete p; }
+extern "C" int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi) {
+    if (!p || which < 0 || which > 4 || !lo || !hi) return ZG_E_INVALID_ARG;
+    *lo = p->q[which].lo;
+    *hi = p->q[which].hi;
+    return ZG_OK;
+}
+extern "C" int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) {
+    if (!pk || !offset) return ZG_E_INVALID_ARG;
+    return pk_params_offset(pk, len, offset);
+}
+
+// ------------------------------------------------------------------------------------------------ prove
+static int check_query_sizes(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) {
+    const uint64_t m = (uint64_t)1 << r->log_m;
+    if (p->q[0].total < m - 1)
+        return fail(ctx, ZG_E_QUERY_SIZE, "h query has %llu points, need %llu", (unsigned long long)p->q[0].total,
+                    (unsigned long long)(m - 1));
+    if (p->q[1].total < r->n_aux)
+        return fail(ctx, ZG_E_QUERY_SIZE, "l query has %llu points, need %u", (unsigned long long)p->q[1].total, r->n_aux);
+    if (p->q[2].total != r->n_a)
+        return fail(ctx, ZG_E_QUERY_SIZE, "a query has %llu points, densities give %llu",
+                    (unsigned long long)p->q[2].total, (unsigned long long)r->n_a);
+    if (p->q[3].total != r->n_b || p->q[4].total != r->n_b)
+        return fail(ctx, ZG_E_QUERY_SIZE, "b queries have %llu/%llu points, densities give %llu",
+                    (unsigned long long)p->q[3].total, (unsigned long long)p->q[4].total, (unsigned long long)r->n_b);
+    return ZG_OK;
+}
+
+extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+    if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)1 << r->log_m;
+    double t0 = now_ms();
+    DevBuf d[3];
+    Fr* abc[3];
+    for (int k = 0; k < 3; k++) {
+        ZG_HIP(ctx, d[k].alloc(m * sizeof(Fr)));
+        abc[k] = d[k].as<Fr>();
+    }
+    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double t1 = now_ms();
+    ZG_TRY(h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double t2 = now_ms();
+    ctx->timings[1] = t1 - t0;
+    ctx->timings[2] = t2 - t1;
+    return ZG_OK;
+}
+
+extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
+                                     const void* d_h_shard, uint8_t partials[ZG_PARTIALS_BYTES]) {
+    if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_TRY(check_query_sizes(ctx, p, r));
+    const uint64_t m = (uint64_t)1 << r->log_m;
+    const uint32_t* w = (const uint32_t*)d_witness;
+    double t0 = now_ms();
+    G1XYZZ h_acc, l_acc, a_acc, b1_acc;
+    G2XYZZ b2_acc;
+    {   // h: first m-1 points of the query; this shard holds [lo, hi)
+        const auto& q = p->q[0];
+        uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
+        uint64_t n = hi > q.lo ? hi - q.lo : 0;
+        if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
+        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), (const uint32_t*)d_h_shard, nullptr, n, &h_acc));
+    }
+    {   // l: aux assignment, full density
+        const auto& q = p->q[1];
+        uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
+        uint64_t n = hi > q.lo ? hi - q.lo : 0;
+        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w + 8 * ((size_t)r->n_inputs + q.lo), nullptr, n, &l_acc));
+    }
+    {   // a: inputs (full density) then aux by a_aux_density
+        const auto& q = p->q[2];
+        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w, r->a_index.as<uint32_t>() + q.lo, q.hi - q.lo, &a_acc));
+    }
+    {
+        const auto& q = p->q[3];
+        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w, r->b_index.as<uint32_t>() + q.lo, q.hi - q.lo, &b1_acc));
+    }
+    {
+        const auto& q = p->q[4];
+        ZG_TRY(msm_g2(ctx, q.buf.as<G2Affine>(), w, r->b_index.as<uint32_t>() + q.lo, q.hi - q.lo, &b2_acc));
+    }
+    jac_bytes(partials, h_acc);
+    jac_bytes(partials + 96, l_acc);
+    jac_bytes(partials + 192, a_acc);
+    jac_bytes(partials + 288, b1_acc);
+    jac_bytes(partials + 384, b2_acc);
+    ctx->timings[3] = now_ms() - t0;
+    return ZG_OK;
+}
+
+static void scalar_words(uint32_t out[8], const uint8_t le[32]) { memcpy(out, le, 32); }
+
+extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world,
+                                const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+    if (!ctx || !p || !partials_all || world < 1 || !r_le || !s_le || !proof_out) return ZG_E_INVALID_ARG;
+    double t0 = now_ms();
+    G1XYZZ h_acc = G1XYZZ::inf(), l_acc = G1XYZZ::inf(), a_ans = G1XYZZ::inf(), b1_ans = G1XYZZ::inf();
+    G2XYZZ b2_ans = G2XYZZ::inf();
+    for (int k = 0; k < world; k++) {
+        const uint8_t* q = partials_all + (size_t)k * ZG_PARTIALS_BYTES;
+        h_acc = h_acc.add(jac_from_bytes<Fq>(q));
+        l_acc = l_acc.add(jac_from_bytes<Fq>(q + 96));
+        a_ans = a_ans.add(jac_from_bytes<Fq>(q + 192));
+        b1_ans = b1_ans.add(jac_from_bytes<Fq>(q + 288));
+        b2_ans = b2_ans.add(jac_from_bytes<Fq2>(q + 384));
+    }
+    if (p->delta_g1.is_inf() || p->delta_g2.is_inf()) return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "vk.delta is the identity");
+    uint32_t r[8], s[8], rs[8];
+    scalar_words(r, r_le);
+    scalar_words(s, s_le);
+    {
+        Fr fr_r, fr_s;
+        memcpy(&fr_r, r, 32);
+        memcpy(&fr_s, s, 32);
+        Fr prod = (fr_r.to_mont() * fr_s.to_mont()).from_mont();
+        memcpy(rs, &prod, 32);
+    }
+    const G1XYZZ delta1 = G1XYZZ::from_affine(p->delta_g1), alpha = G1XYZZ::from_affine(p->alpha_g1),
+                 beta1 = G1XYZZ::from_affine(p->beta_g1);
+    const G2XYZZ delta2 = G2XYZZ::from_affine(p->delta_g2);
+    // A = alpha + r*delta + sum a
+    G1XYZZ g_a = delta1.mul(r).add_mixed(p->alpha_g1).add(a_ans);
+    // B = beta2 + s*delta2 + sum b2
+    G2XYZZ g_b = delta2.mul(s).add_mixed(p->beta_g2).add(b2_ans);
+    // C = rs*delta + s*alpha + r*beta1 + s*(sum a) + r*(sum b1) + sum h + sum l
+    G1XYZZ g_c = delta1.mul(rs).add(alpha.mul(s)).add(beta1.mul(r)).add(a_ans.mul(s)).add(b1_ans.mul(r)).add(h_acc).add(l_acc);
+    G1Affine A = g_a.to_affine(), C = g_c.to_affine();
+    G2Affine B = g_b.to_affine();
+    if (A.is_inf() || B.is_inf() || C.is_inf())
+        return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "a proof element is the identity (BadFormat(\"invalid point\") in za)");
+    fq_to_be(proof_out, A.x); fq_to_be(proof_out + 32, A.y);
+    fq_to_be(proof_out + 64, B.x.c0); fq_to_be(proof_out + 96, B.x.c1);
+    fq_to_be(proof_out + 128, B.y.c0); fq_to_be(proof_out + 160, B.y.c1);
+    fq_to_be(proof_out + 192, C.x); fq_to_be(proof_out + 224, C.y);
+    ctx->timings[4] = now_ms() - t0;
+    return ZG_OK;
+}
+
+extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
+                            const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+    if (!ctx || !p || !r || !proof_out || !r_le || !s_le) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "zg_prove needs an unsharded key (world = 1); use the phase API");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    double t0 = now_ms();
+    ZG_TRY(check_query_sizes(ctx, p, r));
+    const size_t m = (size_t)1 << r->log_m;
+    DevBuf dh;
+    ZG_HIP(ctx, dh.alloc(m * 32));
+    ZG_TRY(zg_prove_h_dev(ctx, r, d_witness, dh.p));
+    uint8_t partials[ZG_PARTIALS_BYTES];
+    ZG_TRY(zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials));
+    ZG_TRY(zg_prove_combine(ctx, p, partials, 1, r_le, s_le, proof_out));
+    ctx->timings[5] = now_ms() - t0;
+    return ZG_OK;
+}
+
+extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
+                        const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+    if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
+    if (!witness32) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    double t0 = now_ms();
+    const size_t nv = (size_t)r->n_inputs + r->n_aux;
+    DevBuf dw;
+    ZG_HIP(ctx, dw.alloc(nv * 32));
+    ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double t1 = now_ms();
+    int rc = zg_prove_dev(ctx, p, r, dw.p, r_le, s_le, proof_out);
+    ctx->timings[0] = t1 - t0;
+    ctx->timings[5] = now_ms() - t0;
+    return rc;
+}
+
+extern "C" int zg_prove_random(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
+                               uint8_t proof_out[256]) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    std::random_device rd;
+    uint8_t rs[2][32];
+    for (int k = 0; k < 2; k++) {
+        // uniform below 2^253 < r: ample for blinding, always canonical
+        for (int i = 0; i < 32; i += 4) {
+            uint32_t v = rd();
+            memcpy(rs[k] + i, &v, 4);
+        }
+        rs[k][31] &= 0x1f;
+    }
+    return zg_prove(ctx, p, r, witness32, rs[0], rs[1], proof_out);
+}
+
+extern "C" int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, char* out,
+                             size_t cap) {
+    if (!proof || !out || (n_public && !public_inputs32)) return ZG_E_INVALID_ARG;
+    std::string j;
+    proof_json(proof, public_inputs32, n_public, &j);
+    if (j.size() >= cap) return ZG_E_BUFFER_TOO_SMALL;
+    memcpy(out, j.c_str(), j.size() + 1);
+    return ZG_OK;
+}
