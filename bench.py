@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the za_amd Groth16/BN254 prover hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--log-m 22]
+
+A "step" is one create_proof (zg_prove_dev) of the synthetic 2^log_m R1CS of config 4
+(SHA256-Merkle-like witness: 97 % bits, SplitMix64 seed 0x5A) with R1CS, proving key and witness
+already resident in HBM; r, s are fixed.  N > 1 is launched by torch.distributed.run, one rank per
+GPU: the MSMs shard by base chunk, the NTT stays on rank 0 (za_amd/dist.py).  Rank 0 prints ONE JSON
+line.  `roofline` is for the dominant kernel (G1 bucket accumulation) from HIP-event timings taken
+inside the timed region; `cpu_baseline` times the oracle (a port of bellman's CPU algorithm) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
+    ap.add_argument("--bit-fraction", type=float, default=0.97)
+    ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
+    ap.add_argument("--cpu-log-m", type=int, default=17, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-only", action="store_true", help="also time a standalone 2^log_m G1 MSM (uniform scalars)")
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, args):
+    """Oracle prove (bellman-algorithm CPU port) on a 2^cpu_log_m instance of the same workload."""
+    from oracle import coracle as co
+    from za_amd import synth
+    lg = min(args.cpu_log_m, args.log_m)
+    sr = synth.SynthR1CS(lg, 2, args.bit_fraction, args.seed)
+    r1 = sr.load(ctx)
+    m = 1 << lg
+    n_a = 2 + r1.a_aux_total
+    n_b = r1.b_input_total + r1.b_aux_total
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 1000)
+    # download the synthetic key for the CPU run
+    import ctypes as C
+    vk5 = np.zeros(448, dtype=np.uint8)
+    ctx._check(ctx.lib.zg_params_download(P.h, C.c_int(-1), vk5.ctypes.data_as(C.c_void_p), C.c_size_t(448)))
+    arrs = []
+    for which, elem in ((0, 64), (1, 64), (2, 64), (3, 64), (4, 128)):
+        tot = P.query_total(which)
+        a = np.zeros(max(tot, 1) * elem, dtype=np.uint8)
+        ctx._check(ctx.lib.zg_params_download(P.h, C.c_int(which), a.ctypes.data_as(C.c_void_p), C.c_size_t(tot * elem)))
+        arrs.append(a[: tot * elem])
+    mp = co.MontParams(vk5[0:64].tobytes(), vk5[64:128].tobytes(), vk5[128:256].tobytes(), vk5[256:320].tobytes(),
+                       vk5[320:448].tobytes(), *arrs)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    t0 = time.time()
+    proof_cpu, tm = co.prove(mp, csr, sr.witness, 5, 7, threads=threads, timings=True)
+    dt = time.time() - t0
+    d_w = ctx.upload(sr.witness)
+    proof_gpu = ctx.prove_dev(P, r1, d_w, 5, 7)
+    ok = proof_cpu == proof_gpu
+    ctx.free(d_w)
+    P.close(); r1.close()
+    n = sr.n_constraints
+    sr.close()
+    return {"value": n / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "oracle/c create_proof (bellman-algorithm port, %d threads) on the same synthetic workload at "
+                      "2^%d constraints: %.2f s (r1cs %.2f, H %.2f, MSM %.2f); proof bytes equal to the GPU's: %s"
+                      % (threads, lg, dt, tm[0], tm[1], tm[2], ok)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus),
+              file=sys.stderr)
+        sys.exit(2)
+    import torch
+    import za_amd
+    from za_amd import synth
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = za_amd.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- workload (untimed set-up): R1CS + witness + proving key resident in HBM
+    t_setup = time.time()
+    sr = synth.SynthR1CS(args.log_m, 2, args.bit_fraction, args.seed)
+    r1 = sr.load(ctx)
+    m = 1 << args.log_m
+    n_a = sr.n_inputs + r1.a_aux_total
+    n_b = r1.b_input_total + r1.b_aux_total
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 7000, rank=rank, world=world)
+    d_w = ctx.upload(sr.witness)
+    n_constraints = sr.n_constraints
+    nnz = list(sr.nnz)
+    n_aux = sr.n_aux
+    sr.close()
+    t_setup = time.time() - t_setup
+    r_blind, s_blind = 0x1234567, 0x7654321
+
+    if world > 1:
+        from za_amd.dist import GpuEngine, sharded_prove
+        engine = GpuEngine(ctx, P, r1, d_w, world)
+
+        def step():
+            return sharded_prove(engine, r_blind, s_blind)
+    else:
+        def step():
+            return ctx.prove_dev(P, r1, d_w, r_blind, s_blind)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    proof = None
+    for _ in range(args.warmup):
+        proof = step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    phases = ctx.last_timings()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    msm_line = None
+    if args.msm_only and world == 1:
+        d_b = synth.synth_bases_g1(ctx, m, 4242)
+        d_s = synth.synth_scalars(ctx, m, 99)
+        ctx.msm_g1_dev(d_b, d_s, m)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ctx.msm_g1_dev(d_b, d_s, m)
+        torch.cuda.synchronize()
+        msm_line = {"g1_msm_points_per_s": 3 * m / (time.perf_counter() - t1), "points": m}
+        ctx.free(d_b); ctx.free(d_s)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        acc_ms, acc_n, acc_bytes = prof["msm_accumulate_g1"]
+        roof = None
+        if acc_n:
+            achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("msm_accumulate_g1_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "launches": acc_n, "avg_launch_ms": acc_ms / acc_n,
+                    "algorithmic_bytes_per_launch": acc_bytes / acc_n}
+        line = {
+            "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
+            "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 Montgomery (256-bit modular integer)", "data": "synthetic",
+            "config": {"workload": "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
+                                   "seed 0x%x), n_constraints + n_inputs = 2^%d, synthetic proving key with known "
+                                   "discrete logs" % (100 * args.bit_fraction, args.seed, args.log_m),
+                       "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
+                       "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
+            "roofline": roof,
+            "phases_ms_last_step": phases,
+            "kernel_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
+            "setup_s": t_setup,
+            "proof_sha": __import__("hashlib").sha256(bytes(proof)).hexdigest()[:16] if proof is not None else None,
+        }
+        if msm_line:
+            line["g1_msm"] = msm_line
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(ctx, args)
+            except Exception as e:  # the bench line must still come out
+                line["cpu_baseline"] = {"error": repr(e)}
+        elif world > 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

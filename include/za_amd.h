@@ -177,6 +177,8 @@ int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partia
                      const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */
 int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi);
+/* Full (unsharded) length of query `which`. */
+int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
 
 /* ---- formats ---------------------------------------------------------------------------------
  * proof.json exactly as JsonProofAndInput::write emits it (prover/src/groth16/format.rs:80-128):
@@ -189,6 +191,15 @@ int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size
 /* ---- timing of the last zg_prove* call on this ctx (milliseconds, GPU events + host clock):
  * [0] witness upload, [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
+
+/* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline
+ * line.  id: 0 msm_accumulate_g1, 1 msm_accumulate_g2, 2 msm_digit_sort, 3 msm_bucket_reduce,
+ * 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval.  alg_bytes = algorithmic HBM bytes of the timed launches. */
+#define ZG_PROFILE_KERNELS 7
+int zg_profile_enable(zg_ctx* ctx, int on);
+int zg_profile_reset(zg_ctx* ctx);
+int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes);
+const char* zg_profile_name(int id);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,52 @@
+/* za_amd synthetic workloads -- NOT part of the drop-in boundary.
+ *
+ * Generators for the benchmark configurations of BASELINE.json / SURVEY.md section 8(d): the za
+ * compiler (which would produce the R1CS and witness) and bellman's generate_random_parameters
+ * (which would produce the proving key) are out of scope for this round, so bench.py and the
+ * full-size parity tests build their inputs here.  The prover treats them like any other input.
+ */
+#ifndef ZA_AMD_SYNTH_H
+#define ZA_AMD_SYNTH_H
+#include "za_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zg_synth zg_synth;
+
+/* Synthetic satisfiable R1CS with n_constraints + n_inputs = 2^log_m exactly and a
+ * consistent witness, SplitMix64-seeded.  Row i defines a fresh aux variable:
+ *   with probability bit_fraction:  (2a)*(b) = a + b - c   (c = a XOR b over earlier bit variables),
+ *   otherwise:                      (k1 x + k2 y)*(k3 z + k4 t) = c   with uniform Fr coefficients.
+ * bit_fraction = 0.97 gives the SHA256-Merkle-like witness statistics of config 4; 0.0 the
+ * uniform-Fr config 5.  64 seed aux variables precede the defined ones. */
+int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_fraction, uint64_t seed, zg_synth** out);
+/* info: n_inputs, n_aux, n_constraints, nnz(A), nnz(B), nnz(C) */
+int zg_synth_r1cs_info(const zg_synth* s, uint64_t info[6]);
+/* which: 0-2 row_ptr[k] (u64), 3-5 col[k] (u32), 6-8 coeff[k] (32 B canonical LE), 9 witness (32 B canonical LE) */
+const void* zg_synth_ptr(const zg_synth* s, int which);
+void zg_synth_free(zg_synth* s);
+
+/* d_out[i] = k_i * G with k_i = splitmix64(seed + i) (a known discrete log, so MSM results can be
+ * checked as (sum s_i k_i) * G).  Affine Montgomery LE, 64 B (G1) / 128 B (G2) per point. */
+int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);
+int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);
+/* Proving key whose queries are zg_synth_bases_* arrays (seeds seed+1.. for h, l, a, b_g1; b_g2 uses
+ * the b_g1 discrete logs) and vk elements alpha = 3G, beta = 5G, delta = 7G.  Not a valid CRS: it
+ * exercises exactly the prover's arithmetic, with every discrete log known to the tests. */
+int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t seed,
+                        int rank, int world, zg_params** out);
+/* k_i for the generators above */
+uint64_t zg_synth_dlog(uint64_t seed, uint64_t i);
+/* d_out[i] = uniform scalar below 2^253 from splitmix64 (canonical LE), for standalone MSM runs */
+int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);
+
+/* Copy this handle's resident shard of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2), or with
+ * which = -1 the five vk points (448 bytes, zg_params_from_mont order), back to host memory. */
+int zg_params_download(const zg_params* p, int which, void* out, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -36,8 +36,9 @@ ABI_SYMBOLS = [
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
-    "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range",
+    "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_proof_json", "zg_last_timings",
+    "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_name",
 ]
 
 
@@ -254,6 +255,22 @@ class Context:
                                               _ptr(out)))
         return out.tobytes()
 
+    def profile_enable(self, on=True):
+        self._check(self.lib.zg_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_reset(self):
+        self._check(self.lib.zg_profile_reset(self.h))
+
+    def profile_get(self):
+        """{kernel class: (total ms, launches, algorithmic bytes)} since the last reset."""
+        self.lib.zg_profile_name.restype = C.c_char_p
+        out = {}
+        for i in range(7):
+            ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
+            self._check(self.lib.zg_profile_get(self.h, C.c_int(i), C.byref(ms), C.byref(n), C.byref(b)))
+            out[self.lib.zg_profile_name(C.c_int(i)).decode()] = (ms.value, n.value, b.value)
+        return out
+
     def last_timings(self):
         t = (C.c_double * 6)()
         self._check(self.lib.zg_last_timings(self.h, t))
@@ -289,6 +306,15 @@ class Params:
         lo, hi = C.c_uint64(), C.c_uint64()
         self.ctx._check(self.ctx.lib.zg_params_shard_range(self.h, C.c_int(which), C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def query_total(self, which):
+        t = C.c_uint64()
+        self.ctx._check(self.ctx.lib.zg_params_query_total(self.h, C.c_int(which), C.byref(t)))
+        return t.value
+
+    @property
+    def total_h(self):
+        return self.query_total(0)
 
     def close(self):
         if self.h:

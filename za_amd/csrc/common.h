@@ -19,6 +19,11 @@ struct Ctx {
     int num_cu = 256;
     std::string last_error;
     double timings[6] = {0, 0, 0, 0, 0, 0};
+    // optional per-kernel timing with HIP events on `stream` (zg_profile_*)
+    bool prof_enabled = false;
+    struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes; };
+    std::vector<ProfPending> prof_pending;
+    struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
     // reusable MSM scratch, see msm.hip
@@ -26,6 +31,22 @@ struct Ctx {
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
+
+// kernel classes timed by the profiling facility
+enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,
+              PROF_R1CS_EVAL, PROF_COUNT };
+struct ProfScope {
+    Ctx* c; int idx = -1;
+    ProfScope(Ctx* ctx, int id, uint64_t alg_bytes) : c(ctx) {
+        if (!ctx->prof_enabled) return;
+        Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes};
+        if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+        (void)hipEventRecord(p.e0, ctx->stream);
+        ctx->prof_pending.push_back(p);
+        idx = (int)ctx->prof_pending.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_pending[idx].e1, c->stream); }
+};
 
 #define ZG_HIP(ctx, expr)                                                                      \
     do {                                                                                       \

@@ -1,0 +1,27 @@
+// Opaque handle layouts behind include/za_amd.h (shared by prover.hip and synth.hip).
+#pragma once
+#include "common.h"
+
+struct zg_ctx : public zg::Ctx {};
+
+struct zg_r1cs {
+    uint32_t n_inputs = 0, n_aux = 0;
+    uint64_t n_constraints = 0;
+    uint32_t log_m = 0;
+    zg::DevBuf row_ptr[3], col[3], coeff[3];
+    // dense position -> flat variable index for the a and b queries
+    zg::DevBuf a_index, b_index;
+    uint64_t n_a = 0, n_b = 0;
+    uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
+};
+
+struct zg_params {
+    zg::G1Affine alpha_g1, beta_g1, delta_g1;
+    zg::G2Affine beta_g2, delta_g2;
+    struct Query {
+        zg::DevBuf buf;
+        uint64_t total = 0, lo = 0, hi = 0;
+    } q[5];  // h, l, a, b_g1, b_g2
+    int rank = 0, world = 1;
+};
+

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <memory>
 
 #include "common.h"
 
@@ -374,7 +375,10 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
     ZG_HIP(ctx, S.meta.reserve((size_t)(MAXWIN + 4) * 4));
     ZG_HIP(ctx, hipMemsetAsync(S.counts.p, 0, (size_t)(nkeys + 1) * 4, st));
 
+    constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
+    constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
     int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
+    std::unique_ptr<ProfScope> ps(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
     hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin,
                        S.counts.as<uint32_t>(), (uint32_t*)nullptr);
 
@@ -389,6 +393,7 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
                        S.cursor.as<uint32_t>());
     hipLaunchKernelGGL(k_meta, dim3(1), dim3(MAXWIN + 1), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                        nkeys, P.B, P.nwin, S.meta.as<uint32_t>());
+    ps.reset();
     uint32_t meta[MAXWIN + 4];
     ZG_HIP(ctx, hipMemcpyAsync(meta, S.meta.p, (size_t)(P.nwin + 3) * 4, hipMemcpyDeviceToHost, st));
     ZG_HIP(ctx, hipStreamSynchronize(st));
@@ -398,13 +403,16 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
     ZG_HIP(ctx, S.sorted.reserve((size_t)total_entries * 4));
     ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
     ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
+    ps.reset(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
     hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin,
                        S.cursor.as<uint32_t>(), S.sorted.as<uint32_t>());
     hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(), nkeys,
                        S.item_key.as<uint32_t>());
+    ps.reset(new ProfScope(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES));
     hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
                        S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                        S.item_key.as<uint32_t>(), total_items, P.T, S.partial.as<XYZZ<F>>());
+    ps.reset();
 
     // stage 2 geometry: ~16 items per thread
     WinTable tab;
@@ -423,10 +431,12 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
     tab.chunk_lo[P.nwin] = chunks;
     ZG_HIP(ctx, S.chunk_out.reserve((size_t)chunks * sizeof(XYZZ<F>)));
     ZG_HIP(ctx, S.win_out.reserve((size_t)P.nwin * sizeof(XYZZ<F>)));
+    ps.reset(new ProfScope(ctx, PROF_MSM_REDUCE, 0));
     hipLaunchKernelGGL((k_reduce_chunks<F>), dim3((chunks + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
                        S.item_key.as<uint32_t>(), tab, P.nwin, P.B, S.chunk_out.as<XYZZ<F>>());
     hipLaunchKernelGGL((k_reduce_windows<F>), dim3(P.nwin), dim3(128), 128 * sizeof(XYZZ<F>), st,
                        S.chunk_out.as<XYZZ<F>>(), tab, S.win_out.as<XYZZ<F>>());
+    ps.reset();
     std::vector<XYZZ<F>> win(P.nwin);
     ZG_HIP(ctx, hipMemcpyAsync(win.data(), S.win_out.p, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ZG_HIP(ctx, hipStreamSynchronize(st));

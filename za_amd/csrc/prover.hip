@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "formats.h"
+#include "handles.h"
 
 namespace zg {
 
@@ -60,29 +61,6 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, Fr* __
 }  // namespace zg
 
 using namespace zg;
-
-struct zg_ctx : public zg::Ctx {};
-
-struct zg_r1cs {
-    uint32_t n_inputs = 0, n_aux = 0;
-    uint64_t n_constraints = 0;
-    uint32_t log_m = 0;
-    DevBuf row_ptr[3], col[3], coeff[3];
-    // dense position -> flat variable index for the a and b queries
-    DevBuf a_index, b_index;
-    uint64_t n_a = 0, n_b = 0;
-    uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
-};
-
-struct zg_params {
-    G1Affine alpha_g1, beta_g1, delta_g1;
-    G2Affine beta_g2, delta_g2;
-    struct Query {
-        DevBuf buf;
-        uint64_t total = 0, lo = 0, hi = 0;
-    } q[5];  // h, l, a, b_g1, b_g2
-    int rank = 0, world = 1;
-};
 
 // ------------------------------------------------------------------------------------------------ ctx
 extern "C" int zg_init(int device, zg_ctx** out) {
@@ -171,6 +149,47 @@ extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) {
     if (!ctx || !ms) return ZG_E_INVALID_ARG;
     for (int i = 0; i < 6; i++) ms[i] = ctx->timings[i];
     return ZG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+extern "C" int zg_profile_enable(zg_ctx* ctx, int on) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ctx->prof_enabled = on != 0;
+    return ZG_OK;
+}
+static int prof_drain(zg_ctx* ctx) {
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& p : ctx->prof_pending) {
+        float ms = 0;
+        if (p.e0 && p.e1 && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            ctx->prof[p.id].ms += ms;
+            ctx->prof[p.id].launches += 1;
+            ctx->prof[p.id].bytes += p.bytes;
+        }
+        if (p.e0) (void)hipEventDestroy(p.e0);
+        if (p.e1) (void)hipEventDestroy(p.e1);
+    }
+    ctx->prof_pending.clear();
+    return ZG_OK;
+}
+extern "C" int zg_profile_reset(zg_ctx* ctx) {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    ZG_TRY(prof_drain(ctx));
+    for (auto& s : ctx->prof) s = zg::Ctx::ProfStat();
+    return ZG_OK;
+}
+extern "C" int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
+    if (!ctx || id < 0 || id >= PROF_COUNT || !ms || !launches || !alg_bytes) return ZG_E_INVALID_ARG;
+    ZG_TRY(prof_drain(ctx));
+    *ms = ctx->prof[id].ms;
+    *launches = ctx->prof[id].launches;
+    *alg_bytes = ctx->prof[id].bytes;
+    return ZG_OK;
+}
+extern "C" const char* zg_profile_name(int id) {
+    static const char* names[] = {"msm_accumulate_g1", "msm_accumulate_g2", "msm_digit_sort", "msm_bucket_reduce",
+                                  "ntt_pass", "ntt_pointwise", "r1cs_eval"};
+    return id >= 0 && id < PROF_COUNT ? names[id] : "";
 }
 
 // ------------------------------------------------------------------------------------------------ point <-> bytes
@@ -386,6 +405,9 @@ extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) {
 static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3]) {
     const size_t m = (size_t)1 << r->log_m;
     hipStream_t st = ctx->stream;
+    uint64_t nnz_total = 0;
+    for (int k = 0; k < 3; k++) nnz_total += r->col[k].bytes / 4;
+    ProfScope ps(ctx, PROF_R1CS_EVAL, 36 * nnz_total + 96 * (r->n_constraints + r->n_inputs));
     for (int k = 0; k < 3; k++) {
         // only the padding and the input rows need clearing, but a full memset is one cheap launch
         ZG_HIP(ctx, hipMemsetAsync(d_abc[k] + r->n_constraints, 0, (m - r->n_constraints) * sizeof(Fr), st));
@@ -491,6 +513,11 @@ extern "C" int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo
     if (!p || which < 0 || which > 4 || !lo || !hi) return ZG_E_INVALID_ARG;
     *lo = p->q[which].lo;
     *hi = p->q[which].hi;
+    return ZG_OK;
+}
+extern "C" int zg_params_query_total(const zg_params* p, int which, uint64_t* total) {
+    if (!p || which < 0 || which > 4 || !total) return ZG_E_INVALID_ARG;
+    *total = p->q[which].total;
     return ZG_OK;
 }
 extern "C" int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) {

@@ -1,0 +1,278 @@
+// Synthetic workloads for bench.py and the full-size parity tests (include/za_amd_synth.h).
+// Not part of the drop-in boundary: stands in for the za compiler's R1CS + witness output and for
+// bellman's generate_random_parameters, which are out of scope this round.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/za_amd_synth.h"
+#include "common.h"
+#include "handles.h"
+
+using namespace zg;
+
+static inline uint64_t splitmix64_at(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ static inline uint64_t splitmix64_hd(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct zg_synth {
+    uint32_t n_inputs = 0, n_aux = 0;
+    uint64_t n_constraints = 0;
+    std::vector<uint64_t> row_ptr[3];
+    std::vector<uint32_t> col[3];
+    std::vector<uint8_t> coeff[3];
+    std::vector<uint8_t> witness;
+};
+
+namespace {
+struct Rng {
+    uint64_t seed, ctr = 0;
+    uint64_t next() { return splitmix64_at(seed, ctr++); }
+    Fr fr() {  // uniform below 2^253, Montgomery form
+        Fr c;
+        for (int i = 0; i < 4; i++) {
+            uint64_t v = next();
+            c.l[2 * i] = (uint32_t)v;
+            c.l[2 * i + 1] = (uint32_t)(v >> 32);
+        }
+        c.l[7] &= 0x1fffffffu;
+        return c.to_mont();
+    }
+};
+void push_term(zg_synth* s, int k, uint32_t var, const Fr& coeff_mont) {
+    s->col[k].push_back(var);
+    Fr c = coeff_mont.from_mont();
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(&c);
+    s->coeff[k].insert(s->coeff[k].end(), b, b + 32);
+}
+}  // namespace
+
+extern "C" int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_fraction, uint64_t seed, zg_synth** out) {
+    if (!out || log_m >= 28 || n_inputs == 0 || ((uint64_t)1 << log_m) <= n_inputs) return ZG_E_INVALID_ARG;
+    const uint64_t m = (uint64_t)1 << log_m;
+    const uint64_t n = m - n_inputs;
+    const uint32_t n_seed = 64;
+    std::unique_ptr<zg_synth> s(new zg_synth());
+    s->n_inputs = n_inputs;
+    s->n_constraints = n;
+    s->n_aux = (uint32_t)(n + n_seed);
+    const size_t nv = (size_t)n_inputs + s->n_aux;
+    std::vector<Fr> w(nv);  // Montgomery
+    Rng rng{seed};
+    const Fr one = Fr::one(), two = Fr::from_u64(2), minus_one = one.neg();
+    std::vector<uint32_t> bits;
+    bits.reserve(nv);
+    w[0] = one;
+    for (uint32_t i = 1; i < n_inputs; i++) w[i] = rng.fr();
+    for (uint32_t i = 0; i < n_seed; i++) {
+        uint32_t v = n_inputs + i;
+        if (i & 1) {
+            w[v] = rng.fr();
+        } else {
+            w[v] = (rng.next() & 1) ? one : Fr::zero();
+            bits.push_back(v);
+        }
+    }
+    const uint64_t thresh = bit_fraction >= 1.0 ? ~0ull : (uint64_t)(bit_fraction * 18446744073709551615.0);
+    for (int k = 0; k < 3; k++) {
+        s->row_ptr[k].reserve(n + 1);
+        s->row_ptr[k].push_back(0);
+    }
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t c = n_inputs + n_seed + (uint32_t)i;
+        const bool bit_row = bit_fraction > 0.0 && rng.next() <= thresh;
+        if (bit_row) {
+            uint32_t a = bits[rng.next() % bits.size()];
+            uint32_t b = bits[(rng.next() % bits.size()) & ~(size_t)1];
+            // (2a) * b = a + b - c   <=>   c = a xor b
+            push_term(s.get(), 0, a, two);
+            push_term(s.get(), 1, b, one);
+            push_term(s.get(), 2, a, one);
+            push_term(s.get(), 2, b, one);
+            push_term(s.get(), 2, c, minus_one);
+            w[c] = w[a] + w[b] - two * w[a] * w[b];
+            bits.push_back(c);
+        } else {
+            uint32_t x = (uint32_t)(rng.next() % c), y = (uint32_t)(rng.next() % c);
+            uint32_t z = (uint32_t)(rng.next() % c), t = (uint32_t)(rng.next() % c);
+            Fr k1 = rng.fr(), k2 = rng.fr(), k3 = rng.fr(), k4 = rng.fr();
+            push_term(s.get(), 0, x, k1);
+            push_term(s.get(), 0, y, k2);
+            push_term(s.get(), 1, z, k3);
+            push_term(s.get(), 1, t, k4);
+            push_term(s.get(), 2, c, one);
+            w[c] = (k1 * w[x] + k2 * w[y]) * (k3 * w[z] + k4 * w[t]);
+        }
+        for (int k = 0; k < 3; k++) s->row_ptr[k].push_back(s->col[k].size());
+    }
+    s->witness.resize(nv * 32);
+    for (size_t i = 0; i < nv; i++) {
+        Fr c = w[i].from_mont();
+        memcpy(s->witness.data() + 32 * i, &c, 32);
+    }
+    *out = s.release();
+    return ZG_OK;
+}
+
+extern "C" int zg_synth_r1cs_info(const zg_synth* s, uint64_t info[6]) {
+    if (!s || !info) return ZG_E_INVALID_ARG;
+    info[0] = s->n_inputs; info[1] = s->n_aux; info[2] = s->n_constraints;
+    for (int k = 0; k < 3; k++) info[3 + k] = s->col[k].size();
+    return ZG_OK;
+}
+extern "C" const void* zg_synth_ptr(const zg_synth* s, int which) {
+    if (!s || which < 0 || which > 9) return nullptr;
+    if (which < 3) return s->row_ptr[which].data();
+    if (which < 6) return s->col[which - 3].data();
+    if (which < 9) return s->coeff[which - 6].data();
+    return s->witness.data();
+}
+extern "C" void zg_synth_free(zg_synth* s) { delete s; }
+extern "C" uint64_t zg_synth_dlog(uint64_t seed, uint64_t i) { return splitmix64_at(seed, i); }
+
+// ------------------------------------------------------------------------------------------------ device generators
+template <class F>
+__global__ void __launch_bounds__(128) k_synth_bases(Affine<F>* __restrict__ out, size_t n, uint64_t seed, Affine<F> gen) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = splitmix64_hd(seed, i);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int b = 63; b >= 0; b--) {
+        acc = acc.dbl();
+        if ((k >> b) & 1) acc = acc.add_mixed(gen);
+    }
+    out[i] = acc.to_affine();
+}
+__global__ void __launch_bounds__(256) k_synth_scalars(uint32_t* __restrict__ out, size_t n, uint64_t seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a, b;
+    uint64_t v0 = splitmix64_hd(seed, 4 * i), v1 = splitmix64_hd(seed, 4 * i + 1), v2 = splitmix64_hd(seed, 4 * i + 2),
+             v3 = splitmix64_hd(seed, 4 * i + 3);
+    a.x = (uint32_t)v0; a.y = (uint32_t)(v0 >> 32); a.z = (uint32_t)v1; a.w = (uint32_t)(v1 >> 32);
+    b.x = (uint32_t)v2; b.y = (uint32_t)(v2 >> 32); b.z = (uint32_t)v3; b.w = (uint32_t)(v3 >> 32) & 0x1fffffffu;
+    reinterpret_cast<uint4*>(out)[2 * i] = a;
+    reinterpret_cast<uint4*>(out)[2 * i + 1] = b;
+}
+
+static G1Affine g1_generator() { return G1Affine{Fq::from_u64(1), Fq::from_u64(2)}; }
+static G2Affine g2_generator() {
+    // prover/src/groth16/ethereum.rs:28-31 (printed there as [c1, c0])
+    auto fq = [](uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t l5, uint32_t l6, uint32_t l7) {
+        Fq c;
+        c.l[0] = l0; c.l[1] = l1; c.l[2] = l2; c.l[3] = l3; c.l[4] = l4; c.l[5] = l5; c.l[6] = l6; c.l[7] = l7;
+        return c.to_mont();
+    };
+    G2Affine g;
+    // x.c0 = 0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed
+    g.x.c0 = fq(0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu);
+    // x.c1 = 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2
+    g.x.c1 = fq(0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u);
+    // y.c0 = 0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa
+    g.y.c0 = fq(0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u);
+    // y.c1 = 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b
+    g.y.c1 = fq(0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u);
+    return g;
+}
+
+extern "C" int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL((k_synth_bases<Fq>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (G1Affine*)d_out, n, seed, g1_generator());
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+extern "C" int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return ZG_OK;
+    G2Affine g = g2_generator();
+    if (!on_curve(g, Fq2{Fq::from_u64(3), Fq::zero()} * Fq2{Fq::from_u64(9), Fq::from_u64(1)}.inv()))
+        return fail(ctx, ZG_E_INVALID_ARG, "internal: G2 generator constant is not on the twist");
+    hipLaunchKernelGGL((k_synth_bases<Fq2>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (G2Affine*)d_out, n, seed, g);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_out, n,
+                       seed);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+extern "C" int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t seed,
+                                   int rank, int world, zg_params** out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<zg_params> p(new zg_params());
+    p->rank = rank;
+    p->world = world;
+    const G1XYZZ g1 = G1XYZZ::from_affine(g1_generator());
+    const G2XYZZ g2 = G2XYZZ::from_affine(g2_generator());
+    p->alpha_g1 = g1.mul_small(3).to_affine();
+    p->beta_g1 = g1.mul_small(5).to_affine();
+    p->beta_g2 = g2.mul_small(5).to_affine();
+    p->delta_g1 = g1.mul_small(7).to_affine();
+    p->delta_g2 = g2.mul_small(7).to_affine();
+    const uint64_t totals[5] = {n_h, n_l, n_a, n_b, n_b};
+    const uint64_t seeds[5] = {seed + 1, seed + 2, seed + 3, seed + 4, seed + 4};
+    for (int k = 0; k < 5; k++) {
+        auto& q = p->q[k];
+        q.total = totals[k];
+        uint64_t chunk = (q.total + world - 1) / world;
+        q.lo = std::min<uint64_t>(q.total, (uint64_t)rank * chunk);
+        q.hi = std::min<uint64_t>(q.total, q.lo + chunk);
+        const size_t elem = k == 4 ? 128 : 64;
+        ZG_HIP(ctx, q.buf.alloc((q.hi - q.lo) * elem));
+        // generator index i maps to global position lo + i: fold lo into the seed stream position
+        if (q.hi > q.lo) {
+            const size_t cnt = q.hi - q.lo;
+            // splitmix64_hd(seed, lo + i) == splitmix64_hd(seed + lo * GOLDEN, i)
+            const uint64_t s2 = seeds[k] + q.lo * 0x9E3779B97F4A7C15ull;
+            if (k == 4) ZG_TRY(zg_synth_bases_g2_dev(ctx, q.buf.p, cnt, s2));
+            else ZG_TRY(zg_synth_bases_g1_dev(ctx, q.buf.p, cnt, s2));
+        }
+    }
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = p.release();
+    return ZG_OK;
+}
+
+// Copy a resident query shard (which = 0..4) or the five vk points (which = -1, 448 bytes in the
+// zg_params_from_mont order) back to the host -- lets tests and the CPU baseline see a synthetic key.
+extern "C" int zg_params_download(const zg_params* p, int which, void* out, size_t bytes) {
+    if (!p || !out || which < -1 || which > 4) return ZG_E_INVALID_ARG;
+    if (which == -1) {
+        if (bytes < 448) return ZG_E_BUFFER_TOO_SMALL;
+        uint8_t* o = (uint8_t*)out;
+        memcpy(o, &p->alpha_g1, 64);
+        memcpy(o + 64, &p->beta_g1, 64);
+        memcpy(o + 128, &p->beta_g2, 128);
+        memcpy(o + 256, &p->delta_g1, 64);
+        memcpy(o + 320, &p->delta_g2, 128);
+        return ZG_OK;
+    }
+    const auto& q = p->q[which];
+    const size_t elem = which == 4 ? 128 : 64;
+    const size_t have = (q.hi - q.lo) * elem;
+    if (bytes < have) return ZG_E_BUFFER_TOO_SMALL;
+    if (have && hipMemcpy(out, q.buf.p, have, hipMemcpyDeviceToHost) != hipSuccess) return ZG_E_HIP;
+    return ZG_OK;
+}
