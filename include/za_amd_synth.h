@@ -46,6 +46,17 @@ int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);
  * which = -1 the five vk points (448 bytes, zg_params_from_mont order), back to host memory. */
 int zg_params_download(const zg_params* p, int which, void* out, size_t bytes);
 
+/* ---- self-test hooks (tests only) ----------------------------------------------------------------
+ * which: 0 Fq, 1 Fr; op: 0 mul, 1 add, 2 sub, 3 inv, 4 to_mont, 5 from_mont, 6 neg, 7 sqr; operands are
+ * n 32-byte Montgomery-LE values.  _host runs the library's host build of csrc/fp.h, _dev the gfx950 one. */
+int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+/* out = k*p (+ q when q != NULL) with the host curve code; group 1 = G1 (64 B affine), 2 = G2 (128 B). */
+int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out);
+/* Parse + validate a bellman Parameters body on the host (no GPU) and check write(read(x)) == x.
+ * counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, bytes consumed. */
+int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

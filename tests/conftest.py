@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    """libza_amd.so and the oracle library, built in-tree (hipcc cross-compiles without a GPU)."""
+    from za_amd import build as zbuild
+    zbuild.build()
+    from oracle import coracle
+    coracle.build()
+    import za_amd
+    return za_amd.load_library()
+
+
+@pytest.fixture(scope="session")
+def ctx(lib_built):
+    import za_amd
+    c = za_amd.Context(0)   # raises ZaAmdError(ZG_E_NO_DEVICE) without a GPU: no CPU fallback
+    yield c
+    c.close()

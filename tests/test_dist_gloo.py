@@ -1,0 +1,131 @@
+"""world_size-2 gloo test of the one-process-per-GPU orchestration (za_amd/dist.py) on CPU.
+
+The per-rank compute engine is backed by the oracle here (tests may use it; the product never does);
+what is under test is the sharding, the H scatter, the partial-sum all-gather and the combine order.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import bn254 as bn
+from oracle import coracle as co
+from oracle import groth16 as g
+from tests.util import golden, r1cs_from_fixture
+
+
+class OracleEngine:
+    """Same interface as za_amd.dist.GpuEngine, computed with the Python / C oracle on CPU tensors."""
+
+    def __init__(self, fx, rank, world):
+        from za_amd.dist import shard_range
+        self.device = torch.device("cpu")
+        self.rank, self.world = rank, world
+        self.r1 = r1cs_from_fixture(fx)
+        self.w = [int(x, 16) for x in fx["witness"]]
+        self.params, _ = g.params_read(bytes.fromhex(fx["params"]))
+        self.m = 1 << self.r1.domain_log()
+        self.n_h = len(self.params.h)
+        self.h_chunk_entries = (self.n_h + world - 1) // world
+        self.shard_range = shard_range
+        _, _, _, self.ad, self.bi, self.bd = g.eval_constraints(self.r1, self.w)
+
+    def compute_h(self):
+        h = g.h_coefficients(self.r1, self.w) + [0]
+        n = self.world * self.h_chunk_entries
+        h = h + [0] * (max(n, self.m) - len(h))
+        buf = b"".join(bn.le32(x) for x in h[:n])
+        return torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+
+    def _jac(self, P, fb):
+        if P is None:
+            return b"\0" * (3 * fb)
+        enc = bn.g1_to_mont_bytes(P) if fb == 32 else bn.g2_to_mont_bytes(P)
+        one = bn.le32(bn.mont(1, bn.Q)) + (b"\0" * 32 if fb == 64 else b"")
+        return enc + one
+
+    def partials(self, h_shard):
+        p, ni = self.params, self.r1.num_inputs
+        hs = [bn.from_le32(bytes(h_shard[32 * i:32 * i + 32].tolist())) for i in range(h_shard.numel() // 32)]
+        lo, hi = self.shard_range(self.n_h, self.rank, self.world)
+        hi = min(hi, self.m - 1)
+        h_acc = bn.msm_naive(p.h[lo:hi], hs[:max(hi - lo, 0)])
+        aux = self.w[ni:]
+        lo, hi = self.shard_range(len(p.l), self.rank, self.world)
+        l_acc = bn.msm_naive(p.l[lo:hi], aux[lo:hi])
+        a_idx = list(range(ni)) + [ni + i for i, d in enumerate(self.ad) if d]
+        b_idx = [i for i, d in enumerate(self.bi) if d] + [ni + i for i, d in enumerate(self.bd) if d]
+        lo, hi = self.shard_range(len(p.a), self.rank, self.world)
+        a_acc = bn.msm_naive(p.a[lo:hi], [self.w[i] for i in a_idx[lo:hi]])
+        lo, hi = self.shard_range(len(p.b_g1), self.rank, self.world)
+        b1 = bn.msm_naive(p.b_g1[lo:hi], [self.w[i] for i in b_idx[lo:hi]])
+        b2 = bn.msm_naive(p.b_g2[lo:hi], [self.w[i] for i in b_idx[lo:hi]])
+        buf = self._jac(h_acc, 32) + self._jac(l_acc, 32) + self._jac(a_acc, 32) + self._jac(b1, 32) + self._jac(b2, 64)
+        assert len(buf) == 576
+        return torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+
+    def combine(self, partials_all, world, r, s):
+        pa = bytes(partials_all)
+        acc = [None] * 5
+        for k in range(world):
+            q = pa[576 * k:576 * (k + 1)]
+            pts = [None if q[64 + 96 * i:96 + 96 * i] == b"\0" * 32 else bn.g1_from_mont_bytes(q[96 * i:96 * i + 64])
+                   for i in range(4)]
+            pts.append(None if q[384 + 128:384 + 192] == b"\0" * 64 else bn.g2_from_mont_bytes(q[384:384 + 128]))
+            acc = [bn.pt_add(x, y) for x, y in zip(acc, pts)]
+        h_acc, l_acc, a_ans, b1_ans, b2_ans = acc
+        vk = self.params.vk
+        A = bn.pt_add(bn.pt_add(bn.pt_mul(vk.delta_g1, r), vk.alpha_g1), a_ans)
+        B = bn.pt_add(bn.pt_add(bn.pt_mul(vk.delta_g2, s), vk.beta_g2), b2_ans)
+        Cc = bn.pt_add(bn.pt_add(bn.pt_mul(vk.delta_g1, r * s % bn.R), bn.pt_mul(vk.alpha_g1, s)), bn.pt_mul(vk.beta_g1, r))
+        Cc = bn.pt_add(Cc, bn.pt_mul(a_ans, s))
+        Cc = bn.pt_add(Cc, bn.pt_mul(b1_ans, r))
+        Cc = bn.pt_add(bn.pt_add(Cc, h_acc), l_acc)
+        return g.proof_bytes((A, B, Cc))
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from za_amd.dist import sharded_prove
+        fx = golden("proof_chain7.json")
+        eng = OracleEngine(fx, rank, world)
+        proof = sharded_prove(eng, int(fx["r"], 16), int(fx["s"], 16))
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                f.write(proof)
+        else:
+            assert proof is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_prove_over_gloo_matches_golden(tmp_path, world):
+    out = str(tmp_path / "proof.bin")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    fx = golden("proof_chain7.json")
+    assert open(out, "rb").read().hex() == fx["proof"]
+
+
+def test_shard_ranges_partition_exactly():
+    from za_amd.dist import shard_range
+    for total in (0, 1, 7, 127, 128, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))

@@ -1,0 +1,204 @@
+"""create_proof on the GPU (zg_prove*) -- bit-exact proof bytes against the golden fixtures and the C
+oracle, error behaviour mirroring bellman's SynthesisError cases, and the sharded phase API."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as bn
+from oracle import coracle as co
+from oracle import groth16 as g
+from tests.util import download_params, from_mont_bytes, golden, r1cs_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_fixture(ctx, fx):
+    r1 = r1cs_from_fixture(fx)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, used = ctx.params_load(bytes.fromhex(fx["params"]), checked=True)
+    assert used == len(fx["params"]) // 2
+    w = co.witness_bytes([int(x, 16) for x in fx["witness"]])
+    return R, P, w, csr
+
+
+@pytest.mark.parametrize("name", ["proof_factor.json", "proof_chain7.json"])
+def test_prove_matches_golden_bytes_and_json(ctx, name):
+    import za_amd
+    fx = golden(name)
+    R, P, w, _ = _load_fixture(ctx, fx)
+    assert [R.a_aux_total, R.b_input_total, R.b_aux_total] == [sum(fx["a_aux_density"]), sum(fx["b_input_density"]),
+                                                                sum(fx["b_aux_density"])]
+    proof = ctx.prove(P, R, w, int(fx["r"], 16), int(fx["s"], 16))
+    assert proof.hex() == fx["proof"]
+    wi = [int(x, 16) for x in fx["witness"]]
+    assert za_amd.proof_json(proof, wi[1:fx["n_inputs"]]) == fx["proof_json"]
+    a, b, c = R.eval(w)
+    assert from_mont_bytes(a, bn.R) == [int(x, 16) for x in fx["a"]]
+    assert from_mont_bytes(b, bn.R) == [int(x, 16) for x in fx["b"]]
+    assert from_mont_bytes(c, bn.R) == [int(x, 16) for x in fx["c"]]
+
+
+def test_prove_from_za_pk_container(ctx):
+    """proving.key as `za setup` writes it (format.rs:223-252): skip the header, read the bellman body."""
+    import za_amd
+    fx = golden("proof_factor.json")
+    pk = bytes.fromhex(fx["pk_container"])
+    off = za_amd.pk_params_offset(pk)
+    P, used = ctx.params_load(pk[off:])
+    assert off + used == len(pk)
+    R, _, w, _ = _load_fixture(ctx, fx)
+    assert ctx.prove(P, R, w, 5, 7).hex() == fx["proof"]
+
+
+def test_proof_verifies_under_the_pairing_equation(ctx):
+    """The reference's acceptance criterion (prover.rs:291-305) applied to the GPU's proof with fresh r, s."""
+    fx = golden("proof_chain7.json")
+    R, P, w, _ = _load_fixture(ctx, fx)
+    pb = ctx.prove(P, R, w, 0xDEADBEEF, 0xFEEDFACE)
+    v = [int.from_bytes(pb[32 * i:32 * i + 32], "big") for i in range(8)]
+    proof = ((bn.Fq(v[0]), bn.Fq(v[1])), (bn.Fq2(v[2], v[3]), bn.Fq2(v[4], v[5])), (bn.Fq(v[6]), bn.Fq(v[7])))
+    params, _ = g.params_read(bytes.fromhex(fx["params"]))
+    wi = [int(x, 16) for x in fx["witness"]]
+    pub = wi[1:fx["n_inputs"]]
+    assert g.verify_proof(params.vk, proof, pub)
+    assert not g.verify_proof(params.vk, proof, [(pub[0] + 1) % bn.R] + pub[1:])
+
+
+def test_random_blinding_still_verifies(ctx):
+    fx = golden("proof_factor.json")
+    R, P, w, _ = _load_fixture(ctx, fx)
+    out = np.zeros(256, dtype=np.uint8)
+    wa = np.frombuffer(w, dtype=np.uint8)
+    ctx._check(ctx.lib.zg_prove_random(ctx.h, P.h, R.h, wa.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    pb = out.tobytes()
+    assert pb.hex() != fx["proof"]
+    v = [int.from_bytes(pb[32 * i:32 * i + 32], "big") for i in range(8)]
+    proof = ((bn.Fq(v[0]), bn.Fq(v[1])), (bn.Fq2(v[2], v[3]), bn.Fq2(v[4], v[5])), (bn.Fq(v[6]), bn.Fq(v[7])))
+    params, _ = g.params_read(bytes.fromhex(fx["params"]))
+    assert g.verify_proof(params.vk, proof, [6])
+    assert not g.verify_proof(params.vk, proof, [7])
+
+
+def test_error_behaviour(ctx):
+    import za_amd
+    fx = golden("proof_chain7.json")
+    R, P, w, csr = _load_fixture(ctx, fx)
+    # AssignmentMissing: no witness
+    out = np.zeros(256, dtype=np.uint8)
+    rs = np.zeros(32, dtype=np.uint8)
+    rc = ctx.lib.zg_prove(ctx.h, P.h, R.h, None, rs.ctypes.data_as(C.c_void_p), rs.ctypes.data_as(C.c_void_p),
+                          out.ctypes.data_as(C.c_void_p))
+    assert rc == za_amd.ZG_E_ASSIGNMENT_MISSING
+    # key / circuit mismatch: multiexp's query-size assertion
+    fx2 = golden("proof_factor.json")
+    R2, P2, w2, _ = _load_fixture(ctx, fx2)
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.prove(P2, R, w, 1, 1)
+    assert e.value.code == za_amd.ZG_E_QUERY_SIZE
+    # UnexpectedIdentity: delta_g1 = identity
+    params, _ = g.params_read(bytes.fromhex(fx["params"]))
+    params.vk.delta_g1 = None
+    Pz, _ = ctx.params_load(g.params_write(params))
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.prove(Pz, R, w, 1, 1)
+    assert e.value.code == za_amd.ZG_E_UNEXPECTED_IDENTITY
+    # malformed key: IoError
+    bad = bytearray(bytes.fromhex(fx["params"])); bad[0] |= 0x80
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.params_load(bytes(bad))
+    assert e.value.code == za_amd.ZG_E_IO
+    # PolynomialDegreeTooLarge: constraints + inputs need a domain of 2^28 (Fr::S = 28)
+    rp = [np.zeros(1, dtype=np.uint64)] * 3
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.r1cs_load(2, 2, (1 << 27) + 1, rp, [np.zeros(1, np.uint32)] * 3, [np.zeros(32, np.uint8)] * 3)
+    assert e.value.code == za_amd.ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE
+
+
+@pytest.mark.parametrize("lg,bitf", [(10, 0.9), (12, 0.0), (14, 0.97)])
+def test_synthetic_circuits_against_c_oracle(ctx, lg, bitf):
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, 2, bitf, 1000 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 50 + lg)
+    mp = download_params(ctx, P)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    r, s = 0x1111 + lg, 0x2222 + lg
+    exp = co.prove(mp, csr, sr.witness, r, s, threads=16)
+    got = ctx.prove(P, R, sr.witness, r, s)
+    assert exp == got
+    sr.close()
+
+
+def test_sharded_phases_equal_the_unsharded_proof(ctx):
+    """world = 3 shards driven sequentially on one GPU: h -> partials per shard -> combine."""
+    from za_amd import synth
+    lg = 12
+    sr = synth.SynthR1CS(lg, 3, 0.8, 4242)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P1 = synth.synth_params(ctx, *sizes, 900)
+    d_w = ctx.upload(sr.witness)
+    r, s = 12345, 67890
+    whole = ctx.prove_dev(P1, R, d_w, r, s)
+    world = 3
+    d_h = ctx.alloc(32 * (m + world))
+    ctx.h2d(d_h, np.zeros(32 * (m + world), dtype=np.uint8))
+    ctx.prove_h_dev(R, d_w, d_h)
+    parts = []
+    for rank in range(world):
+        Pk = synth.synth_params(ctx, *sizes, 900, rank=rank, world=world)
+        lo, hi = Pk.shard_range(0)
+        assert Pk.total_h == m - 1
+        parts.append(ctx.prove_partials_dev(Pk, R, d_w, d_h + 32 * lo))
+    got = ctx.prove_combine(P1, np.concatenate(parts), world, r, s)
+    assert got == whole
+    sr.close()
+
+
+def test_full_size_proof_matches_discrete_log_expectation(ctx):
+    """2^20 constraints (config 3 size): with every base's discrete log known, the proof's three
+    elements are k*G for scalars computed independently (H from the C oracle)."""
+    from za_amd import synth
+    lg = 20
+    sr = synth.SynthR1CS(lg, 2, 0.97, 0x5A)
+    R = sr.load(ctx)
+    m = 1 << lg
+    n_a, n_b = sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total
+    seed = 7000
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, seed)
+    r, s = 0x1234567, 0x7654321
+    got = ctx.prove(P, R, sr.witness, r, s)
+    # independent expectation
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    a, b, c, ad, bi, bd = co.r1cs_eval(csr, sr.witness, threads=32)
+    h = co.h_coeffs(a, b, c, sr.n_constraints + sr.n_inputs, lg, threads=32)
+    wv = np.frombuffer(bytes(sr.witness), dtype="<u8").reshape(-1, 4)
+    hv = np.frombuffer(bytes(h), dtype="<u8").reshape(-1, 4)
+
+    def dot(vals, ks):
+        tot = 0
+        for row, k in zip(vals.tolist(), ks.tolist()):
+            tot += (row[0] | (row[1] << 64) | (row[2] << 128) | (row[3] << 192)) * k
+        return tot % bn.R
+    ni = sr.n_inputs
+    a_idx = np.concatenate([np.arange(ni), ni + np.nonzero(ad)[0]])
+    b_idx = np.concatenate([np.nonzero(bi)[0], ni + np.nonzero(bd)[0]])
+    assert len(a_idx) == n_a and len(b_idx) == n_b
+    sh = dot(hv, synth.splitmix64_array(seed + 1, m - 1))
+    sl = dot(wv[ni:], synth.splitmix64_array(seed + 2, sr.n_aux))
+    sa = dot(wv[a_idx], synth.splitmix64_array(seed + 3, n_a))
+    sb = dot(wv[b_idx], synth.splitmix64_array(seed + 4, n_b))
+    alpha, beta, delta = 3, 5, 7
+    eA = (alpha + sa + r * delta) % bn.R
+    eB = (beta + sb + s * delta) % bn.R
+    eC = (r * s * delta + s * alpha + r * beta + s * sa + r * sb + sh + sl) % bn.R
+    A = co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eA)
+    B = co.g2_mul(bn.g2_to_mont_bytes(bn.G2_GEN), eB)
+    Cc = co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eC)
+    pa, pb, pc = bn.g1_from_mont_bytes(A), bn.g2_from_mont_bytes(B), bn.g1_from_mont_bytes(Cc)
+    assert got == g.proof_bytes((pa, pb, pc))
+    sr.close()

@@ -1,0 +1,117 @@
+"""The pure-Python oracle against public anchors, its own identities and the committed golden vectors."""
+import random
+
+from oracle import bn254 as bn
+from oracle import groth16 as g
+from tests.util import golden, r1cs_from_fixture
+
+
+def test_curve_constants_and_public_anchor():
+    assert bn.is_on_curve(bn.G1_GEN, bn.G1_B) and bn.is_on_curve(bn.G2_GEN, bn.G2_B)
+    p2 = bn.pt_double(bn.G1_GEN)   # EIP-196 / alt_bn128 test value of 2*G1
+    assert p2[0].v == 1368015179489954701390400359078579693043519447331113978918064868415326638035
+    assert p2[1].v == 9918110051302171585080402603319702774565515993150576347155970296011118125764
+    assert bn.pt_mul(bn.G1_GEN, bn.R) is None and bn.pt_mul(bn.G2_GEN, bn.R) is None
+    assert pow(bn.FR_ROOT_OF_UNITY, 1 << 28, bn.R) == 1 and pow(bn.FR_ROOT_OF_UNITY, 1 << 27, bn.R) != 1
+
+
+def test_pairing_bilinear():
+    a, b = 1234567, 7654321
+    e1 = bn.pairing(bn.pt_mul(bn.G2_GEN, b), bn.pt_mul(bn.G1_GEN, a))
+    assert e1 == bn.pairing(bn.G2_GEN, bn.pt_mul(bn.G1_GEN, a * b))
+    assert not (e1 == bn.Fq12.one())
+
+
+def test_fft_matches_naive_dft_and_inverts():
+    rng = random.Random(1)
+    d = g.Domain(4)
+    a = [rng.randrange(bn.R) for _ in range(16)]
+    b = list(a)
+    d.fft(b)
+    assert b == g.dft_naive(a, d.omega)
+    d.ifft(b)
+    assert b == a
+    c = list(a)
+    d.coset_fft(c)
+    d.icoset_fft(c)
+    assert c == a
+
+
+def test_golden_proofs_verify_under_the_pairing_equation():
+    """The reference's own acceptance test (prover/src/groth16/prover.rs:291-305): verify(prove(x)) is
+    true, and false for a wrong public input."""
+    for name in ("proof_factor.json", "proof_chain7.json"):
+        fx = golden(name)
+        params, used = g.params_read(bytes.fromhex(fx["params"]))
+        assert used == len(fx["params"]) // 2
+        pb = bytes.fromhex(fx["proof"])
+        v = [int.from_bytes(pb[32 * i:32 * i + 32], "big") for i in range(8)]
+        proof = ((bn.Fq(v[0]), bn.Fq(v[1])), (bn.Fq2(v[2], v[3]), bn.Fq2(v[4], v[5])), (bn.Fq(v[6]), bn.Fq(v[7])))
+        w = [int(x, 16) for x in fx["witness"]]
+        pub = w[1:fx["n_inputs"]]
+        assert g.verify_proof(params.vk, proof, pub)
+        bad = list(pub)
+        bad[0] = (bad[0] + 1) % bn.R
+        assert not g.verify_proof(params.vk, proof, bad)
+
+
+def test_golden_proof_regenerates_and_matches_trapdoor():
+    fx = golden("proof_factor.json")
+    r1 = r1cs_from_fixture(fx)
+    w = [int(x, 16) for x in fx["witness"]]
+    td = [int(x, 16) for x in fx["trapdoor"]]
+    params, trap = g.generate_parameters(r1, *td)
+    assert g.params_write(params).hex() == fx["params"]
+    r, s = int(fx["r"], 16), int(fx["s"], 16)
+    proof = g.create_proof(r1, params, w, r, s)
+    assert g.proof_bytes(proof).hex() == fx["proof"]
+    assert g.proof_json(proof, w[1:2]) == fx["proof_json"]
+    eA, eB, eC = g.trapdoor_expected_proof(r1, trap, w, r, s)
+    assert proof == (bn.pt_mul(bn.G1_GEN, eA), bn.pt_mul(bn.G2_GEN, eB), bn.pt_mul(bn.G1_GEN, eC))
+    # public inputs of example/input.json: r = 6  (format.rs:94-97 prints decimal)
+    assert '"public_inputs":["6"]' in fx["proof_json"]
+
+
+def test_h_identity_at_random_point():
+    """a(t) b(t) - c(t) = h(t) Z(t) for the H the oracle computes."""
+    fx = golden("proof_chain7.json")
+    r1 = r1cs_from_fixture(fx)
+    w = [int(x, 16) for x in fx["witness"]]
+    h = [int(x, 16) for x in fx["h"]]
+    a, b, c, *_ = g.eval_constraints(r1, w)
+    d = g.Domain(r1.domain_log())
+    t = 0x1234567890abcdef
+    # Lagrange interpolation through ifft
+    co = []
+    for v in (a, b, c):
+        v = d.pad(v)
+        d.ifft(v)
+        co.append(sum(x * pow(t, i, bn.R) for i, x in enumerate(v)) % bn.R)
+    ht = sum(x * pow(t, i, bn.R) for i, x in enumerate(h)) % bn.R
+    assert (co[0] * co[1] - co[2]) % bn.R == ht * d.z(t) % bn.R
+
+
+def test_params_and_pk_container_round_trip():
+    fx = golden("proof_factor.json")
+    pk = bytes.fromhex(fx["pk_container"])
+    qeqs, ignore, off = g.pk_container_read(pk)
+    assert ignore == [] and len(qeqs) == 1
+    # za's QEQ for p*q===r: a = p, b = q, c = -r (constraint.rs:51: a*b + c = 0)
+    assert qeqs[0] == ([(2, 1)], [(3, 1)], [(1, bn.R - 1)])
+    assert pk[off:].hex() == fx["params"]
+    for bad_first_byte, msg in ((0x80, "compression"), (0x40, "infinity")):
+        buf = bytearray(bytes.fromhex(fx["params"]))
+        buf[0] |= bad_first_byte
+        try:
+            g.params_read(bytes(buf))
+            assert False
+        except ValueError as e:
+            assert msg in str(e)
+
+
+def test_bellman_multiexp_equals_definition():
+    rng = random.Random(5)
+    for n in (1, 31, 32, 40):
+        pts = [bn.pt_mul(bn.G1_GEN, rng.randrange(1, bn.R)) for _ in range(n)]
+        sc = [rng.choice([0, 1, bn.R - 1, rng.randrange(bn.R)]) for _ in range(n)]
+        assert g.multiexp_bellman(pts, None, sc) == bn.msm_naive(pts, sc)

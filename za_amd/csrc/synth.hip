@@ -276,3 +276,114 @@ extern "C" int zg_params_download(const zg_params* p, int which, void* out, size
     if (have && hipMemcpy(out, q.buf.p, have, hipMemcpyDeviceToHost) != hipSuccess) return ZG_E_HIP;
     return ZG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ self-test hooks
+// Host-side (no GPU) and device-side entry points that expose the product's own field / curve
+// arithmetic and the key parser to the tests.
+#include "formats.h"
+
+template <class F>
+static void st_field_host(int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        F x, y, z;
+        memcpy(&x, a + 32 * i, 32);
+        memcpy(&y, b + 32 * i, 32);
+        switch (op) {
+            case 0: z = x * y; break;
+            case 1: z = x + y; break;
+            case 2: z = x - y; break;
+            case 3: z = x.inv(); break;
+            case 4: z = x.to_mont(); break;
+            case 5: z = x.from_mont(); break;
+            case 6: z = x.neg(); break;
+            default: z = x.sqr(); break;
+        }
+        memcpy(out + 32 * i, &z, 32);
+    }
+}
+// which: 0 Fq, 1 Fr.  op: 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr.  Montgomery LE operands.
+extern "C" int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+    if (!a || !b || !out) return ZG_E_INVALID_ARG;
+    if (which) st_field_host<Fr>(op, a, b, out, n); else st_field_host<Fq>(op, a, b, out, n);
+    return ZG_OK;
+}
+template <class F>
+__global__ void k_st_field(int op, const F* a, const F* b, F* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = a[i], y = b[i], z;
+    switch (op) {
+        case 0: z = x * y; break;
+        case 1: z = x + y; break;
+        case 2: z = x - y; break;
+        case 3: z = x.inv(); break;
+        case 4: z = x.to_mont(); break;
+        case 5: z = x.from_mont(); break;
+        case 6: z = x.neg(); break;
+        default: z = x.sqr(); break;
+    }
+    out[i] = z;
+}
+extern "C" int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out,
+                                     size_t n) {
+    if (!ctx || !a || !b || !out) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf da, db, dout;
+    ZG_HIP(ctx, da.alloc(n * 32)); ZG_HIP(ctx, db.alloc(n * 32)); ZG_HIP(ctx, dout.alloc(n * 32));
+    ZG_HIP(ctx, hipMemcpyAsync(da.p, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipMemcpyAsync(db.p, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (n) {
+        if (which)
+            hipLaunchKernelGGL((k_st_field<Fr>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
+                               da.as<Fr>(), db.as<Fr>(), dout.as<Fr>(), n);
+        else
+            hipLaunchKernelGGL((k_st_field<Fq>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
+                               da.as<Fq>(), db.as<Fq>(), dout.as<Fq>(), n);
+    }
+    ZG_HIP(ctx, hipMemcpyAsync(out, dout.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+// out = k * p (+ q if q != NULL) with the product's HOST curve code; group 1 = G1 (64 B points), 2 = G2 (128 B)
+extern "C" int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out) {
+    if (!p || !k32 || !out) return ZG_E_INVALID_ARG;
+    uint32_t k[8];
+    memcpy(k, k32, 32);
+    if (group == 1) {
+        G1Affine a, b;
+        memcpy(&a, p, 64);
+        G1XYZZ r = G1XYZZ::from_affine(a).mul(k);
+        if (q) { memcpy(&b, q, 64); r = r.add_mixed(b); }
+        G1Affine o = r.to_affine();
+        memcpy(out, &o, 64);
+    } else {
+        G2Affine a, b;
+        memcpy(&a, p, 128);
+        G2XYZZ r = G2XYZZ::from_affine(a).mul(k);
+        if (q) { memcpy(&b, q, 128); r = r.add_mixed(b); }
+        G2Affine o = r.to_affine();
+        memcpy(out, &o, 128);
+    }
+    return ZG_OK;
+}
+// Parse and validate a bellman Parameters body without a GPU.  counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, consumed.
+// err (nullable) receives the parser's message.
+extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap) {
+    if (!buf || !counts) return ZG_E_INVALID_ARG;
+    zg_ctx tmp;
+    ParsedParams pp;
+    size_t used = 0;
+    int rc = parse_bellman_params(&tmp, buf, len, checked != 0, &pp, &used);
+    if (err && err_cap) {
+        strncpy(err, tmp.last_error.c_str(), err_cap - 1);
+        err[err_cap - 1] = 0;
+    }
+    if (rc) return rc;
+    counts[0] = pp.ic.size(); counts[1] = pp.h.size(); counts[2] = pp.l.size(); counts[3] = pp.a.size();
+    counts[4] = pp.b_g1.size(); counts[5] = pp.b_g2.size(); counts[6] = used;
+    // round trip: Parameters::write(Parameters::read(x)) == x
+    std::vector<uint8_t> again;
+    write_bellman_params(pp, &again);
+    if (again.size() != used || memcmp(again.data(), buf, used) != 0) return ZG_E_BAD_FORMAT;
+    return ZG_OK;
+}
