@@ -214,6 +214,15 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # explicit teardown (keeps profilers that hook process exit happy)
+    try:
+        ctx.free(d_w)
+        P.close()
+        r1.close()
+        ctx.close()
+    except Exception:
+        pass
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

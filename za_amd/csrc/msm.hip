@@ -2,19 +2,24 @@
 //
 // Replaces bellman_ce::multiexp::multiexp (the 8 calls inside create_proof, reference call site
 // prover/src/groth16/prover.rs:173).  Bellman runs one CPU thread per c-bit window with 2^c-1
-// Jacobian buckets; the result is a group element, so any bucket schedule gives the same point.
+// Jacobian buckets, skips exponent 0 and adds exponent-1 bases straight into the accumulator; the
+// result is a group element, so any bucket schedule gives the same point.
 // GPU schedule (all kernels on ctx->stream):
-//   1. k_count      signed c-bit digits of every scalar -> per-bucket counts (global atomics,
-//                   wave-aggregated for the wave's leading key so 0/1-heavy witnesses do not
-//                   serialise on one address -- bellman special-cases exponent 0 and 1 for the same reason)
-//   2. scan         exclusive prefix sums: bucket offsets and "item" offsets (an item = up to T
-//                   points of one bucket; heavy buckets are split so work per thread is bounded)
-//   3. k_scatter    counting-sort scatter of (base index | sign) into bucket order
-//   4. k_accumulate one thread per item: gather affine bases (64 B / 128 B, dwordx4 loads), XYZZ mixed adds
-//   5. k_reduce_chunks  per window, weighted running-sum over runs of items:
-//                   sum_i w_i P_i = sum_i (w_i - w_{i-1}) * (P_i + P_{i+1} + ...)
-//   6. k_reduce_windows one workgroup per window, LDS tree over the chunk results
-//   7. host: Horner over <= 64 window sums (c doublings each).
+//   0. k_classify   counts scalars equal to 0, equal to 1, and the rest; the window size c is planned
+//                   from the number of "real" scalars (a 97%-bit witness needs far fewer buckets)
+//   1. k_digits<0>  signed c-bit digits of every scalar -> per-bucket counts (global atomics, the lanes
+//                   sharing the wave's leading key are aggregated); scalars == 1 go to one extra
+//                   "ones" bucket, as bellman special-cases them
+//   2. scans        exclusive prefix sums: bucket offsets and "item" offsets (an item = up to T points
+//                   of one bucket, so work per thread is bounded for any scalar distribution)
+//   3. k_digits<1>  counting-sort scatter of (base index | sign) into bucket order
+//   4. k_accumulate one thread per item: gather affine bases (dwordx4 loads), XYZZ mixed adds   [dominant]
+//   5. k_tree_leaf / k_tree_level   hierarchical bucket reduction over FIXED bucket ranges:
+//                   a node over L children of span s has  R = sum R_t,  W = sum W_t + s * sum t R_t,
+//                   with sum t R_t from the running-sum trick; the root's W is  sum_b (b+1) bucket_b.
+//                   No scalar multiplications, log_L(2^(c-1)) short launches.
+//   6. k_sum_array  fan-in-16 passes over the partial sums of the "ones" bucket
+//   7. host: Horner over <= 128 window sums (c doublings each) + the ones sum.
 // Algorithmic HBM bytes: 64 B base + 32 B scalar per point (G1), 128 + 32 (G2).  The kernel is
 // integer-ALU bound (about 10 field multiplications per point per window), not HBM bound.
 #include <algorithm>
@@ -28,9 +33,11 @@
 namespace zg {
 
 static constexpr int MAXWIN = 128;
+static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
+static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, cursor, sorted, item_key, partial, chunk_out, win_out, bsum, meta;
+    DevBuf counts, offsets, item_off, cursor, sorted, item_key, partial, node[4], ones[2], bsum, meta;
 };
 
 struct MsmPlan {
@@ -40,18 +47,17 @@ struct MsmPlan {
     uint32_t T;      // max points per item
 };
 
-static MsmPlan plan_msm(size_t n, int elem_cost /*1 for G1, 3 for G2: same plan*/) {
-    (void)elem_cost;
+// n_real: scalars that are neither 0 nor 1; n_ones: scalars equal to 1
+static MsmPlan plan_msm(size_t n_real, size_t n_ones) {
     MsmPlan best{};
     double best_cost = 1e300;
     for (int c = 2; c <= 22; c++) {
         int nwin = (255 + c - 1) / c;
         if (nwin > MAXWIN) continue;
         double B = (double)(1u << (c - 1));
-        // stage-1 mixed adds + stage-2 full adds (2 per bucket, ~1.5x a mixed add) + fixed launch work
-        double cost = (double)n * nwin + 3.0 * nwin * B + 2000.0 * nwin;
-        // sorted-index footprint must stay below 2^32 entries
-        if ((double)n * nwin >= 4.0e9) continue;
+        // stage-1 mixed adds + tree reduction (~3.2 full adds per bucket, a full add ~1.5 mixed adds) + launches
+        double cost = (double)n_real * nwin + 4.8 * nwin * B + 3000.0 * ((c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
+        if ((double)n_real * nwin + (double)n_ones >= 4.0e9) continue;  // sorted-index footprint < 2^32 entries
         if (cost < best_cost) {
             best_cost = cost;
             best.c = c;
@@ -60,7 +66,7 @@ static MsmPlan plan_msm(size_t n, int elem_cost /*1 for G1, 3 for G2: same plan*
         }
     }
     best.nkeys = (uint32_t)best.nwin * best.B;
-    size_t mean = (n + best.B - 1) / best.B;
+    size_t mean = (n_real + best.B - 1) / best.B;
     size_t T = 2 * mean;
     if (T < 16) T = 16;
     if (T > 512) T = 512;
@@ -103,11 +109,37 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// mode 0: histogram (counts[key] += 1); mode 1: scatter (sorted[cursor[key]++] = i | sign<<31)
+// zeros / ones / other scalars (through the index indirection), one atomic per wave and class
+__global__ void __launch_bounds__(256) k_classify(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
+                                                  size_t n, uint32_t* __restrict__ cls /*[3]*/) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n_round = (n + 63) & ~(size_t)63;
+    uint32_t zeros = 0, ones = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        if (i < n) {
+            Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
+            uint32_t hi = s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7];
+            zeros += (hi | s.w[0]) == 0;
+            ones += hi == 0 && s.w[0] == 1;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        zeros += __shfl_down(zeros, d);
+        ones += __shfl_down(ones, d);
+    }
+    if (lane_id() == 0) {
+        if (zeros) atomicAdd(&cls[0], zeros);
+        if (ones) atomicAdd(&cls[1], ones);
+    }
+}
+
+// mode 0: histogram (counts[key] += 1); mode 1: scatter (sorted[cursor[key]++] = i | sign<<31).
+// Key `ones_key` collects the scalars equal to 1.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars,
                                                 const uint32_t* __restrict__ index, size_t n, int c, int nwin,
-                                                uint32_t* __restrict__ counts_or_cursor,
+                                                uint32_t ones_key, uint32_t* __restrict__ counts_or_cursor,
                                                 uint32_t* __restrict__ sorted) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n_round = (n + 63) & ~(size_t)63;
@@ -119,6 +151,20 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 #pragma unroll
         for (int k = 0; k < 8; k++) s.w[k] = 0;
         if (in) s = load_scalar(scalars, index ? (size_t)index[i] : i);
+        {   // scalar == 1: one aggregated atomic per wave on the ones bucket, then no digits
+            const bool one = s.w[0] == 1 && (s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7]) == 0;
+            const uint64_t om = __ballot(one);
+            if (om) {
+                const int leader = __ffsll((unsigned long long)om) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&counts_or_cursor[ones_key], (uint32_t)__popcll(om));
+                if (MODE == 1) {
+                    base = __shfl(base, leader);
+                    if (one) sorted[base + mbcnt(om)] = (uint32_t)i;
+                }
+                if (one) s.w[0] = 0;
+            }
+        }
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
             int32_t d = next_digit(s, c, carry);
@@ -182,7 +228,11 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
     return wave_off + x - v;
 }
 
-__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t T) { return (cnt + T - 1) / T; }
+// items of bucket idx: the ones bucket (idx == nkeys - 1) uses T_ONES points per item
+__device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t T, uint32_t idx, uint32_t nkeys) {
+    const uint32_t t = idx + 1 == nkeys ? T_ONES : T;
+    return (cnt + t - 1) / t;
+}
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __restrict__ counts, uint32_t nkeys,
                                                               uint32_t T, uint32_t* __restrict__ bsum /*[2][nb]*/,
@@ -195,7 +245,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __
         uint32_t idx = base + k;
         uint32_t cnt = idx < nkeys ? counts[idx] : 0;
         sc += cnt;
-        si += items_of(cnt, T);
+        si += items_of(cnt, T, idx, nkeys);
     }
     uint32_t tc, ti;
     block_excl_scan(sc, lds, tc);
@@ -237,7 +287,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
         uint32_t idx = base + k;
         cnt[k] = idx < nkeys ? counts[idx] : 0;
         sc += cnt[k];
-        si += items_of(cnt[k], T);
+        si += items_of(cnt[k], T, idx, nkeys);
     }
     uint32_t tc, ti;
     uint32_t ec = block_excl_scan(sc, lds, tc) + bsum[blockIdx.x];
@@ -251,19 +301,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
             if (idx < nkeys) cursor[idx] = ec;
         }
         ec += cnt[k];
-        ei += items_of(cnt[k], T);
+        ei += items_of(cnt[k], T, idx, nkeys);
     }
 }
 
-// meta[0] = total entries, meta[1] = total items, meta[2 + w] = item_off[w * B] for w = 0..nwin
-__global__ void k_meta(const uint32_t* offsets, const uint32_t* item_off, uint32_t nkeys, uint32_t B, int nwin,
-                       uint32_t* meta) {
-    int t = threadIdx.x;
-    if (t == 0) {
+// meta[0] = total entries, meta[1] = total items, meta[2], meta[3] = item range of the ones bucket (key nkeys-1)
+__global__ void k_meta(const uint32_t* offsets, const uint32_t* item_off, uint32_t nkeys, uint32_t* meta) {
+    if (threadIdx.x == 0) {
         meta[0] = offsets[nkeys];
         meta[1] = item_off[nkeys];
+        meta[2] = item_off[nkeys - 1];
+        meta[3] = item_off[nkeys];
     }
-    if (t <= nwin) meta[2 + t] = item_off[(size_t)t * B];
 }
 
 __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict__ item_off, uint32_t nkeys,
@@ -281,14 +330,15 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ item_off,
                                                     const uint32_t* __restrict__ item_key, uint32_t total_items,
-                                                    uint32_t T, XYZZ<F>* __restrict__ partial) {
+                                                    uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_items) return;
     uint32_t key = item_key[t];
+    uint32_t Tk = key == ones_key ? T_ONES : T;
     uint32_t seg = t - item_off[key];
-    uint32_t start = offsets[key] + seg * T;
+    uint32_t start = offsets[key] + seg * Tk;
     uint32_t end = offsets[key + 1];
-    if (end > start + T) end = start + T;
+    if (end > start + Tk) end = start + Tk;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t k = start; k < end; k++) {
         uint32_t e = sorted[k];
@@ -299,60 +349,56 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
     partial[t] = acc;
 }
 
-// ------------------------------------------------------------------------------------------------ stage 2
-struct WinTable {
-    uint32_t item_lo[MAXWIN + 1];   // first item of each window (and one past the end)
-    uint32_t chunk_lo[MAXWIN + 1];  // first chunk (thread) of each window
-    uint32_t per_chunk[MAXWIN];     // items per chunk
-};
-
+// ------------------------------------------------------------------------------------------------ stage 2: bucket tree
+// Leaf level: node g covers buckets [g << fbits, (g+1) << fbits).  Bucket b of the node has weight t+1
+// (t = b - first bucket):  R = sum bucket_t,  W = sum (t+1) bucket_t  via the running sum.
 template <class F>
-__global__ void __launch_bounds__(128) k_reduce_chunks(const XYZZ<F>* __restrict__ partial,
-                                                       const uint32_t* __restrict__ item_key, WinTable tab, int nwin,
-                                                       uint32_t B, XYZZ<F>* __restrict__ chunk_out) {
+__global__ void __launch_bounds__(128) k_tree_leaf(const XYZZ<F>* __restrict__ partial,
+                                                   const uint32_t* __restrict__ item_off, uint32_t n_nodes, int fbits,
+                                                   XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= tab.chunk_lo[nwin]) return;
-    int w = 0;
-    while (w + 1 < nwin && g >= tab.chunk_lo[w + 1]) w++;
-    uint32_t j = g - tab.chunk_lo[w];
-    uint32_t L = tab.per_chunk[w];
-    uint32_t lo = tab.item_lo[w] + j * L;
-    uint32_t hi = tab.item_lo[w + 1];
-    if (hi > lo + L) hi = lo + L;
-    const uint32_t key0 = (uint32_t)w * B;
-    XYZZ<F> running = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-    for (uint32_t i = hi; i-- > lo;) {
-        uint32_t wi = item_key[i] - key0 + 1u;
-        uint32_t wprev = i > lo ? item_key[i - 1] - key0 + 1u : 0u;
-        running = running.add(partial[i]);
-        uint32_t gap = wi - wprev;
-        if (gap == 1u)
-            acc = acc.add(running);
-        else if (gap > 1u)
-            acc = acc.add(running.mul_small(gap));
+    if (g >= n_nodes) return;
+    const uint32_t first = g << fbits;
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    for (int t = (1 << fbits) - 1; t >= 0; t--) {
+        uint32_t lo = item_off[first + t], hi = item_off[first + t + 1];
+        for (uint32_t i = lo; i < hi; i++) run = run.add(partial[i]);
+        acc = acc.add(run);
     }
-    chunk_out[g] = acc;
+    outR[g] = run;
+    outW[g] = acc;
 }
-
+// Inner level: children [k << fbits, (k+1) << fbits) each spanning 2^sbits buckets.
+//   R = sum R_t,   W = sum W_t + 2^sbits * sum t R_t,   sum t R_t = (sum (t+1) R_t) - R.
 template <class F>
-__global__ void __launch_bounds__(128) k_reduce_windows(const XYZZ<F>* __restrict__ chunk_out, WinTable tab,
-                                                        XYZZ<F>* __restrict__ win_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem);
-    const int w = blockIdx.x;
-    const uint32_t lo = tab.chunk_lo[w], hi = tab.chunk_lo[w + 1];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = acc.add(chunk_out[i]);
-    lds[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            acc = acc.add(lds[threadIdx.x + s]);
-            lds[threadIdx.x] = acc;
-        }
-        __syncthreads();
+__global__ void __launch_bounds__(128) k_tree_level(const XYZZ<F>* __restrict__ inR, const XYZZ<F>* __restrict__ inW,
+                                                    uint32_t n_nodes, int fbits, int sbits,
+                                                    XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_nodes) return;
+    const uint32_t first = k << fbits;
+    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf(), sw = XYZZ<F>::inf();
+    for (int t = (1 << fbits) - 1; t >= 0; t--) {
+        run = run.add(inR[first + t]);
+        acc = acc.add(run);
+        sw = sw.add(inW[first + t]);
     }
-    if (threadIdx.x == 0) win_out[w] = acc;
+    XYZZ<F> tr = acc.add(run.neg());
+    for (int d = 0; d < sbits; d++) tr = tr.dbl();
+    outR[k] = run;
+    outW[k] = sw.add(tr);
+}
+// out[i] = in[16 i] + ... + in[16 i + 15]
+template <class F>
+__global__ void __launch_bounds__(128) k_sum_array(const XYZZ<F>* __restrict__ in, uint32_t n_in,
+                                                   XYZZ<F>* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = i * 16;
+    if (lo >= n_in) return;
+    uint32_t hi = lo + 16 < n_in ? lo + 16 : n_in;
+    XYZZ<F> acc = in[lo];
+    for (uint32_t j = lo + 1; j < hi; j++) acc = acc.add(in[j]);
+    out[i] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -365,21 +411,30 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
     if (!ctx->msm_scratch) ctx->msm_scratch = new MsmScratch();
     MsmScratch& S = *ctx->msm_scratch;
     hipStream_t st = ctx->stream;
-    const MsmPlan P = plan_msm(n, 1);
-    const uint32_t nkeys = P.nkeys;
+    constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
+    constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
+    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
+
+    // ---- classify, then plan the window size from the number of scalars that are neither 0 nor 1
+    ZG_HIP(ctx, S.meta.reserve(64));
+    ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
+    std::unique_ptr<ProfScope> ps(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, S.meta.as<uint32_t>() + 8);
+    uint32_t cls[2];
+    ZG_HIP(ctx, hipMemcpyAsync(cls, S.meta.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, st));
+    ZG_HIP(ctx, hipStreamSynchronize(st));
+    const size_t n_zero = cls[0], n_ones = cls[1], n_real = n - n_zero - n_ones;
+    if (n_real == 0 && n_ones == 0) return ZG_OK;  // all scalars zero
+    const MsmPlan P = plan_msm(n_real, n_ones);
+    const uint32_t ones_key = P.nkeys;   // one extra bucket after the nwin * B regular ones
+    const uint32_t nkeys = P.nkeys + 1;
 
     ZG_HIP(ctx, S.counts.reserve((size_t)(nkeys + 1) * 4));
     ZG_HIP(ctx, S.offsets.reserve((size_t)(nkeys + 1) * 4));
     ZG_HIP(ctx, S.item_off.reserve((size_t)(nkeys + 1) * 4));
     ZG_HIP(ctx, S.cursor.reserve((size_t)(nkeys + 1) * 4));
-    ZG_HIP(ctx, S.meta.reserve((size_t)(MAXWIN + 4) * 4));
     ZG_HIP(ctx, hipMemsetAsync(S.counts.p, 0, (size_t)(nkeys + 1) * 4, st));
-
-    constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
-    constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
-    int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
-    std::unique_ptr<ProfScope> ps(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
-    hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin,
+    hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
                        S.counts.as<uint32_t>(), (uint32_t*)nullptr);
 
     // nkeys + 1 entries are scanned so that entry nkeys receives the totals
@@ -391,54 +446,77 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
                        S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                        S.cursor.as<uint32_t>());
-    hipLaunchKernelGGL(k_meta, dim3(1), dim3(MAXWIN + 1), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                       nkeys, P.B, P.nwin, S.meta.as<uint32_t>());
+    hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
+                       S.meta.as<uint32_t>());
     ps.reset();
-    uint32_t meta[MAXWIN + 4];
-    ZG_HIP(ctx, hipMemcpyAsync(meta, S.meta.p, (size_t)(P.nwin + 3) * 4, hipMemcpyDeviceToHost, st));
+    uint32_t meta[4];
+    ZG_HIP(ctx, hipMemcpyAsync(meta, S.meta.p, 16, hipMemcpyDeviceToHost, st));
     ZG_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t total_entries = meta[0], total_items = meta[1];
-    if (total_items == 0) return ZG_OK;  // all scalars zero
+    const uint32_t ones_lo = meta[2], ones_hi = meta[3];
+    if (total_items == 0) return ZG_OK;
 
     ZG_HIP(ctx, S.sorted.reserve((size_t)total_entries * 4));
     ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
     ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
     ps.reset(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
-    hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin,
+    hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
                        S.cursor.as<uint32_t>(), S.sorted.as<uint32_t>());
     hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(), nkeys,
                        S.item_key.as<uint32_t>());
     ps.reset(new ProfScope(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES));
     hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
                        S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                       S.item_key.as<uint32_t>(), total_items, P.T, S.partial.as<XYZZ<F>>());
-    ps.reset();
-
-    // stage 2 geometry: ~16 items per thread
-    WinTable tab;
-    memset(&tab, 0, sizeof(tab));
-    uint32_t chunks = 0;
-    for (int w = 0; w < P.nwin; w++) {
-        tab.item_lo[w] = meta[2 + w];
-        uint32_t items = meta[2 + w + 1] - meta[2 + w];
-        uint32_t L = 16;
-        uint32_t nch = (items + L - 1) / L;
-        tab.per_chunk[w] = L;
-        tab.chunk_lo[w] = chunks;
-        chunks += nch;
-    }
-    tab.item_lo[P.nwin] = meta[2 + P.nwin];
-    tab.chunk_lo[P.nwin] = chunks;
-    ZG_HIP(ctx, S.chunk_out.reserve((size_t)chunks * sizeof(XYZZ<F>)));
-    ZG_HIP(ctx, S.win_out.reserve((size_t)P.nwin * sizeof(XYZZ<F>)));
+                       S.item_key.as<uint32_t>(), total_items, P.T, ones_key, S.partial.as<XYZZ<F>>());
     ps.reset(new ProfScope(ctx, PROF_MSM_REDUCE, 0));
-    hipLaunchKernelGGL((k_reduce_chunks<F>), dim3((chunks + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
-                       S.item_key.as<uint32_t>(), tab, P.nwin, P.B, S.chunk_out.as<XYZZ<F>>());
-    hipLaunchKernelGGL((k_reduce_windows<F>), dim3(P.nwin), dim3(128), 128 * sizeof(XYZZ<F>), st,
-                       S.chunk_out.as<XYZZ<F>>(), tab, S.win_out.as<XYZZ<F>>());
+
+    // ---- bucket tree over the regular keys: fan-in 2^TREE_LAMBDA per level until one node per window remains
+    int bits = P.c - 1;
+    int f1 = std::min(bits, TREE_LAMBDA);
+    uint32_t n_nodes = P.nkeys >> f1;
+    for (int k = 0; k < 4; k++) ZG_HIP(ctx, S.node[k].reserve((size_t)n_nodes * sizeof(XYZZ<F>)));
+    XYZZ<F>* curR = S.node[0].as<XYZZ<F>>();
+    XYZZ<F>* curW = S.node[1].as<XYZZ<F>>();
+    XYZZ<F>* nxtR = S.node[2].as<XYZZ<F>>();
+    XYZZ<F>* nxtW = S.node[3].as<XYZZ<F>>();
+    hipLaunchKernelGGL((k_tree_leaf<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
+                       S.item_off.as<uint32_t>(), n_nodes, f1, curR, curW);
+    int sbits = f1;
+    bits -= f1;
+    while (bits > 0) {
+        int f = std::min(bits, TREE_LAMBDA);
+        n_nodes >>= f;
+        hipLaunchKernelGGL((k_tree_level<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, curR, curW, n_nodes, f,
+                           sbits, nxtR, nxtW);
+        std::swap(curR, nxtR);
+        std::swap(curW, nxtW);
+        sbits += f;
+        bits -= f;
+    }
+    // n_nodes == nwin now; curW[w] = sum_b (b+1) * bucket_{w,b}
+
+    // ---- ones bucket: fan-in-16 passes over its partial sums
+    const XYZZ<F>* ones_ptr = nullptr;
+    if (ones_hi > ones_lo) {
+        uint32_t cnt = ones_hi - ones_lo;
+        const XYZZ<F>* in = S.partial.as<XYZZ<F>>() + ones_lo;
+        int pp = 0;
+        while (cnt > 1) {
+            uint32_t nout = (cnt + 15) / 16;
+            ZG_HIP(ctx, S.ones[pp].reserve((size_t)nout * sizeof(XYZZ<F>)));
+            hipLaunchKernelGGL((k_sum_array<F>), dim3((nout + 127) / 128), dim3(128), 0, st, in, cnt,
+                               S.ones[pp].as<XYZZ<F>>());
+            in = S.ones[pp].as<XYZZ<F>>();
+            cnt = nout;
+            pp ^= 1;
+        }
+        ones_ptr = in;
+    }
     ps.reset();
-    std::vector<XYZZ<F>> win(P.nwin);
-    ZG_HIP(ctx, hipMemcpyAsync(win.data(), S.win_out.p, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    std::vector<XYZZ<F>> win(P.nwin + 1);
+    ZG_HIP(ctx, hipMemcpyAsync(win.data(), curW, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    win[P.nwin] = XYZZ<F>::inf();
+    if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(&win[P.nwin], ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ZG_HIP(ctx, hipStreamSynchronize(st));
     ZG_HIP(ctx, hipGetLastError());
 
@@ -447,7 +525,7 @@ static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars
         for (int k = 0; k < P.c; k++) acc = acc.dbl();
         acc = acc.add(win[w]);
     }
-    *out = acc;
+    *out = acc.add(win[P.nwin]);
     return ZG_OK;
 }
 
