@@ -26,8 +26,11 @@ struct Ctx {
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
-    // reusable MSM scratch, see msm.hip
-    struct MsmScratch* msm_scratch = nullptr;
+    // reusable MSM scratch (one per concurrent job) and side streams, see msm.hip
+    struct MsmScratch* msm_scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_ev = nullptr;
+    bool side_ready = false;
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
@@ -37,15 +40,16 @@ enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDU
               PROF_R1CS_EVAL, PROF_COUNT };
 struct ProfScope {
     Ctx* c; int idx = -1;
-    ProfScope(Ctx* ctx, int id, uint64_t alg_bytes) : c(ctx) {
+    hipStream_t st;
+    ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream) {
         if (!ctx->prof_enabled) return;
         Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes};
         if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
-        (void)hipEventRecord(p.e0, ctx->stream);
+        (void)hipEventRecord(p.e0, st);
         ctx->prof_pending.push_back(p);
         idx = (int)ctx->prof_pending.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_pending[idx].e1, c->stream); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_pending[idx].e1, st); }
 };
 
 #define ZG_HIP(ctx, expr)                                                                      \
@@ -96,6 +100,14 @@ int msm_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const u
            size_t n, G1XYZZ* out);
 int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index,
            size_t n, G2XYZZ* out);
+struct MsmDesc {
+    const void* bases;
+    const uint32_t* scalars;
+    const uint32_t* index;
+    size_t n;
+};
+// the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
+int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2);
 void msm_scratch_free(Ctx* ctx);
 
 // ---- ntt.hip

@@ -38,6 +38,8 @@ static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
     DevBuf counts, offsets, item_off, cursor, sorted, item_key, partial, node[4], ones[2], bsum, meta;
+    static constexpr size_t HOST_BYTES = 64 * 1024;
+    unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
 
 struct MsmPlan {
@@ -402,144 +404,243 @@ __global__ void __launch_bounds__(128) k_sum_array(const XYZZ<F>* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
+// An MSM runs in three device phases separated by two tiny host read-backs (class counts, then
+// totals).  msm_batch() drives several jobs phase by phase, each on its own HIP stream, so the
+// latency-bound tree launches of one MSM overlap the throughput-bound accumulation of the next.
+struct MsmJobBase {
+    virtual ~MsmJobBase() {}
+    virtual int phase_a() = 0;
+    virtual int phase_b() = 0;
+    virtual int phase_c() = 0;
+    virtual int finish() = 0;
+    hipStream_t st = nullptr;
+    bool done = false;
+};
+
 template <class F>
-static int msm_run(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
-                   XYZZ<F>* out) {
-    *out = XYZZ<F>::inf();
-    if (n == 0) return ZG_OK;
-    if (n >= (1ull << 31)) return fail(ctx, ZG_E_INVALID_ARG, "msm: n = %zu exceeds 2^31-1", n);
-    if (!ctx->msm_scratch) ctx->msm_scratch = new MsmScratch();
-    MsmScratch& S = *ctx->msm_scratch;
-    hipStream_t st = ctx->stream;
-    constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
-    constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
-    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
-
-    // ---- classify, then plan the window size from the number of scalars that are neither 0 nor 1
-    ZG_HIP(ctx, S.meta.reserve(64));
-    ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
-    std::unique_ptr<ProfScope> ps(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
-    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, S.meta.as<uint32_t>() + 8);
-    uint32_t cls[2];
-    ZG_HIP(ctx, hipMemcpyAsync(cls, S.meta.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, st));
-    ZG_HIP(ctx, hipStreamSynchronize(st));
-    const size_t n_zero = cls[0], n_ones = cls[1], n_real = n - n_zero - n_ones;
-    if (n_real == 0 && n_ones == 0) return ZG_OK;  // all scalars zero
-    const MsmPlan P = plan_msm(n_real, n_ones);
-    const uint32_t ones_key = P.nkeys;   // one extra bucket after the nwin * B regular ones
-    const uint32_t nkeys = P.nkeys + 1;
-
-    ZG_HIP(ctx, S.counts.reserve((size_t)(nkeys + 1) * 4));
-    ZG_HIP(ctx, S.offsets.reserve((size_t)(nkeys + 1) * 4));
-    ZG_HIP(ctx, S.item_off.reserve((size_t)(nkeys + 1) * 4));
-    ZG_HIP(ctx, S.cursor.reserve((size_t)(nkeys + 1) * 4));
-    ZG_HIP(ctx, hipMemsetAsync(S.counts.p, 0, (size_t)(nkeys + 1) * 4, st));
-    hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
-                       S.counts.as<uint32_t>(), (uint32_t*)nullptr);
-
-    // nkeys + 1 entries are scanned so that entry nkeys receives the totals
-    const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
-    ZG_HIP(ctx, S.bsum.reserve((size_t)nb * 2 * 4));
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
-                       S.bsum.as<uint32_t>(), nb);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nb);
-    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
-                       S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                       S.cursor.as<uint32_t>());
-    hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
-                       S.meta.as<uint32_t>());
-    ps.reset();
-    uint32_t meta[4];
-    ZG_HIP(ctx, hipMemcpyAsync(meta, S.meta.p, 16, hipMemcpyDeviceToHost, st));
-    ZG_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t total_entries = meta[0], total_items = meta[1];
-    const uint32_t ones_lo = meta[2], ones_hi = meta[3];
-    if (total_items == 0) return ZG_OK;
-
-    ZG_HIP(ctx, S.sorted.reserve((size_t)total_entries * 4));
-    ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
-    ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
-    ps.reset(new ProfScope(ctx, PROF_MSM_SORT, n * 32));
-    hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
-                       S.cursor.as<uint32_t>(), S.sorted.as<uint32_t>());
-    hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(), nkeys,
-                       S.item_key.as<uint32_t>());
-    ps.reset(new ProfScope(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES));
-    hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
-                       S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                       S.item_key.as<uint32_t>(), total_items, P.T, ones_key, S.partial.as<XYZZ<F>>());
-    ps.reset(new ProfScope(ctx, PROF_MSM_REDUCE, 0));
-
-    // ---- bucket tree over the regular keys: fan-in 2^TREE_LAMBDA per level until one node per window remains
-    int bits = P.c - 1;
-    int f1 = std::min(bits, TREE_LAMBDA);
-    uint32_t n_nodes = P.nkeys >> f1;
-    for (int k = 0; k < 4; k++) ZG_HIP(ctx, S.node[k].reserve((size_t)n_nodes * sizeof(XYZZ<F>)));
-    XYZZ<F>* curR = S.node[0].as<XYZZ<F>>();
-    XYZZ<F>* curW = S.node[1].as<XYZZ<F>>();
-    XYZZ<F>* nxtR = S.node[2].as<XYZZ<F>>();
-    XYZZ<F>* nxtW = S.node[3].as<XYZZ<F>>();
-    hipLaunchKernelGGL((k_tree_leaf<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
-                       S.item_off.as<uint32_t>(), n_nodes, f1, curR, curW);
-    int sbits = f1;
-    bits -= f1;
-    while (bits > 0) {
-        int f = std::min(bits, TREE_LAMBDA);
-        n_nodes >>= f;
-        hipLaunchKernelGGL((k_tree_level<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, curR, curW, n_nodes, f,
-                           sbits, nxtR, nxtW);
-        std::swap(curR, nxtR);
-        std::swap(curW, nxtW);
-        sbits += f;
-        bits -= f;
-    }
-    // n_nodes == nwin now; curW[w] = sum_b (b+1) * bucket_{w,b}
-
-    // ---- ones bucket: fan-in-16 passes over its partial sums
+struct MsmJob : MsmJobBase {
+    Ctx* ctx;
+    MsmScratch& S;
+    const Affine<F>* d_bases;
+    const uint32_t* d_scalars;
+    const uint32_t* d_index;
+    size_t n;
+    XYZZ<F>* out;
+    MsmPlan P{};
+    uint32_t ones_key = 0, nkeys = 0;
+    int grid = 1;
+    XYZZ<F>* curW = nullptr;
     const XYZZ<F>* ones_ptr = nullptr;
-    if (ones_hi > ones_lo) {
-        uint32_t cnt = ones_hi - ones_lo;
-        const XYZZ<F>* in = S.partial.as<XYZZ<F>>() + ones_lo;
-        int pp = 0;
-        while (cnt > 1) {
-            uint32_t nout = (cnt + 15) / 16;
-            ZG_HIP(ctx, S.ones[pp].reserve((size_t)nout * sizeof(XYZZ<F>)));
-            hipLaunchKernelGGL((k_sum_array<F>), dim3((nout + 127) / 128), dim3(128), 0, st, in, cnt,
-                               S.ones[pp].as<XYZZ<F>>());
-            in = S.ones[pp].as<XYZZ<F>>();
-            cnt = nout;
-            pp ^= 1;
-        }
-        ones_ptr = in;
-    }
-    ps.reset();
-    std::vector<XYZZ<F>> win(P.nwin + 1);
-    ZG_HIP(ctx, hipMemcpyAsync(win.data(), curW, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-    win[P.nwin] = XYZZ<F>::inf();
-    if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(&win[P.nwin], ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-    ZG_HIP(ctx, hipStreamSynchronize(st));
-    ZG_HIP(ctx, hipGetLastError());
+    static constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
+    static constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
 
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = P.nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < P.c; k++) acc = acc.dbl();
-        acc = acc.add(win[w]);
+    MsmJob(Ctx* c, MsmScratch& scratch, hipStream_t stream, const Affine<F>* b, const uint32_t* sc, const uint32_t* idx,
+           size_t n_, XYZZ<F>* o)
+        : ctx(c), S(scratch), d_bases(b), d_scalars(sc), d_index(idx), n(n_), out(o) {
+        st = stream;
+        *out = XYZZ<F>::inf();
+        if (n == 0) done = true;
     }
-    *out = acc.add(win[P.nwin]);
+
+    int phase_a() override {
+        if (done) return ZG_OK;
+        if (n >= (1ull << 31)) return fail(ctx, ZG_E_INVALID_ARG, "msm: n = %zu exceeds 2^31-1", n);
+        if (!S.host) ZG_HIP(ctx, hipHostMalloc((void**)&S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
+        grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
+        ZG_HIP(ctx, S.meta.reserve(64));
+        ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
+        ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
+        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, S.meta.as<uint32_t>() + 8);
+        ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, st));
+        return ZG_OK;
+    }
+
+    int phase_b() override {
+        if (done) return ZG_OK;
+        const uint32_t* cls = reinterpret_cast<const uint32_t*>(S.host);
+        const size_t n_zero = cls[0], n_ones = cls[1], n_real = n - n_zero - n_ones;
+        if (n_real == 0 && n_ones == 0) {  // all scalars zero
+            done = true;
+            return ZG_OK;
+        }
+        P = plan_msm(n_real, n_ones);
+        ones_key = P.nkeys;  // one extra bucket after the nwin * B regular ones
+        nkeys = P.nkeys + 1;
+        ZG_HIP(ctx, S.counts.reserve((size_t)(nkeys + 1) * 4));
+        ZG_HIP(ctx, S.offsets.reserve((size_t)(nkeys + 1) * 4));
+        ZG_HIP(ctx, S.item_off.reserve((size_t)(nkeys + 1) * 4));
+        ZG_HIP(ctx, S.cursor.reserve((size_t)(nkeys + 1) * 4));
+        ZG_HIP(ctx, hipMemsetAsync(S.counts.p, 0, (size_t)(nkeys + 1) * 4, st));
+        ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
+        hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
+                           S.counts.as<uint32_t>(), (uint32_t*)nullptr);
+        // nkeys + 1 entries are scanned so that entry nkeys receives the totals
+        const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
+        ZG_HIP(ctx, S.bsum.reserve((size_t)nb * 2 * 4));
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
+                           S.bsum.as<uint32_t>(), nb);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nb);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
+                           S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                           S.cursor.as<uint32_t>());
+        hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
+                           S.meta.as<uint32_t>());
+        ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
+        return ZG_OK;
+    }
+
+    int phase_c() override {
+        if (done) return ZG_OK;
+        const uint32_t* meta = reinterpret_cast<const uint32_t*>(S.host);
+        const uint32_t total_entries = meta[0], total_items = meta[1];
+        const uint32_t ones_lo = meta[2], ones_hi = meta[3];
+        if (total_items == 0) {
+            done = true;
+            return ZG_OK;
+        }
+        ZG_HIP(ctx, S.sorted.reserve((size_t)total_entries * 4));
+        ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
+        ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
+        {
+            ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
+            hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
+                               S.cursor.as<uint32_t>(), S.sorted.as<uint32_t>());
+            hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
+                               nkeys, S.item_key.as<uint32_t>());
+        }
+        {
+            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st);
+            hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
+                               S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                               S.item_key.as<uint32_t>(), total_items, P.T, ones_key, S.partial.as<XYZZ<F>>());
+        }
+        ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
+        // ---- bucket tree over the regular keys: fan-in 2^TREE_LAMBDA per level until one node per window remains
+        int bits = P.c - 1;
+        int f1 = std::min(bits, TREE_LAMBDA);
+        uint32_t n_nodes = P.nkeys >> f1;
+        for (int k = 0; k < 4; k++) ZG_HIP(ctx, S.node[k].reserve((size_t)n_nodes * sizeof(XYZZ<F>)));
+        XYZZ<F>* curR = S.node[0].template as<XYZZ<F>>();
+        curW = S.node[1].template as<XYZZ<F>>();
+        XYZZ<F>* nxtR = S.node[2].template as<XYZZ<F>>();
+        XYZZ<F>* nxtW = S.node[3].template as<XYZZ<F>>();
+        hipLaunchKernelGGL((k_tree_leaf<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
+                           S.item_off.as<uint32_t>(), n_nodes, f1, curR, curW);
+        int sbits = f1;
+        bits -= f1;
+        while (bits > 0) {
+            int f = std::min(bits, TREE_LAMBDA);
+            n_nodes >>= f;
+            hipLaunchKernelGGL((k_tree_level<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, curR, curW, n_nodes, f,
+                               sbits, nxtR, nxtW);
+            std::swap(curR, nxtR);
+            std::swap(curW, nxtW);
+            sbits += f;
+            bits -= f;
+        }
+        // n_nodes == nwin now; curW[w] = sum_b (b+1) * bucket_{w,b}
+        // ---- ones bucket: fan-in-16 passes over its partial sums
+        ones_ptr = nullptr;
+        if (ones_hi > ones_lo) {
+            uint32_t cnt = ones_hi - ones_lo;
+            const XYZZ<F>* in = S.partial.as<XYZZ<F>>() + ones_lo;
+            int pp = 0;
+            while (cnt > 1) {
+                uint32_t nout = (cnt + 15) / 16;
+                ZG_HIP(ctx, S.ones[pp].reserve((size_t)nout * sizeof(XYZZ<F>)));
+                hipLaunchKernelGGL((k_sum_array<F>), dim3((nout + 127) / 128), dim3(128), 0, st, in, cnt,
+                                   S.ones[pp].as<XYZZ<F>>());
+                in = S.ones[pp].template as<XYZZ<F>>();
+                cnt = nout;
+                pp ^= 1;
+            }
+            ones_ptr = in;
+        }
+        static_assert((MAXWIN + 1) * sizeof(XYZZ<F>) <= MsmScratch::HOST_BYTES, "pinned buffer too small");
+        XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host);
+        ZG_HIP(ctx, hipMemcpyAsync(hw, curW, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.nwin, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        ZG_HIP(ctx, hipGetLastError());
+        return ZG_OK;
+    }
+
+    int finish() override {
+        if (done) return ZG_OK;
+        const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(S.host);
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (int w = P.nwin - 1; w >= 0; w--) {
+            for (int k = 0; k < P.c; k++) acc = acc.dbl();
+            acc = acc.add(hw[w]);
+        }
+        if (ones_ptr) acc = acc.add(hw[P.nwin]);
+        *out = acc;
+        done = true;
+        return ZG_OK;
+    }
+};
+
+static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
+    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_a());
+    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
+    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_b());
+    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
+    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_c());
+    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
+    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->finish());
     return ZG_OK;
+}
+
+static MsmScratch& scratch_slot(Ctx* ctx, int slot) {
+    if (!ctx->msm_scratch[slot]) ctx->msm_scratch[slot] = new MsmScratch();
+    return *ctx->msm_scratch[slot];
 }
 
 int msm_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
            G1XYZZ* out) {
-    return msm_run<Fq>(ctx, d_bases, d_scalars, d_index, n, out);
+    MsmJob<Fq> job(ctx, scratch_slot(ctx, 0), ctx->stream, d_bases, d_scalars, d_index, n, out);
+    MsmJobBase* jobs[1] = {&job};
+    return run_jobs(ctx, jobs, 1);
 }
 int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
            G2XYZZ* out) {
-    return msm_run<Fq2>(ctx, d_bases, d_scalars, d_index, n, out);
+    MsmJob<Fq2> job(ctx, scratch_slot(ctx, 0), ctx->stream, d_bases, d_scalars, d_index, n, out);
+    MsmJobBase* jobs[1] = {&job};
+    return run_jobs(ctx, jobs, 1);
 }
+
+// The five multiexps of create_proof, concurrently on the ctx's side streams.
+int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2) {
+    // side streams start after everything already queued on the main stream
+    if (!ctx->side_ready) {
+        for (int k = 0; k < 5; k++) ZG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+        ctx->side_ready = true;
+    }
+    ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
+    for (int k = 0; k < 5; k++) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ctx->side_ev, 0));
+    MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
+    MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
+    MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
+    MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
+    MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
+    // heaviest first: the G2 job, then h, then the witness MSMs
+    MsmJobBase* jobs[5] = {&j2, &j0, &j1, &j3, &j4};
+    return run_jobs(ctx, jobs, 5);
+}
+
 void msm_scratch_free(Ctx* ctx) {
-    delete ctx->msm_scratch;
-    ctx->msm_scratch = nullptr;
+    for (int k = 0; k < 5; k++) {
+        if (ctx->msm_scratch[k]) {
+            if (ctx->msm_scratch[k]->host) (void)hipHostFree(ctx->msm_scratch[k]->host);
+            delete ctx->msm_scratch[k];
+            ctx->msm_scratch[k] = nullptr;
+        }
+    }
+    if (ctx->side_ready) {
+        for (int k = 0; k < 5; k++) (void)hipStreamDestroy(ctx->side[k]);
+        (void)hipEventDestroy(ctx->side_ev);
+        ctx->side_ready = false;
+    }
 }
 
 }  // namespace zg

@@ -574,33 +574,36 @@ extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r
     const uint64_t m = (uint64_t)1 << r->log_m;
     const uint32_t* w = (const uint32_t*)d_witness;
     double t0 = now_ms();
-    G1XYZZ h_acc, l_acc, a_acc, b1_acc;
+    G1XYZZ g1out[4];
     G2XYZZ b2_acc;
+    MsmDesc d1[4], d2;
     {   // h: first m-1 points of the query; this shard holds [lo, hi)
         const auto& q = p->q[0];
         uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
         uint64_t n = hi > q.lo ? hi - q.lo : 0;
         if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
-        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), (const uint32_t*)d_h_shard, nullptr, n, &h_acc));
+        d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n};
     }
     {   // l: aux assignment, full density
         const auto& q = p->q[1];
         uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
         uint64_t n = hi > q.lo ? hi - q.lo : 0;
-        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w + 8 * ((size_t)r->n_inputs + q.lo), nullptr, n, &l_acc));
+        d1[1] = MsmDesc{q.buf.p, w + 8 * ((size_t)r->n_inputs + q.lo), nullptr, (size_t)n};
     }
     {   // a: inputs (full density) then aux by a_aux_density
         const auto& q = p->q[2];
-        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w, r->a_index.as<uint32_t>() + q.lo, q.hi - q.lo, &a_acc));
+        d1[2] = MsmDesc{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
     }
     {
         const auto& q = p->q[3];
-        ZG_TRY(msm_g1(ctx, q.buf.as<G1Affine>(), w, r->b_index.as<uint32_t>() + q.lo, q.hi - q.lo, &b1_acc));
+        d1[3] = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
     }
     {
         const auto& q = p->q[4];
-        ZG_TRY(msm_g2(ctx, q.buf.as<G2Affine>(), w, r->b_index.as<uint32_t>() + q.lo, q.hi - q.lo, &b2_acc));
+        d2 = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
     }
+    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc));
+    const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
     jac_bytes(partials + 192, a_acc);
