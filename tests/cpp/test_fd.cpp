@@ -1,0 +1,227 @@
+// Host unit test of the device field / curve code (za_amd/csrc/fd.h, ecd.h) against the plain
+// 8x32 Montgomery implementation (fp.h, ec.h), which is itself pinned to the golden vectors.
+// Built with -DZG_FD_DEBUG: every Fd carries an upper bound and each sub<K> / pack asserts it,
+// so the lazy-reduction constants in ecd.h are machine-checked here.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "../../za_amd/csrc/ecd.h"
+
+using namespace zg;
+
+static std::mt19937_64 rng(12345);
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            printf("CHECK failed at line %d: %s\n", __LINE__, #cond);        \
+            if (++failures > 10) exit(1);                                    \
+        }                                                                    \
+    } while (0)
+
+template <class Pw>
+static Fp<Pw> rand_canon() {  // uniform-ish canonical integer < p
+    Fp<Pw> r;
+    for (;;) {
+        for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)rng();
+        r.l[7] &= 0x3fffffffu;
+        bool lt = false;
+        for (int i = 7; i >= 0; i--) {
+            if (r.l[i] < Pw::MOD[i]) { lt = true; break; }
+            if (r.l[i] > Pw::MOD[i]) break;
+        }
+        if (lt) return r;
+    }
+}
+// Fd (M261) from a canonical integer; and back to a canonical integer
+template <class P29>
+static Fd<P29> fd_of(const Fp<typename P29::Wide>& canon) { return Fd<P29>::to_mont(Fd<P29>::load_canon(&canon)); }
+template <class P29>
+static Fp<typename P29::Wide> canon_of(const Fd<P29>& v) {
+    Fp<typename P29::Wide> out;
+    v.from_mont().store(&out);
+    return out;
+}
+
+template <class P29>
+static void test_field(const char* name) {
+    using W = typename P29::Wide;
+    using F = Fp<W>;
+    using D = Fd<P29>;
+    // constants
+    {
+        F one_c = F::zero(); one_c.l[0] = 1;
+        CHECK(canon_of<P29>(D::one()) == one_c);
+        F x = rand_canon<W>();
+        // m256 <-> m261: x*2^256 (host Montgomery form of x) -> x*2^261
+        F xm = x.to_mont();
+        D viaconv = D::load_canon(&xm).m256_to_m261();
+        CHECK(canon_of<P29>(viaconv) == x);
+        F back; viaconv.m261_to_m256().canonical().store(&back);
+        CHECK(back == xm);
+    }
+    for (int it = 0; it < 20000; it++) {
+        F a = rand_canon<W>(), b = rand_canon<W>();
+        if (it == 0) { a = F::zero(); }
+        if (it == 1) { for (int i = 0; i < 8; i++) a.l[i] = W::MOD[i]; a.l[0] -= 1; b = a; }
+        F am = a.to_mont(), bm = b.to_mont();
+        D ad = fd_of<P29>(a), bd = fd_of<P29>(b);
+        CHECK(canon_of<P29>(ad * bd) == (am * bm).from_mont());
+        CHECK(canon_of<P29>(ad.sqr()) == am.sqr().from_mont());
+        CHECK(canon_of<P29>(ad + bd) == (am + bm).from_mont());
+        CHECK(canon_of<P29>(D::template sub<2>(ad, bd)) == (am - bm).from_mont());
+        // lazy chains: ((a+b)+(a+b)) - b*7 ... against the strict implementation
+        D s = ad + bd; s = s + s; s = s + ad;                  // 2a+2b+a, bound ~ 5
+        F sm = am + bm; sm = sm + sm; sm = sm + am;
+        D t = D::template sub<6>(ad, s);                       // a - s
+        CHECK(canon_of<P29>(t) == (am - sm).from_mont());
+        D big = t;
+        for (int k = 0; k < 4; k++) big = big + big;           // bound ~ 7*16 = 112 < cap
+        F bigm = am - sm;
+        for (int k = 0; k < 4; k++) bigm = bigm + bigm;
+        CHECK(canon_of<P29>(big.reduce()) == bigm.from_mont());
+        CHECK(canon_of<P29>(big * bd) == (bigm * bm).from_mont());
+        CHECK(big.is_zero_mod_p() == bigm.is_zero());
+        // pack / unpack of a reduced value
+        F mem; big.reduce().store(&mem);
+        CHECK(canon_of<P29>(D::load_red(&mem)) == bigm.from_mont());
+        if (it < 50) {
+            D inv = ad.inv();
+            if (!a.is_zero()) CHECK(canon_of<P29>(inv * ad) == F::one().from_mont());
+        }
+    }
+    // values that are multiples of p must test as zero
+    {
+        F a = rand_canon<W>();
+        D ad = fd_of<P29>(a);
+        D z = D::template sub<2>(ad, ad);   // == 2p as an integer
+        CHECK(z.is_zero_mod_p());
+        D z2 = z + z + z;                   // 6p
+        CHECK(z2.is_zero_mod_p());
+        CHECK(!(z2 + D::one()).is_zero_mod_p());
+        CHECK(D::zero().is_zero_mod_p());
+    }
+    printf("%s field ok\n", name);
+}
+
+// ---- curve: lazy XYZZ vs strict XYZZ
+template <class L, class F>
+static Affine<F> aff_to_m261(const Affine<F>& p);  // host M256 affine -> memory in M261
+template <>
+Affine<Fq> aff_to_m261<FqL, Fq>(const Affine<Fq>& p) {
+    Affine<Fq> o;
+    FqD::load_canon(&p.x).m256_to_m261().canonical().store(&o.x);
+    FqD::load_canon(&p.y).m256_to_m261().canonical().store(&o.y);
+    return o;
+}
+template <>
+Affine<Fq2> aff_to_m261<Fq2L, Fq2>(const Affine<Fq2>& p) {
+    Affine<Fq2> o;
+    FqD::load_canon(&p.x.c0).m256_to_m261().canonical().store(&o.x.c0);
+    FqD::load_canon(&p.x.c1).m256_to_m261().canonical().store(&o.x.c1);
+    FqD::load_canon(&p.y.c0).m256_to_m261().canonical().store(&o.y.c0);
+    FqD::load_canon(&p.y.c1).m256_to_m261().canonical().store(&o.y.c1);
+    return o;
+}
+static Fq m261_to_host(const Fq& m) {
+    Fq o;
+    FqD::load_canon(&m).m261_to_m256().canonical().store(&o);
+    return o;
+}
+static Fq2 m261_to_host(const Fq2& m) { return Fq2{m261_to_host(m.c0), m261_to_host(m.c1)}; }
+
+template <class L, class F>
+static bool same_point(const XYZZd<L>& d, const XYZZ<F>& h) {
+    Affine<F> dm;
+    d.to_affine_mem(&dm);
+    Affine<F> ha = h.to_affine();
+    Affine<F> dh{m261_to_host(dm.x), m261_to_host(dm.y)};
+    return dh.x == ha.x && dh.y == ha.y;
+}
+
+template <class L, class F>
+static void test_curve(const char* name, const Affine<F>& gen) {
+    using XD = XYZZd<L>;
+    using XH = XYZZ<F>;
+    auto rand_pt = [&]() {
+        uint32_t k[8];
+        for (int i = 0; i < 8; i++) k[i] = (uint32_t)rng();
+        k[7] &= 0x0fffffffu;
+        return XH::from_affine(gen).mul(k).to_affine();
+    };
+    auto dev_aff = [&](const Affine<F>& p) {
+        Affine<F> m = aff_to_m261<L, F>(p);
+        return AffD<L>::load(&m);
+    };
+    for (int it = 0; it < 300; it++) {
+        Affine<F> p = rand_pt(), q = rand_pt(), r = rand_pt();
+        AffD<L> pd = dev_aff(p), qd = dev_aff(q), rd = dev_aff(r);
+        XH hacc = XH::from_affine(p);
+        XD dacc = XD::from_affine(pd);
+        // a run of mixed adds with signs, as in bucket accumulation
+        for (int k = 0; k < 6; k++) {
+            bool neg = (rng() & 1) != 0;
+            const Affine<F>& b = (k & 1) ? q : r;
+            const AffD<L>& bd = (k & 1) ? qd : rd;
+            hacc = hacc.add_mixed(neg ? b.neg() : b);
+            dacc = dacc.add_mixed(neg ? bd.negated() : bd);
+            CHECK((same_point<L, F>(dacc, hacc)));
+        }
+        // store / load round trip
+        XYZZ<F> mem;
+        dacc.store(&mem);
+        XD re = XD::load(&mem);
+        CHECK((same_point<L, F>(re, hacc)));
+        // full add, doubling, negation
+        XH h2 = XH::from_affine(q).add_mixed(r);
+        XD d2 = XD::from_affine(qd).add_mixed(rd);
+        CHECK((same_point<L, F>(re.add(d2), hacc.add(h2))));
+        CHECK((same_point<L, F>(re.dbl(), hacc.dbl())));
+        CHECK((same_point<L, F>(re.add(re), hacc.dbl())));          // add() must detect doubling
+        CHECK(re.add(re.neg()).is_inf());                          // P + (-P)
+        CHECK((same_point<L, F>(re.dbl().dbl().add(re.neg()), hacc.dbl().dbl().add(hacc.neg()))));
+        // mixed add special cases
+        XD one = XD::from_affine(pd);
+        CHECK((same_point<L, F>(one.add_mixed(pd), XH::from_affine(p).dbl())));
+        CHECK(one.add_mixed(pd.negated()).is_inf());
+        CHECK((same_point<L, F>(XD::inf().add_mixed(pd), XH::from_affine(p))));
+        Affine<F> infm = Affine<F>::inf();
+        CHECK((same_point<L, F>(one.add_mixed(AffD<L>::load(&infm)), XH::from_affine(p))));
+        // tree-style chain: running sums with repeated add / dbl keeps every bound in range
+        XD run = XD::inf(), acc = XD::inf();
+        XH hrun = XH::inf(), hac = XH::inf();
+        for (int t = 0; t < 8; t++) {
+            run = run.add(t & 1 ? re : d2);
+            hrun = hrun.add(t & 1 ? hacc : h2);
+            acc = acc.add(run);
+            hac = hac.add(hrun);
+        }
+        XD tr = acc.add(run.neg());
+        XH htr = hac.add(hrun.neg());
+        for (int d = 0; d < 5; d++) { tr = tr.dbl(); htr = htr.dbl(); }
+        CHECK((same_point<L, F>(tr, htr)));
+    }
+    printf("%s curve ok\n", name);
+}
+
+int main() {
+    test_field<Fq29>("Fq");
+    test_field<Fr29>("Fr");
+    G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};
+    test_curve<FqL, Fq>("G1", g1);
+    // G2 generator (prover/src/groth16/ethereum.rs:28-31)
+    auto fq = [](uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t l5, uint32_t l6, uint32_t l7) {
+        Fq c; c.l[0]=l0; c.l[1]=l1; c.l[2]=l2; c.l[3]=l3; c.l[4]=l4; c.l[5]=l5; c.l[6]=l6; c.l[7]=l7; return c.to_mont();
+    };
+    G2Affine g2;
+    g2.x.c0 = fq(0xd992f6edu, 0x46debd5cu, 0xf75edaddu, 0x674322d4u, 0x5e5c4479u, 0x426a0066u, 0x121f1e76u, 0x1800deefu);
+    g2.x.c1 = fq(0xaef312c2u, 0x97e485b7u, 0x35a9e712u, 0xf1aa4933u, 0x31fb5d25u, 0x7260bfb7u, 0x920d483au, 0x198e9393u);
+    g2.y.c0 = fq(0x66fa7daau, 0x4ce6cc01u, 0x0c43d37bu, 0xe3d1e769u, 0x8dcb408fu, 0x4aab7180u, 0xdb8c6debu, 0x12c85ea5u);
+    g2.y.c1 = fq(0xd122975bu, 0x55acdadcu, 0x70b38ef3u, 0xbc4b3133u, 0x690c3395u, 0xec9e99adu, 0x585ff075u, 0x090689d0u);
+    test_curve<Fq2L, Fq2>("G2", g2);
+    if (failures) { printf("FAILED: %d\n", failures); return 1; }
+    printf("ALL OK\n");
+    return 0;
+}

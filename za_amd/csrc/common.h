@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "../../include/za_amd.h"
-#include "ec.h"
+#include "ecd.h"
 
 namespace zg {
 
@@ -116,6 +116,36 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 // (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
 void ntt_tables_free(Ctx* ctx);
+
+// ---- M261 (device memory form, x*2^261) <-> host Montgomery form (x*2^256), host side.
+// m261_to_host accepts any representative below 2^256 (device values are reduce()d, < 2.01 p).
+template <class Pw>
+inline Fp<Pw> m261_to_host(const Fp<Pw>& v) {
+    static const Fp<Pw> inv32 = Fp<Pw>::from_u64(32).inv();
+    return v * inv32;
+}
+template <class Pw>
+inline Fp<Pw> host_to_m261(const Fp<Pw>& v) {
+    static const Fp<Pw> c32 = Fp<Pw>::from_u64(32);
+    return v * c32;
+}
+inline Fq2 m261_to_host(const Fq2& v) { return Fq2{m261_to_host(v.c0), m261_to_host(v.c1)}; }
+inline Fq2 host_to_m261(const Fq2& v) { return Fq2{host_to_m261(v.c0), host_to_m261(v.c1)}; }
+template <class F>
+inline XYZZ<F> m261_to_host(const XYZZ<F>& p) {
+    return XYZZ<F>{m261_to_host(p.x), m261_to_host(p.y), m261_to_host(p.zz), m261_to_host(p.zzz)};
+}
+template <class F>
+inline Affine<F> host_to_m261(const Affine<F>& p) { return Affine<F>{host_to_m261(p.x), host_to_m261(p.y)}; }
+template <class F>
+inline Affine<F> m261_to_host(const Affine<F>& p) { return Affine<F>{m261_to_host(p.x), m261_to_host(p.y)}; }
+// in-place conversion of n field elements in HBM: dir 0 = ABI (2^256) -> M261, 1 = M261 -> ABI; which 0 = Fq, 1 = Fr
+int convert_mont_dev(Ctx* ctx, void* d_elems, size_t n, int which, int dir, hipStream_t st = nullptr);
+
+// field selector for the lazy device arithmetic
+template <class F> struct LazyOf;
+template <> struct LazyOf<Fq> { using L = FqL; };
+template <> struct LazyOf<Fq2> { using L = Fq2L; };
 
 // ---- host helpers (field element <-> bytes)
 template <class F>

@@ -20,6 +20,7 @@
 //                   No scalar multiplications, log_L(2^(c-1)) short launches.
 //   6. k_sum_array  fan-in-16 passes over the partial sums of the "ones" bucket
 //   7. host: Horner over <= 128 window sums (c doublings each) + the ones sum.
+// Bases live in HBM in the device field's M261 form (fd.h); field work uses the lazy 9x29-limb arithmetic.
 // Algorithmic HBM bytes: 64 B base + 32 B scalar per point (G1), 128 + 32 (G2).  The kernel is
 // integer-ALU bound (about 10 field multiplications per point per window), not HBM bound.
 #include <algorithm>
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ item_off,
                                                     const uint32_t* __restrict__ item_key, uint32_t total_items,
                                                     uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
+    using L = typename LazyOf<F>::L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_items) return;
     uint32_t key = item_key[t];
@@ -341,14 +343,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
     uint32_t start = offsets[key] + seg * Tk;
     uint32_t end = offsets[key + 1];
     if (end > start + Tk) end = start + Tk;
-    XYZZ<F> acc = XYZZ<F>::inf();
+    XYZZd<L> acc = XYZZd<L>::inf();
     for (uint32_t k = start; k < end; k++) {
         uint32_t e = sorted[k];
-        Affine<F> p = bases[e & 0x7fffffffu];
-        if (e >> 31) p.y = p.y.neg();
+        AffD<L> p = AffD<L>::load(&bases[e & 0x7fffffffu]);
+        if (e >> 31) p = p.negated();
         acc = acc.add_mixed(p);
     }
-    partial[t] = acc;
+    acc.store(&partial[t]);
 }
 
 // ------------------------------------------------------------------------------------------------ stage 2: bucket tree
@@ -358,17 +360,18 @@ template <class F>
 __global__ void __launch_bounds__(128) k_tree_leaf(const XYZZ<F>* __restrict__ partial,
                                                    const uint32_t* __restrict__ item_off, uint32_t n_nodes, int fbits,
                                                    XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
+    using L = typename LazyOf<F>::L;
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_nodes) return;
     const uint32_t first = g << fbits;
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    XYZZd<L> run = XYZZd<L>::inf(), acc = XYZZd<L>::inf();
     for (int t = (1 << fbits) - 1; t >= 0; t--) {
         uint32_t lo = item_off[first + t], hi = item_off[first + t + 1];
-        for (uint32_t i = lo; i < hi; i++) run = run.add(partial[i]);
+        for (uint32_t i = lo; i < hi; i++) run = run.add(XYZZd<L>::load(&partial[i]));
         acc = acc.add(run);
     }
-    outR[g] = run;
-    outW[g] = acc;
+    run.store(&outR[g]);
+    acc.store(&outW[g]);
 }
 // Inner level: children [k << fbits, (k+1) << fbits) each spanning 2^sbits buckets.
 //   R = sum R_t,   W = sum W_t + 2^sbits * sum t R_t,   sum t R_t = (sum (t+1) R_t) - R.
@@ -376,31 +379,33 @@ template <class F>
 __global__ void __launch_bounds__(128) k_tree_level(const XYZZ<F>* __restrict__ inR, const XYZZ<F>* __restrict__ inW,
                                                     uint32_t n_nodes, int fbits, int sbits,
                                                     XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
+    using L = typename LazyOf<F>::L;
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_nodes) return;
     const uint32_t first = k << fbits;
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf(), sw = XYZZ<F>::inf();
+    XYZZd<L> run = XYZZd<L>::inf(), acc = XYZZd<L>::inf(), sw = XYZZd<L>::inf();
     for (int t = (1 << fbits) - 1; t >= 0; t--) {
-        run = run.add(inR[first + t]);
+        run = run.add(XYZZd<L>::load(&inR[first + t]));
         acc = acc.add(run);
-        sw = sw.add(inW[first + t]);
+        sw = sw.add(XYZZd<L>::load(&inW[first + t]));
     }
-    XYZZ<F> tr = acc.add(run.neg());
+    XYZZd<L> tr = acc.add(run.neg());
     for (int d = 0; d < sbits; d++) tr = tr.dbl();
-    outR[k] = run;
-    outW[k] = sw.add(tr);
+    run.store(&outR[k]);
+    sw.add(tr).store(&outW[k]);
 }
 // out[i] = in[16 i] + ... + in[16 i + 15]
 template <class F>
 __global__ void __launch_bounds__(128) k_sum_array(const XYZZ<F>* __restrict__ in, uint32_t n_in,
                                                    XYZZ<F>* __restrict__ out) {
+    using L = typename LazyOf<F>::L;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t lo = i * 16;
     if (lo >= n_in) return;
     uint32_t hi = lo + 16 < n_in ? lo + 16 : n_in;
-    XYZZ<F> acc = in[lo];
-    for (uint32_t j = lo + 1; j < hi; j++) acc = acc.add(in[j]);
-    out[i] = acc;
+    XYZZd<L> acc = XYZZd<L>::load(&in[lo]);
+    for (uint32_t j = lo + 1; j < hi; j++) acc = acc.add(XYZZd<L>::load(&in[j]));
+    acc.store(&out[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -568,11 +573,12 @@ struct MsmJob : MsmJobBase {
         if (done) return ZG_OK;
         const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(S.host);
         XYZZ<F> acc = XYZZ<F>::inf();
+        // the device works in the 2^261 Montgomery domain; window sums come back reduce()d in that form
         for (int w = P.nwin - 1; w >= 0; w--) {
             for (int k = 0; k < P.c; k++) acc = acc.dbl();
-            acc = acc.add(hw[w]);
+            if (!hw[w].is_inf()) acc = acc.add(m261_to_host(hw[w]));
         }
-        if (ones_ptr) acc = acc.add(hw[P.nwin]);
+        if (ones_ptr && !hw[P.nwin].is_inf()) acc = acc.add(m261_to_host(hw[P.nwin]));
         *out = acc;
         done = true;
         return ZG_OK;

@@ -36,10 +36,12 @@ static double now_ms() {
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-// coefficient c (canonical) -> c * 2^512 mod r, so that mont_mul(coeff, w_canonical) = c*w in Montgomery form
+// Device field values are M261 residues (x * 2^261, fd.h).
+// coefficient c (plain integer) -> c * 2^522 mod r, so that coeff * w_integer (one Montgomery
+// multiplication) is c*w in M261 form with no per-proof conversion of the witness
 __global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) c[i] = c[i].to_mont().to_mont();
+    if (i < n) (FrD::to_mont(FrD::load_canon(&c[i])) * FrD::r2()).canonical().store(&c[i]);
 }
 
 // out[row] = sum_e coeff[e] * w[col[e]]  for one CSR matrix; one thread per row
@@ -48,14 +50,21 @@ __global__ void __launch_bounds__(256) k_r1cs_eval(const uint64_t* __restrict__ 
                                                    uint64_t n_rows, Fr* __restrict__ out) {
     uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
-    Fr acc = Fr::zero();
-    for (uint64_t e = row_ptr[row], end = row_ptr[row + 1]; e < end; e++) acc = acc + coeff[e] * w[col[e]];
-    out[row] = acc;
+    FrD acc = FrD::zero();
+    uint32_t since = 0;
+    for (uint64_t e = row_ptr[row], end = row_ptr[row + 1]; e < end; e++) {
+        acc = acc + FrD::load_canon(&coeff[e]) * FrD::load_canon(&w[col[e]]);
+        if (++since == 64) {  // each term adds < 1.01 p to the lazy bound
+            acc = acc.reduce();
+            since = 0;
+        }
+    }
+    acc.reduce().store(&out[row]);
 }
-// the `input_i * 0 = 0` rows: a[n + i] = w_i (Montgomery); b, c stay zero
+// the `input_i * 0 = 0` rows: a[n + i] = w_i; b, c stay zero
 __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, Fr* __restrict__ a_tail) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_inputs) a_tail[i] = w[i].to_mont();
+    if (i < n_inputs) FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a_tail[i]);
 }
 
 }  // namespace zg
@@ -244,6 +253,7 @@ static int msm_host(zg_ctx* ctx, const uint8_t* bases, size_t n_bases, const uin
         ZG_HIP(ctx, di.alloc(index.size() * 4));
         ZG_HIP(ctx, hipMemcpyAsync(di.p, index.data(), index.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
+    ZG_TRY(convert_mont_dev(ctx, db.p, n_bases * sizeof(Affine<F>) / 32, 0, 0));  // ABI form -> device form
     XYZZ<F> r;
     int rc;
     if constexpr (sizeof(F) == sizeof(Fq))
@@ -268,7 +278,11 @@ extern "C" int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_sca
     if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     G1XYZZ r;
-    ZG_TRY(msm_g1(ctx, (const G1Affine*)d_bases, (const uint32_t*)d_scalars, d_scalar_index, n, &r));
+    DevBuf tmp;  // the caller's bases are in the ABI's 2^256 form: work on a converted copy
+    ZG_HIP(ctx, tmp.alloc(n * sizeof(G1Affine)));
+    ZG_HIP(ctx, hipMemcpyAsync(tmp.p, d_bases, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream));
+    ZG_TRY(convert_mont_dev(ctx, tmp.p, n * 2, 0, 0));
+    ZG_TRY(msm_g1(ctx, tmp.as<G1Affine>(), (const uint32_t*)d_scalars, d_scalar_index, n, &r));
     jac_bytes(out_jac, r);
     return ZG_OK;
 }
@@ -277,7 +291,11 @@ extern "C" int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_sca
     if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     G2XYZZ r;
-    ZG_TRY(msm_g2(ctx, (const G2Affine*)d_bases, (const uint32_t*)d_scalars, d_scalar_index, n, &r));
+    DevBuf tmp;
+    ZG_HIP(ctx, tmp.alloc(n * sizeof(G2Affine)));
+    ZG_HIP(ctx, hipMemcpyAsync(tmp.p, d_bases, n * sizeof(G2Affine), hipMemcpyDeviceToDevice, ctx->stream));
+    ZG_TRY(convert_mont_dev(ctx, tmp.p, n * 4, 0, 0));
+    ZG_TRY(msm_g2(ctx, tmp.as<G2Affine>(), (const uint32_t*)d_scalars, d_scalar_index, n, &r));
     jac_bytes(out_jac, r);
     return ZG_OK;
 }
@@ -316,6 +334,7 @@ extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, con
         ZG_HIP(ctx, hipMemcpyAsync(d[k].p, src[k], n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     ZG_HIP(ctx, dh.alloc(m * 32));
+    for (int k = 0; k < 3; k++) ZG_TRY(convert_mont_dev(ctx, d[k].p, n_rows, 1, 0));  // ABI form -> device form
     ZG_TRY(h_poly_dev(ctx, d[0].as<Fr>(), d[1].as<Fr>(), d[2].as<Fr>(), log_m, dh.as<Fr>()));
     if (m > 1) ZG_HIP(ctx, hipMemcpyAsync(h_out, dh.p, (m - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -437,6 +456,7 @@ extern "C" int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witnes
         abc[k] = d[k].as<Fr>();
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc));
+    for (int k = 0; k < 3; k++) ZG_TRY(convert_mont_dev(ctx, d[k].p, rows, 1, 1));  // device form -> ABI form
     uint8_t* outs[3] = {a_out, b_out, c_out};
     for (int k = 0; k < 3; k++)
         ZG_HIP(ctx, hipMemcpyAsync(outs[k], d[k].p, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -457,9 +477,12 @@ static int params_upload(zg_ctx* ctx, zg_params* p, int which, const void* host,
     q.total = total;
     shard_range(total, p->rank, p->world, &q.lo, &q.hi);
     ZG_HIP(ctx, q.buf.alloc((q.hi - q.lo) * elem));
-    if (q.hi > q.lo)
+    if (q.hi > q.lo) {
         ZG_HIP(ctx, hipMemcpyAsync(q.buf.p, (const uint8_t*)host + q.lo * elem, (q.hi - q.lo) * elem,
                                    hipMemcpyHostToDevice, ctx->stream));
+        // resident bases are kept in the device field's M261 form
+        ZG_TRY(convert_mont_dev(ctx, q.buf.p, (q.hi - q.lo) * elem / 32, 0, 0));
+    }
     return ZG_OK;
 }
 

@@ -142,16 +142,19 @@ extern "C" uint64_t zg_synth_dlog(uint64_t seed, uint64_t i) { return splitmix64
 
 // ------------------------------------------------------------------------------------------------ device generators
 template <class F>
-__global__ void __launch_bounds__(128) k_synth_bases(Affine<F>* __restrict__ out, size_t n, uint64_t seed, Affine<F> gen) {
+__global__ void __launch_bounds__(128) k_synth_bases(Affine<F>* __restrict__ out, size_t n, uint64_t seed,
+                                                     Affine<F> gen_m261) {
+    using L = typename LazyOf<F>::L;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t k = splitmix64_hd(seed, i);
-    XYZZ<F> acc = XYZZ<F>::inf();
+    const AffD<L> gen = AffD<L>::load(&gen_m261);
+    XYZZd<L> acc = XYZZd<L>::inf();
     for (int b = 63; b >= 0; b--) {
         acc = acc.dbl();
         if ((k >> b) & 1) acc = acc.add_mixed(gen);
     }
-    out[i] = acc.to_affine();
+    acc.to_affine_mem(&out[i]);   // canonical, device (M261) form
 }
 __global__ void __launch_bounds__(256) k_synth_scalars(uint32_t* __restrict__ out, size_t n, uint64_t seed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,26 +188,36 @@ static G2Affine g2_generator() {
     return g;
 }
 
-extern "C" int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
-    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
-    ZG_HIP(ctx, hipSetDevice(ctx->device));
+// internal: bases in the device's M261 form (what zg_params keeps resident)
+static int synth_bases_g1_m261(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
     if (n == 0) return ZG_OK;
     hipLaunchKernelGGL((k_synth_bases<Fq>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (G1Affine*)d_out, n, seed, g1_generator());
+                       (G1Affine*)d_out, n, seed, host_to_m261(g1_generator()));
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
-extern "C" int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
-    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
-    ZG_HIP(ctx, hipSetDevice(ctx->device));
+static int synth_bases_g2_m261(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
     if (n == 0) return ZG_OK;
     G2Affine g = g2_generator();
     if (!on_curve(g, Fq2{Fq::from_u64(3), Fq::zero()} * Fq2{Fq::from_u64(9), Fq::from_u64(1)}.inv()))
         return fail(ctx, ZG_E_INVALID_ARG, "internal: G2 generator constant is not on the twist");
     hipLaunchKernelGGL((k_synth_bases<Fq2>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (G2Affine*)d_out, n, seed, g);
+                       (G2Affine*)d_out, n, seed, host_to_m261(g));
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
+}
+// public: bases in the ABI's 2^256 Montgomery form, like any caller-supplied device bases
+extern "C" int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_TRY(synth_bases_g1_m261(ctx, d_out, n, seed));
+    return convert_mont_dev(ctx, d_out, n * 2, 0, 1);
+}
+extern "C" int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+    if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_TRY(synth_bases_g2_m261(ctx, d_out, n, seed));
+    return convert_mont_dev(ctx, d_out, n * 4, 0, 1);
 }
 extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
     if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
@@ -246,8 +259,8 @@ extern "C" int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint
             const size_t cnt = q.hi - q.lo;
             // splitmix64_hd(seed, lo + i) == splitmix64_hd(seed + lo * GOLDEN, i)
             const uint64_t s2 = seeds[k] + q.lo * 0x9E3779B97F4A7C15ull;
-            if (k == 4) ZG_TRY(zg_synth_bases_g2_dev(ctx, q.buf.p, cnt, s2));
-            else ZG_TRY(zg_synth_bases_g1_dev(ctx, q.buf.p, cnt, s2));
+            if (k == 4) ZG_TRY(synth_bases_g2_m261(ctx, q.buf.p, cnt, s2));
+            else ZG_TRY(synth_bases_g1_m261(ctx, q.buf.p, cnt, s2));
         }
     }
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -274,6 +287,14 @@ extern "C" int zg_params_download(const zg_params* p, int which, void* out, size
     const size_t have = (q.hi - q.lo) * elem;
     if (bytes < have) return ZG_E_BUFFER_TOO_SMALL;
     if (have && hipMemcpy(out, q.buf.p, have, hipMemcpyDeviceToHost) != hipSuccess) return ZG_E_HIP;
+    // resident bases are in the device's M261 form: hand back the ABI's 2^256 form
+    Fq* f = reinterpret_cast<Fq*>(out);
+    for (size_t i = 0; i < have / 32; i++) {
+        Fq v;
+        memcpy(&v, f + i, 32);
+        v = m261_to_host(v);
+        memcpy(f + i, &v, 32);
+    }
     return ZG_OK;
 }
 
@@ -307,22 +328,25 @@ extern "C" int zg_selftest_field_host(int which, int op, const uint8_t* a, const
     if (which) st_field_host<Fr>(op, a, b, out, n); else st_field_host<Fq>(op, a, b, out, n);
     return ZG_OK;
 }
-template <class F>
-__global__ void k_st_field(int op, const F* a, const F* b, F* out, size_t n) {
+// operands arrive in the ABI's 2^256 form; the op runs in the device field (fd.h) and converts back
+template <class P29>
+__global__ void k_st_field(int op, const Fp<typename P29::Wide>* a, const Fp<typename P29::Wide>* b,
+                           Fp<typename P29::Wide>* out, size_t n) {
+    using D = Fd<P29>;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    F x = a[i], y = b[i], z;
+    D x = D::load_canon(&a[i]).m256_to_m261(), y = D::load_canon(&b[i]).m256_to_m261(), z;
     switch (op) {
         case 0: z = x * y; break;
         case 1: z = x + y; break;
-        case 2: z = x - y; break;
+        case 2: z = D::template sub<2>(x, y); break;
         case 3: z = x.inv(); break;
-        case 4: z = x.to_mont(); break;
-        case 5: z = x.from_mont(); break;
-        case 6: z = x.neg(); break;
+        case 4: z = D::load_canon(&a[i]) * D::r2(); break;                 // integer a -> a * 2^256 once converted back
+        case 5: x.from_mont().store(&out[i]); return;                       // a * 2^256 -> integer a
+        case 6: z = x.template neg<2>(); break;
         default: z = x.sqr(); break;
     }
-    out[i] = z;
+    z.m261_to_m256().canonical().store(&out[i]);
 }
 extern "C" int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out,
                                      size_t n) {
@@ -334,10 +358,10 @@ extern "C" int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8
     ZG_HIP(ctx, hipMemcpyAsync(db.p, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
     if (n) {
         if (which)
-            hipLaunchKernelGGL((k_st_field<Fr>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
+            hipLaunchKernelGGL((k_st_field<Fr29>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
                                da.as<Fr>(), db.as<Fr>(), dout.as<Fr>(), n);
         else
-            hipLaunchKernelGGL((k_st_field<Fq>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
+            hipLaunchKernelGGL((k_st_field<Fq29>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, op,
                                da.as<Fq>(), db.as<Fq>(), dout.as<Fq>(), n);
     }
     ZG_HIP(ctx, hipMemcpyAsync(out, dout.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
