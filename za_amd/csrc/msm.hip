@@ -38,7 +38,7 @@ static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, cursor, sorted, item_key, partial, node[4], ones[2], bsum, meta;
+    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, node[4], ones[2], bsum, meta;
     static constexpr size_t HOST_BYTES = 64 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
@@ -137,70 +137,60 @@ __global__ void __launch_bounds__(256) k_classify(const uint32_t* __restrict__ s
     }
 }
 
-// mode 0: histogram (counts[key] += 1); mode 1: scatter (sorted[cursor[key]++] = i | sign<<31).
-// Key `ones_key` collects the scalars equal to 1.
+// ------------------------------------------------------------------------------------------------ digit sort
+// (point, window) pairs are sorted by bucket with a two-level partition that never touches global
+// atomics (device-scope atomics from 8 XCDs are fabric transactions on MI355X; the first version of
+// this file spent more time in them than in curve arithmetic):
+//   level 1  k_part_hist / k_part_scatter: tiles of PART_TP points; per-tile LDS histogram over
+//            (window, high bucket bits) bins [+ one bin for scalars == 1]; an exclusive scan over
+//            [bin][tile] gives every tile a private output range per bin, ranks come from LDS atomics.
+//   level 2  k_part_local: one workgroup per bin sorts its segment by the low bucket bits in LDS,
+//            writes the per-bucket counts and the final (base index | sign) order.
+static constexpr int PART_TP = 4096;  // points per tile
+
+__device__ __forceinline__ bool scalar_is_zero(const Scalar256& s) {
+    return (s.w[0] | s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7]) == 0;
+}
+__device__ __forceinline__ bool scalar_is_one(const Scalar256& s) {
+    return s.w[0] == 1 && (s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7]) == 0;
+}
+
+// MODE 0: tile_tab[bin * ntiles + tile] = number of the tile's pairs in `bin`
+// MODE 1: tile_tab holds the exclusive scan of that table; pairs are written to A[pos] = {val, low bits}
 template <int MODE>
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars,
-                                                const uint32_t* __restrict__ index, size_t n, int c, int nwin,
-                                                uint32_t ones_key, uint32_t* __restrict__ counts_or_cursor,
-                                                uint32_t* __restrict__ sorted) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n_round = (n + 63) & ~(size_t)63;
-    const uint32_t B = 1u << (c - 1);
-    const uint32_t lane = lane_id();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool in = i < n;
-        Scalar256 s;
-#pragma unroll
-        for (int k = 0; k < 8; k++) s.w[k] = 0;
-        if (in) s = load_scalar(scalars, index ? (size_t)index[i] : i);
-        {   // scalar == 1: one aggregated atomic per wave on the ones bucket, then no digits
-            const bool one = s.w[0] == 1 && (s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7]) == 0;
-            const uint64_t om = __ballot(one);
-            if (om) {
-                const int leader = __ffsll((unsigned long long)om) - 1;
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&counts_or_cursor[ones_key], (uint32_t)__popcll(om));
-                if (MODE == 1) {
-                    base = __shfl(base, leader);
-                    if (one) sorted[base + mbcnt(om)] = (uint32_t)i;
-                }
-                if (one) s.w[0] = 0;
-            }
+__global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
+                                              size_t n, int c, int nwin, int hb, int lb, uint32_t ntiles,
+                                              uint32_t* __restrict__ tile_tab, uint2* __restrict__ A) {
+    extern __shared__ uint32_t lds_bins[];
+    const uint32_t nbins = ((uint32_t)nwin << hb) + 1u;  // last bin: scalars == 1
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x)
+        lds_bins[b] = MODE == 0 ? 0u : tile_tab[(size_t)b * ntiles + tile];
+    __syncthreads();
+    const size_t base = (size_t)tile * PART_TP;
+    const uint32_t lomask = (1u << lb) - 1u;
+    for (uint32_t k = threadIdx.x; k < (uint32_t)PART_TP; k += blockDim.x) {
+        const size_t i = base + k;
+        if (i >= n) break;
+        Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
+        if (scalar_is_zero(s)) continue;
+        if (scalar_is_one(s)) {
+            uint32_t pos = atomicAdd(&lds_bins[nbins - 1], 1u);
+            if (MODE == 1) A[pos] = make_uint2((uint32_t)i, 0u);
+            continue;
         }
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
             int32_t d = next_digit(s, c, carry);
-            const bool valid = d != 0;  // lanes past n hold a zero scalar: never valid
-            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            const uint32_t key = (uint32_t)w * B + mag - 1u;
-            const uint32_t val = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-            const uint64_t vm = __ballot(valid);
-            if (vm == 0) continue;  // wave-uniform
-            // Aggregate the lanes that share the leading lane's key into one atomic.
-            const int leader = __ffsll((unsigned long long)vm) - 1;
-            const uint32_t k0 = __shfl(key, leader);
-            const bool same = valid && key == k0;
-            const uint64_t sm = __ballot(same);
-            const uint32_t cnt = (uint32_t)__popcll(sm);
-            if (MODE == 0) {
-                if (same) {
-                    if ((int)lane == leader) atomicAdd(&counts_or_cursor[k0], cnt);
-                } else if (valid) {
-                    atomicAdd(&counts_or_cursor[key], 1u);
-                }
-            } else {
-                uint32_t base = 0;
-                if (same && (int)lane == leader) base = atomicAdd(&counts_or_cursor[k0], cnt);
-                base = __shfl(base, leader);
-                if (same) {
-                    sorted[base + mbcnt(sm)] = val;
-                } else if (valid) {
-                    uint32_t pos = atomicAdd(&counts_or_cursor[key], 1u);
-                    sorted[pos] = val;
-                }
-            }
+            if (d == 0) continue;
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1u;
+            uint32_t pos = atomicAdd(&lds_bins[((uint32_t)w << hb) | (mag >> lb)], 1u);
+            if (MODE == 1) A[pos] = make_uint2((uint32_t)i | (d < 0 ? 0x80000000u : 0u), mag & lomask);
         }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) tile_tab[(size_t)b * ntiles + tile] = lds_bins[b];
     }
 }
 
@@ -301,10 +291,92 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_final(const uint32_t* __r
         if (idx <= nkeys) {  // entry nkeys holds the totals
             offsets[idx] = ec;
             item_off[idx] = ei;
-            if (idx < nkeys) cursor[idx] = ec;
+            if (cursor && idx < nkeys) cursor[idx] = ec;
         }
         ec += cnt[k];
         ei += items_of(cnt[k], T, idx, nkeys);
+    }
+}
+
+// ---- plain exclusive scan of a u32 array (in place), entry n receives the total
+__global__ void __launch_bounds__(SCAN_THREADS) k_xscan_reduce(const uint32_t* __restrict__ v, size_t n,
+                                                               uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t lds[8];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    uint32_t sc = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) sc += base + k < n ? v[base + k] : 0u;
+    uint32_t tot;
+    block_excl_scan(sc, lds, tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) k_xscan_bsums(uint32_t* bsum, uint32_t nb) {
+    __shared__ uint32_t lds[16];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t idx = base + threadIdx.x;
+        uint32_t val = idx < nb ? bsum[idx] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(val, lds, tot);
+        if (idx < nb) bsum[idx] = carry + ex;
+        carry += tot;
+    }
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_xscan_final(uint32_t* __restrict__ v, size_t n,
+                                                              const uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t lds[8];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    uint32_t x[SCAN_PER_THREAD];
+    uint32_t sc = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        x[k] = base + k < n ? v[base + k] : 0u;
+        sc += x[k];
+    }
+    uint32_t tot;
+    uint32_t e = block_excl_scan(sc, lds, tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        if (base + k <= n) v[base + k] = e;   // v has n + 1 entries
+        e += x[k];
+    }
+}
+
+// level 2: one workgroup per bin; segment [tile_off[bin*ntiles], tile_off[(bin+1)*ntiles]) of A
+__global__ void __launch_bounds__(256) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
+                                                    uint32_t ntiles, uint32_t nbins, int lb,
+                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, then 8 words of scan scratch
+    const uint32_t bin = blockIdx.x;
+    const int bits = bin + 1 == nbins ? 0 : lb;   // the ones bin is a single bucket
+    const uint32_t nl = 1u << bits;
+    uint32_t* scratch = lds_l + (1u << lb);
+    const uint32_t start = tile_off[(size_t)bin * ntiles];
+    const uint32_t end = tile_off[(size_t)(bin + 1) * ntiles];   // the scanned table has nbins*ntiles + 1 entries
+    for (uint32_t b = threadIdx.x; b < nl; b += blockDim.x) lds_l[b] = 0;
+    __syncthreads();
+    for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&lds_l[A[i].y], 1u);
+    __syncthreads();
+    // exclusive prefix over the nl local buckets: each thread owns a run of consecutive buckets
+    const uint32_t per = (nl + blockDim.x - 1) / blockDim.x;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) sum += b0 + k < nl ? lds_l[b0 + k] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(sum, scratch, tot);
+    const uint32_t key0 = bin << lb;
+    for (uint32_t k = 0; k < per; k++) {
+        if (b0 + k < nl) {
+            uint32_t cnt = lds_l[b0 + k];
+            counts[key0 + b0 + k] = cnt;
+            lds_l[b0 + k] = start + ex;   // becomes the bucket's write cursor
+            ex += cnt;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) {
+        uint2 e = A[i];
+        sorted[atomicAdd(&lds_l[e.y], 1u)] = e.x;
     }
 }
 
@@ -471,45 +543,73 @@ struct MsmJob : MsmJobBase {
         P = plan_msm(n_real, n_ones);
         ones_key = P.nkeys;  // one extra bucket after the nwin * B regular ones
         nkeys = P.nkeys + 1;
-        ZG_HIP(ctx, S.counts.reserve((size_t)(nkeys + 1) * 4));
+        // bucket bits split into high (level-1 bins) and low (level-2, in LDS) parts
+        const int bbits = P.c - 1;
+        int hb = (bbits + 1) / 2;
+        if (hb > 8) hb = 8;
+        while (hb > 0 && (((size_t)P.nwin << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
+        const int lb = bbits - hb;
+        const uint32_t nbins = ((uint32_t)P.nwin << hb) + 1u;
+        const uint32_t ntiles = (uint32_t)((n + PART_TP - 1) / PART_TP);
+        const size_t tab_n = (size_t)nbins * ntiles;
+        const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
+        // counts is indexed by key = bin << lb | low bits; the ones bin only uses low bits == 0
+        const size_t counts_n = ((size_t)nbins << lb) + 1;
+        ZG_HIP(ctx, S.counts.reserve(counts_n * 4));
         ZG_HIP(ctx, S.offsets.reserve((size_t)(nkeys + 1) * 4));
         ZG_HIP(ctx, S.item_off.reserve((size_t)(nkeys + 1) * 4));
-        ZG_HIP(ctx, S.cursor.reserve((size_t)(nkeys + 1) * 4));
-        ZG_HIP(ctx, hipMemsetAsync(S.counts.p, 0, (size_t)(nkeys + 1) * 4, st));
+        ZG_HIP(ctx, S.tile_tab.reserve((tab_n + 1) * 4));
+        ZG_HIP(ctx, S.abuf.reserve(max_entries * 8));
+        ZG_HIP(ctx, S.sorted.reserve(max_entries * 4));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
-        hipLaunchKernelGGL(k_digits<0>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
-                           S.counts.as<uint32_t>(), (uint32_t*)nullptr);
-        // nkeys + 1 entries are scanned so that entry nkeys receives the totals
+        const size_t lds1 = (size_t)nbins * 4;
+        hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
+                           ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr);
+        {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
+            const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
+            const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
+            ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>((size_t)nbx, (size_t)2 * nbk) * 4));
+            hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
+                               S.bsum.as<uint32_t>());
+            hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nbx);
+            hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
+                               S.bsum.as<uint32_t>());
+        }
+        hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
+                           ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>());
+        // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
+        const size_t lds2 = ((size_t)4 << lb) + 64;
+        hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(256), lds2, st, S.abuf.as<uint2>(),
+                           S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, S.counts.as<uint32_t>(),
+                           S.sorted.as<uint32_t>());
+        // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
-        ZG_HIP(ctx, S.bsum.reserve((size_t)nb * 2 * 4));
         hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
                            S.bsum.as<uint32_t>(), nb);
         hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nb);
         hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
                            S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                           S.cursor.as<uint32_t>());
+                           (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
                            S.meta.as<uint32_t>());
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
+        ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
 
     int phase_c() override {
         if (done) return ZG_OK;
         const uint32_t* meta = reinterpret_cast<const uint32_t*>(S.host);
-        const uint32_t total_entries = meta[0], total_items = meta[1];
+        const uint32_t total_items = meta[1];
         const uint32_t ones_lo = meta[2], ones_hi = meta[3];
         if (total_items == 0) {
             done = true;
             return ZG_OK;
         }
-        ZG_HIP(ctx, S.sorted.reserve((size_t)total_entries * 4));
         ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
         ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
         {
-            ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
-            hipLaunchKernelGGL(k_digits<1>, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, P.c, P.nwin, ones_key,
-                               S.cursor.as<uint32_t>(), S.sorted.as<uint32_t>());
+            ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
                                nkeys, S.item_key.as<uint32_t>());
         }
