@@ -26,6 +26,8 @@ struct Ctx {
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
+    // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
+    struct ProveWs* prove_ws = nullptr;
     // reusable MSM scratch (one per concurrent job) and side streams, see msm.hip
     struct MsmScratch* msm_scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -38,7 +38,7 @@ static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, node[4], ones[2], bsum, meta;
+    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, node[4], ones[2], bsum, meta, heavy;
     static constexpr size_t HOST_BYTES = 64 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
@@ -160,7 +160,8 @@ __device__ __forceinline__ bool scalar_is_one(const Scalar256& s) {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
                                               size_t n, int c, int nwin, int hb, int lb, uint32_t ntiles,
-                                              uint32_t* __restrict__ tile_tab, uint2* __restrict__ A) {
+                                              uint32_t* __restrict__ tile_tab, uint2* __restrict__ A,
+                                              uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_bins[];
     const uint32_t nbins = ((uint32_t)nwin << hb) + 1u;  // last bin: scalars == 1
     const uint32_t tile = blockIdx.x;
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
         if (scalar_is_zero(s)) continue;
         if (scalar_is_one(s)) {
             uint32_t pos = atomicAdd(&lds_bins[nbins - 1], 1u);
-            if (MODE == 1) A[pos] = make_uint2((uint32_t)i, 0u);
+            if (MODE == 1) sorted[pos] = (uint32_t)i;   // the ones bin is one bucket and the last bin: final order
             continue;
         }
         uint32_t carry = 0;
@@ -353,6 +354,10 @@ __global__ void __launch_bounds__(256) k_part_local(const uint2* __restrict__ A,
     uint32_t* scratch = lds_l + (1u << lb);
     const uint32_t start = tile_off[(size_t)bin * ntiles];
     const uint32_t end = tile_off[(size_t)(bin + 1) * ntiles];   // the scanned table has nbins*ntiles + 1 entries
+    if (bin + 1 == nbins) {   // scalars == 1: k_part<1> already wrote them in final order
+        if (threadIdx.x == 0) counts[bin << lb] = end - start;
+        return;
+    }
     for (uint32_t b = threadIdx.x; b < nl; b += blockDim.x) lds_l[b] = 0;
     __syncthreads();
     for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&lds_l[A[i].y], 1u);
@@ -390,10 +395,11 @@ __global__ void k_meta(const uint32_t* offsets, const uint32_t* item_off, uint32
     }
 }
 
+// item -> key map for the regular keys (the ones key, last, is filled by a memset)
 __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict__ item_off, uint32_t nkeys,
                                                      uint32_t* __restrict__ item_key) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= nkeys) return;
+    if (key + 1 >= nkeys) return;
     uint32_t lo = item_off[key], hi = item_off[key + 1];
     for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
 }
@@ -426,6 +432,43 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ stage 2: bucket tree
+// Buckets split into more than HEAVY_ITEMS items (the top window of a small-c plan, or skewed
+// scalars) are folded by a whole workgroup first: partial[first item] receives the bucket sum, and the
+// leaf kernel reads only that.  heavy_list / heavy_cnt are filled by k_heavy_collect.
+static constexpr uint32_t HEAVY_ITEMS = 4;
+__global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restrict__ item_off, uint32_t nkeys_regular,
+                                                       uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys_regular) return;
+    if (item_off[key + 1] - item_off[key] > HEAVY_ITEMS) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
+}
+template <class F>
+__global__ void __launch_bounds__(128) k_heavy_fold(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
+                                                    const uint32_t* __restrict__ heavy_cnt,
+                                                    const uint32_t* __restrict__ heavy_list) {
+    using L = typename LazyOf<F>::L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_h);
+    const uint32_t cnt = *heavy_cnt;
+    for (uint32_t slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const uint32_t key = heavy_list[slot];
+        const uint32_t lo = item_off[key], hi = item_off[key + 1];
+        XYZZd<L> acc = XYZZd<L>::inf();
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = acc.add(XYZZd<L>::load(&partial[i]));
+        acc.store(&lds[threadIdx.x]);
+        __syncthreads();
+        for (uint32_t st = blockDim.x >> 1; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                acc = acc.add(XYZZd<L>::load(&lds[threadIdx.x + st]));
+                acc.store(&lds[threadIdx.x]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) acc.store(&partial[lo]);
+        __syncthreads();
+    }
+}
+
 // Leaf level: node g covers buckets [g << fbits, (g+1) << fbits).  Bucket b of the node has weight t+1
 // (t = b - first bucket):  R = sum bucket_t,  W = sum (t+1) bucket_t  via the running sum.
 template <class F>
@@ -439,6 +482,7 @@ __global__ void __launch_bounds__(128) k_tree_leaf(const XYZZ<F>* __restrict__ p
     XYZZd<L> run = XYZZd<L>::inf(), acc = XYZZd<L>::inf();
     for (int t = (1 << fbits) - 1; t >= 0; t--) {
         uint32_t lo = item_off[first + t], hi = item_off[first + t + 1];
+        if (hi - lo > HEAVY_ITEMS) hi = lo + 1;   // folded into partial[lo] by k_heavy_fold
         for (uint32_t i = lo; i < hi; i++) run = run.add(XYZZd<L>::load(&partial[i]));
         acc = acc.add(run);
     }
@@ -564,7 +608,7 @@ struct MsmJob : MsmJobBase {
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
-                           ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr);
+                           ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -576,7 +620,7 @@ struct MsmJob : MsmJobBase {
                                S.bsum.as<uint32_t>());
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
-                           ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>());
+                           ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(256), lds2, st, S.abuf.as<uint2>(),
@@ -612,6 +656,9 @@ struct MsmJob : MsmJobBase {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
                                nkeys, S.item_key.as<uint32_t>());
+            if (ones_hi > ones_lo)
+                ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
+                                              ones_hi - ones_lo, st));
         }
         {
             ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st);
@@ -629,6 +676,15 @@ struct MsmJob : MsmJobBase {
         curW = S.node[1].template as<XYZZ<F>>();
         XYZZ<F>* nxtR = S.node[2].template as<XYZZ<F>>();
         XYZZ<F>* nxtW = S.node[3].template as<XYZZ<F>>();
+        {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
+            ZG_HIP(ctx, S.heavy.reserve(((size_t)P.nkeys + 1) * 4));
+            uint32_t* hcnt = S.heavy.as<uint32_t>();
+            ZG_HIP(ctx, hipMemsetAsync(hcnt, 0, 4, st));
+            hipLaunchKernelGGL(k_heavy_collect, dim3((P.nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
+                               P.nkeys, hcnt, hcnt + 1);
+            hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
+                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hcnt + 1);
+        }
         hipLaunchKernelGGL((k_tree_leaf<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
                            S.item_off.as<uint32_t>(), n_nodes, f1, curR, curW);
         int sbits = f1;

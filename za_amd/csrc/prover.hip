@@ -71,6 +71,16 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, Fr* __
 
 using namespace zg;
 
+namespace zg {
+struct ProveWs {
+    DevBuf abc[3], h;
+};
+}  // namespace zg
+static ProveWs& prove_ws(zg_ctx* ctx) {
+    if (!ctx->prove_ws) ctx->prove_ws = new ProveWs();
+    return *ctx->prove_ws;
+}
+
 // ------------------------------------------------------------------------------------------------ ctx
 extern "C" int zg_init(int device, zg_ctx** out) {
     if (!out) return ZG_E_INVALID_ARG;
@@ -96,6 +106,8 @@ extern "C" void zg_free(zg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ntt_tables_free(ctx);
     msm_scratch_free(ctx);
+    delete ctx->prove_ws;
+    ctx->prove_ws = nullptr;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -571,11 +583,11 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     const size_t m = (size_t)1 << r->log_m;
     double t0 = now_ms();
-    DevBuf d[3];
+    ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
     for (int k = 0; k < 3; k++) {
-        ZG_HIP(ctx, d[k].alloc(m * sizeof(Fr)));
-        abc[k] = d[k].as<Fr>();
+        ZG_HIP(ctx, ws.abc[k].reserve(m * sizeof(Fr)));
+        abc[k] = ws.abc[k].as<Fr>();
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -693,8 +705,8 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     double t0 = now_ms();
     ZG_TRY(check_query_sizes(ctx, p, r));
     const size_t m = (size_t)1 << r->log_m;
-    DevBuf dh;
-    ZG_HIP(ctx, dh.alloc(m * 32));
+    DevBuf& dh = prove_ws(ctx).h;
+    ZG_HIP(ctx, dh.reserve(m * 32));
     ZG_TRY(zg_prove_h_dev(ctx, r, d_witness, dh.p));
     uint8_t partials[ZG_PARTIALS_BYTES];
     ZG_TRY(zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials));
