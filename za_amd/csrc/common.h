@@ -32,6 +32,7 @@ struct Ctx {
     struct MsmScratch* msm_scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t side_ev = nullptr;
+    hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip)
     bool side_ready = false;
 };
 
@@ -109,7 +110,8 @@ struct MsmDesc {
     size_t n;
 };
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
-int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2);
+int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
+               hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr);
 void msm_scratch_free(Ctx* ctx);
 
 // ---- ntt.hip

@@ -28,6 +28,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "common.h"
 
@@ -741,14 +742,36 @@ struct MsmJob : MsmJobBase {
     }
 };
 
+// Advance every job as soon as ITS stream has drained (hipStreamQuery), so jobs do not wait for each
+// other's read-backs: a job whose stream is gated on an event (the h MSM waits for the NTT pipeline)
+// simply stays in its first phase while the others run ahead.
 static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
-    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_a());
-    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
-    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_b());
-    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
-    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->phase_c());
-    for (int j = 0; j < njobs; j++) ZG_HIP(ctx, hipStreamSynchronize(jobs[j]->st));
-    for (int j = 0; j < njobs; j++) ZG_TRY(jobs[j]->finish());
+    int state[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
+    int remaining = njobs;
+    while (remaining > 0) {
+        bool progressed = false;
+        for (int j = 0; j < njobs; j++) {
+            if (state[j] == 4) continue;
+            if (state[j] == 0) {
+                ZG_TRY(jobs[j]->phase_a());
+                state[j] = 1;
+                progressed = true;
+                continue;
+            }
+            hipError_t q = hipStreamQuery(jobs[j]->st);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return fail(ctx, ZG_E_HIP, "stream query failed: %s", hipGetErrorString(q));
+            if (state[j] == 1) ZG_TRY(jobs[j]->phase_b());
+            else if (state[j] == 2) ZG_TRY(jobs[j]->phase_c());
+            else {
+                ZG_TRY(jobs[j]->finish());
+                remaining--;
+            }
+            state[j]++;
+            progressed = true;
+        }
+        if (!progressed) std::this_thread::yield();
+    }
     return ZG_OK;
 }
 
@@ -770,23 +793,32 @@ int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const u
     return run_jobs(ctx, jobs, 1);
 }
 
-// The five multiexps of create_proof, concurrently on the ctx's side streams.
-int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2) {
-    // side streams start after everything already queued on the main stream
+// The five multiexps of create_proof, concurrently on the ctx's side streams.  The witness MSMs
+// (l, a, b_g1, b_g2) are gated on `ev_witness`, the h MSM on `ev_h` (both recorded by the caller on
+// ctx->stream; NULL = whatever is already queued there).  The witness jobs run at high stream
+// priority: their big-register G2 / tree kernels would otherwise starve behind the h accumulation.
+int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
+               hipEvent_t ev_h) {
     if (!ctx->side_ready) {
-        for (int k = 0; k < 5; k++) ZG_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
+        for (int k = 0; k < 5; k++)
+            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, k == 0 ? lo_prio : hi_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
         ctx->side_ready = true;
     }
     ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
-    for (int k = 0; k < 5; k++) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ctx->side_ev, 0));
+    for (int k = 0; k < 5; k++) {
+        hipEvent_t ev = k == 0 ? ev_h : ev_witness;
+        ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
+    }
     MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
     MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
     MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
     MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
     MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
-    // heaviest first: the G2 job, then h, then the witness MSMs
-    MsmJobBase* jobs[5] = {&j2, &j0, &j1, &j3, &j4};
+    // the G2 job has the longest chain: first; h (gated on the NTT) last
+    MsmJobBase* jobs[5] = {&j2, &j1, &j3, &j4, &j0};
     return run_jobs(ctx, jobs, 5);
 }
 

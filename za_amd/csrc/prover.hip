@@ -9,6 +9,7 @@
 #include <chrono>
 #include <memory>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 
@@ -85,6 +86,9 @@ static ProveWs& prove_ws(zg_ctx* ctx) {
 extern "C" int zg_init(int device, zg_ctx** out) {
     if (!out) return ZG_E_INVALID_ARG;
     *out = nullptr;
+    // five MSM streams + the main stream want their own hardware queues (ROCm's default is 4 per
+    // process); only effective if this is the first HIP call of the process, never overrides the user
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZG_E_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return ZG_E_NO_DEVICE;
@@ -577,12 +581,9 @@ static int check_query_sizes(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) 
     return ZG_OK;
 }
 
-extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
-    if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
-    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
-    ZG_HIP(ctx, hipSetDevice(ctx->device));
+// queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
+static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
     const size_t m = (size_t)1 << r->log_m;
-    double t0 = now_ms();
     ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
     for (int k = 0; k < 3; k++) {
@@ -590,13 +591,17 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
         abc[k] = ws.abc[k].as<Fr>();
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc));
+    return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
+}
+extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+    if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    double t0 = now_ms();
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_h_out));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double t1 = now_ms();
-    ZG_TRY(h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out));
-    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double t2 = now_ms();
-    ctx->timings[1] = t1 - t0;
-    ctx->timings[2] = t2 - t1;
+    ctx->timings[1] = 0;
+    ctx->timings[2] = now_ms() - t0;   // R1CS evaluation + H
     return ZG_OK;
 }
 
@@ -637,7 +642,7 @@ extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r
         const auto& q = p->q[4];
         d2 = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
     }
-    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc));
+    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ctx->ev_witness, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
@@ -707,9 +712,23 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     const size_t m = (size_t)1 << r->log_m;
     DevBuf& dh = prove_ws(ctx).h;
     ZG_HIP(ctx, dh.reserve(m * 32));
-    ZG_TRY(zg_prove_h_dev(ctx, r, d_witness, dh.p));
+    // The witness MSMs do not depend on H: gate them on "now", queue the NTT pipeline, gate the h MSM
+    // on its completion, and let the job scheduler overlap everything.
+    static thread_local hipEvent_t ev_w = nullptr, ev_h = nullptr;
+    if (!ev_w) {
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ev_w, hipEventDisableTiming));
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
+    }
+    ZG_HIP(ctx, hipEventRecord(ev_w, ctx->stream));
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p));
+    ZG_HIP(ctx, hipEventRecord(ev_h, ctx->stream));
+    ctx->ev_witness = ev_w;
+    ctx->ev_h = ev_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
-    ZG_TRY(zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials));
+    int rc_p = zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials);
+    ctx->ev_witness = ctx->ev_h = nullptr;
+    ZG_TRY(rc_p);
+    ctx->timings[1] = ctx->timings[2] = 0;   // overlapped with the MSMs: see zg_profile_* for kernel times
     ZG_TRY(zg_prove_combine(ctx, p, partials, 1, r_le, s_le, proof_out));
     ctx->timings[5] = now_ms() - t0;
     return ZG_OK;
