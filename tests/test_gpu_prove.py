@@ -202,3 +202,37 @@ def test_full_size_proof_matches_discrete_log_expectation(ctx):
     pa, pb, pc = bn.g1_from_mont_bytes(A), bn.g2_from_mont_bytes(B), bn.g1_from_mont_bytes(Cc)
     assert got == g.proof_bytes((pa, pb, pc))
     sr.close()
+
+
+def test_gpu_engine_through_torch_distributed_world1(ctx):
+    """za_amd.dist.GpuEngine + sharded_prove on a real GPU (single-rank process group): exercises the
+    torch-tensor plumbing (H buffer, partials tensor) that bench.py --gpus N uses on every rank."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from za_amd import synth
+    from za_amd.dist import GpuEngine, sharded_prove
+    lg = 12
+    sr = synth.SynthR1CS(lg, 2, 0.9, 777)
+    R = sr.load(ctx)
+    m = 1 << lg
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 31)
+    d_w = ctx.upload(sr.witness)
+    expect = ctx.prove_dev(P, R, d_w, 11, 22)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        torch.cuda.set_device(0)
+        eng = GpuEngine(ctx, P, R, d_w, 1)
+        got = sharded_prove(eng, 11, 22)
+        assert got == expect
+        # a second call reuses the cached H buffer
+        assert sharded_prove(eng, 11, 22) == expect
+    finally:
+        if created:
+            dist.destroy_process_group()
+    sr.close()

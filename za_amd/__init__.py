@@ -58,6 +58,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ZaAmdError(-1, "libza_amd.so is missing: build it with `python za_amd/build.py` "
                                  "(there is no Python/CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HSA runtimes cannot
+        # share a process, and whichever loads first wins the SONAME: load torch's first so that
+        # libza_amd.so binds to the same runtime torch.distributed (RCCL) uses.  Not needed for C callers.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.zg_strerror.restype = C.c_char_p
         lib.zg_last_error.restype = C.c_char_p

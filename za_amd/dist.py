@@ -39,6 +39,9 @@ def sharded_prove(engine, r, s, group=None):
         scatter_list = None
     if world > 1:
         dist.scatter(mine, scatter_list, src=0, group=group)
+        # the library launches on its own HIP streams: make the received chunk visible to them
+        if mine.is_cuda:
+            torch.cuda.current_stream(mine.device).synchronize()
     else:
         mine = scatter_list[0]
     part = engine.partials(mine)
