@@ -173,7 +173,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-        acc_ms, acc_n, acc_bytes = prof["msm_accumulate_g1"]
+        acc_ms, acc_n, acc_bytes, acc_units = prof["msm_accumulate_g1"]
         roof = None
         if acc_n:
             achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
@@ -188,6 +188,13 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "launches": acc_n, "avg_launch_ms": acc_ms / acc_n,
                     "algorithmic_bytes_per_launch": acc_bytes / acc_n}
+            # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add
+            # = 8 mul + 2 sqr in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32.  Peak = tools/ubench_valu.hip:
+            # 467.5 G wave-instr/s * 64 lanes on this chip.
+            mads = acc_units * (8 * 162 + 2 * 126)
+            roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "achieved": mads / (acc_ms * 1e-3),
+                                     "peak": 467.5e9 * 64, "frac": mads / (acc_ms * 1e-3) / (467.5e9 * 64),
+                                     "mixed_adds_per_launch": acc_units / acc_n}
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

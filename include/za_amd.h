@@ -199,6 +199,8 @@ int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 int zg_profile_enable(zg_ctx* ctx, int on);
 int zg_profile_reset(zg_ctx* ctx);
 int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes);
+/* work units of the timed launches: mixed additions for the msm_accumulate classes, butterflies for ntt_pass */
+int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units);
 const char* zg_profile_name(int id);
 
 #ifdef __cplusplus

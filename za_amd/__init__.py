@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_proof_json", "zg_last_timings",
-    "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_name",
+    "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
 
 
@@ -269,13 +269,15 @@ class Context:
         self._check(self.lib.zg_profile_reset(self.h))
 
     def profile_get(self):
-        """{kernel class: (total ms, launches, algorithmic bytes)} since the last reset."""
+        """{kernel class: (total ms, launches, algorithmic bytes, work units)} since the last reset."""
         self.lib.zg_profile_name.restype = C.c_char_p
         out = {}
         for i in range(7):
             ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
             self._check(self.lib.zg_profile_get(self.h, C.c_int(i), C.byref(ms), C.byref(n), C.byref(b)))
-            out[self.lib.zg_profile_name(C.c_int(i)).decode()] = (ms.value, n.value, b.value)
+            u = C.c_uint64()
+            self._check(self.lib.zg_profile_get_units(self.h, C.c_int(i), C.byref(u)))
+            out[self.lib.zg_profile_name(C.c_int(i)).decode()] = (ms.value, n.value, b.value, u.value)
         return out
 
     def last_timings(self):

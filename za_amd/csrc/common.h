@@ -21,9 +21,9 @@ struct Ctx {
     double timings[6] = {0, 0, 0, 0, 0, 0};
     // optional per-kernel timing with HIP events on `stream` (zg_profile_*)
     bool prof_enabled = false;
-    struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes; };
+    struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes, units; };
     std::vector<ProfPending> prof_pending;
-    struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0; } prof[8];
+    struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
@@ -44,9 +44,10 @@ enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDU
 struct ProfScope {
     Ctx* c; int idx = -1;
     hipStream_t st;
-    ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream) {
+    ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr, uint64_t units = 0)
+        : c(ctx), st(stream ? stream : ctx->stream) {
         if (!ctx->prof_enabled) return;
-        Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes};
+        Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes, units};
         if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
         (void)hipEventRecord(p.e0, st);
         ctx->prof_pending.push_back(p);

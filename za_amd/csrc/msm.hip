@@ -662,7 +662,7 @@ struct MsmJob : MsmJobBase {
                                               ones_hi - ones_lo, st));
         }
         {
-            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st);
+            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st, meta[0]);  // units: mixed adds
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                S.item_key.as<uint32_t>(), total_items, P.T, ones_key, S.partial.as<XYZZ<F>>());

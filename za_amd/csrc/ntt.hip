@@ -256,7 +256,7 @@ static int dif_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m) {
         if (j < 0) j = 0;
         size_t tiles = ((size_t)1 << log_m) >> (k + j);
         size_t lds_bytes = (size_t)36 << (k + j);   // 9 u32 limbs per element
-        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m);
+        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);  // units: butterflies
         hipLaunchKernelGGL(k_ntt_dif_pass, dim3((unsigned)tiles), dim3(256), lds_bytes, ctx->stream, d, tw, (int)log_m,
                            s_hi, k, j, contiguous);
         ZG_HIP(ctx, hipGetLastError());

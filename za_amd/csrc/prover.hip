@@ -190,6 +190,7 @@ static int prof_drain(zg_ctx* ctx) {
             ctx->prof[p.id].ms += ms;
             ctx->prof[p.id].launches += 1;
             ctx->prof[p.id].bytes += p.bytes;
+            ctx->prof[p.id].units += p.units;
         }
         if (p.e0) (void)hipEventDestroy(p.e0);
         if (p.e1) (void)hipEventDestroy(p.e1);
@@ -209,6 +210,12 @@ extern "C" int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launche
     *ms = ctx->prof[id].ms;
     *launches = ctx->prof[id].launches;
     *alg_bytes = ctx->prof[id].bytes;
+    return ZG_OK;
+}
+extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) {
+    if (!ctx || id < 0 || id >= PROF_COUNT || !units) return ZG_E_INVALID_ARG;
+    ZG_TRY(prof_drain(ctx));
+    *units = ctx->prof[id].units;
     return ZG_OK;
 }
 extern "C" const char* zg_profile_name(int id) {
