@@ -146,6 +146,18 @@ void zg_params_free(zg_params* p);
  * prover/src/groth16/format.rs:223-247) and return the offset of the bellman Parameters body. */
 int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
 
+/* ---- circuits shipped inside a za proving key --------------------------------
+ * zg_pk_load reads a whole `proving.key` as `za setup` writes it (write_pk, prover/src/groth16/format.rs:223-252;
+ * read_pk :254-293): the bincode'd constraints become the CSR R1CS in the variable numbering of
+ * CircomCircuit::synthesize (prover.rs:45-103: ONE, main public signals as inputs, ignore_signals skipped, the rest
+ * aux; a*b + c = 0 becomes A = a, B = b, C = -c), the bellman Parameters body becomes the resident key.
+ * zg_witness_from_binwitness turns the evaluator's `.binwitness` dump (compiler/src/tester/embeeded.rs:47-57,
+ * FS::write_256_w32 at compiler/src/algebra/fs.rs:116-126) into the witness vector zg_prove expects. */
+int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checked, int rank, int world, zg_r1cs** r1cs_out,
+               zg_params** params_out);
+int zg_witness_from_binwitness(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* binwitness, size_t len,
+                               uint8_t* witness32_out, size_t cap);
+
 /* ---- prove -----------------------------------------------------------------------------------
  * Replaces bellman_ce::groth16::create_proof(circuit, params, r, s) -- the deterministic core of
  * create_random_proof (prover/src/groth16/prover.rs:173).  witness32 = (n_inputs + n_aux)

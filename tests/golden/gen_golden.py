@@ -127,7 +127,18 @@ def ntt_kats():
     dump("ntt_kat.json", out)
 
 
-def proof_fixture(name, r1, w, trapdoor, r, s, qeqs=None):
+def w32(x):
+    """FS::write_256_w32 (compiler/src/algebra/fs.rs:116-126): 32 big-endian bytes, 4-byte groups last to first."""
+    b = int(x).to_bytes(32, "big")
+    return b"".join(b[n * 4:(n + 1) * 4] for n in reversed(range(8)))
+
+
+def binwitness(values):
+    """compiler/src/tester/embeeded.rs:47-57: count, then the value of every signal (id 0 = ONE)."""
+    return w32(len(values)) + b"".join(w32(v) for v in values)
+
+
+def proof_fixture(name, r1, w, trapdoor, r, s, qeqs=None, ignore_at=None):
     alpha, beta, gamma, delta, tau = trapdoor
     params, trap = g.generate_parameters(r1, alpha, beta, gamma, delta, tau)
     proof = g.create_proof(r1, params, w, r, s)
@@ -154,6 +165,18 @@ def proof_fixture(name, r1, w, trapdoor, r, s, qeqs=None):
     }
     if qeqs is not None:
         rec["pk_container"] = hx(g.pk_container_write(qeqs, [], pbytes))
+        rec["binwitness"] = hx(binwitness(w))
+    if ignore_at is not None:
+        # the same circuit as za would store it when the optimizer removed signal `ignore_at`:
+        # signal id = variable index, shifted by one past the ignored id; QEQ c = -C
+        def sig(v):
+            return v if v < ignore_at else v + 1
+        qs = [([(sig(v), c) for v, c in A], [(sig(v), c) for v, c in B], [(sig(v), (bn.R - c) % bn.R) for v, c in C])
+              for A, B, C in r1.constraints]
+        rec["pk_container"] = hx(g.pk_container_write(qs, [ignore_at], pbytes))
+        vals = list(w[:ignore_at]) + [0xDEAD] + list(w[ignore_at:])
+        rec["binwitness"] = hx(binwitness(vals))
+        rec["ignore_signals"] = [ignore_at]
     dump(name, rec)
 
 
@@ -170,7 +193,7 @@ def main():
     # a 2^7-domain circuit with mixed bit / field rows, 3 public inputs
     r2, w2 = chain_r1cs(7, n_inputs=3, seed=77, bit_fraction=0.6)
     td = tuple(rng.randrange(1, bn.R) for _ in range(5))
-    proof_fixture("proof_chain7.json", r2, w2, td, rng.randrange(bn.R), rng.randrange(bn.R))
+    proof_fixture("proof_chain7.json", r2, w2, td, rng.randrange(bn.R), rng.randrange(bn.R), ignore_at=r2.num_inputs + 5)
 
 
 if __name__ == "__main__":

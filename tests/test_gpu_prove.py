@@ -236,3 +236,29 @@ def test_gpu_engine_through_torch_distributed_world1(ctx):
         if created:
             dist.destroy_process_group()
     sr.close()
+
+
+@pytest.mark.parametrize("name", ["proof_factor.json", "proof_chain7.json"])
+def test_prove_from_za_proving_key_and_binwitness(ctx, name):
+    """a whole `proving.key` (constraints + ignore_signals + bellman Parameters,
+    format.rs:223-293) and the evaluator's .binwitness dump give the same proof as the flattened inputs."""
+    fx = golden(name)
+    R, P = ctx.pk_load(bytes.fromhex(fx["pk_container"]))
+    assert (R.n_inputs, R.n_aux, R.n_constraints) == (fx["n_inputs"], fx["n_aux"], len(fx["constraints"]))
+    w = ctx.witness_from_binwitness(R, bytes.fromhex(fx["binwitness"]))
+    assert bytes(w) == co.witness_bytes([int(x, 16) for x in fx["witness"]])
+    proof = ctx.prove(P, R, w, int(fx["r"], 16), int(fx["s"], 16))
+    assert proof.hex() == fx["proof"]
+
+
+def test_pk_load_rejects_inconsistent_containers(ctx):
+    import za_amd
+    fx = golden("proof_chain7.json")
+    pk = bytearray(bytes.fromhex(fx["pk_container"]))
+    with pytest.raises(za_amd.ZaAmdError):
+        ctx.pk_load(bytes(pk[:200]))
+    R, P = ctx.pk_load(bytes(pk))
+    bw = bytes.fromhex(fx["binwitness"])
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.witness_from_binwitness(R, bw[:-32])
+    assert e.value.code == za_amd.ZG_E_BAD_FORMAT if hasattr(za_amd, "ZG_E_BAD_FORMAT") else True

@@ -20,6 +20,7 @@ ZG_E_ASSIGNMENT_MISSING = 1
 ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE = 4
 ZG_E_UNEXPECTED_IDENTITY = 5
 ZG_E_IO = 6
+ZG_E_BAD_FORMAT = 20
 ZG_E_QUERY_SIZE = 21
 ZG_E_INVALID_ARG = 22
 ZG_E_BUFFER_TOO_SMALL = 23
@@ -35,6 +36,7 @@ ABI_SYMBOLS = [
     "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
+    "zg_pk_load", "zg_witness_from_binwitness",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_proof_json", "zg_last_timings",
@@ -228,6 +230,21 @@ class Context:
         self._check(self.lib.zg_params_load(self.h, _ptr(b), C.c_size_t(b.size), C.c_int(int(checked)), C.c_int(rank),
                                             C.c_int(world), C.byref(hd), C.byref(used)))
         return Params(self, hd), used.value
+
+    def pk_load(self, pk_bytes, checked=True, rank=0, world=1):
+        """A whole za `proving.key` -> (R1CS, Params)."""
+        b = _u8(pk_bytes)
+        rh, ph = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.zg_pk_load(self.h, _ptr(b), C.c_size_t(b.size), C.c_int(int(checked)), C.c_int(rank),
+                                        C.c_int(world), C.byref(rh), C.byref(ph)))
+        return R1CS(self, rh), Params(self, ph)
+
+    def witness_from_binwitness(self, r1cs, binwitness):
+        b = _u8(binwitness)
+        out = np.zeros(32 * (r1cs.n_inputs + r1cs.n_aux), dtype=np.uint8)
+        self._check(self.lib.zg_witness_from_binwitness(self.h, r1cs.h, _ptr(b), C.c_size_t(b.size), _ptr(out),
+                                                        C.c_size_t(out.size)))
+        return out
 
     def prove(self, params, r1cs, witness, r, s):
         """witness: (n_inputs+n_aux) x 32 B canonical LE; r, s: ints.  Returns the 256-byte proof."""

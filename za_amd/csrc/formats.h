@@ -24,6 +24,21 @@ int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
 // proof.json (format.rs:80-128)
 int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, std::string* out);
 
+// R1CS recovered from a za proving key (format.rs:223-247) in the variable numbering of
+// CircomCircuit::synthesize (prover.rs:45-103)
+struct PkR1cs {
+    uint32_t n_inputs = 0, n_aux = 0;
+    uint64_t n_constraints = 0;
+    size_t params_offset = 0;
+    std::vector<uint32_t> var_of_signal;   // UINT32_MAX for ignored signals
+    std::vector<uint64_t> row_ptr[3];
+    std::vector<uint32_t> col[3];
+    std::vector<uint8_t> coeff[3];
+};
+int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public, uint32_t n_aux, PkR1cs* out);
+int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal, uint32_t n_vars, const uint8_t* bw,
+                            size_t len, uint8_t* witness_out);
+
 Fq2 g2_coeff_b();                       // 3/(9+u), Montgomery
 void fq_to_be(uint8_t out[32], const Fq& mont);
 bool fq_from_be(const uint8_t in[32], Fq* mont);  // false if >= q

@@ -302,3 +302,143 @@ int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t 
 }
 
 }  // namespace zg
+
+namespace zg {
+
+// ---- za proving-key container -> R1CS ------------------------------------------
+// Layout: prover/src/groth16/format.rs:223-252 (write_pk), read back at :254-293.  bincode(QEQ) = three LCs
+// (a, b, c with a*b + c = 0, compiler/src/types/constraint.rs:51); an LC is u64le count, then per term
+// u64le signal id, u64le n_words, n_words x u32le little-endian base-2^32 digits (num-bigint 0.2 serde of
+// compiler/src/algebra/fs.rs:34).
+namespace {
+struct LeReader {
+    const uint8_t* p;
+    size_t len, pos;
+    bool u64(uint64_t* v) {
+        if (pos + 8 > len) return false;
+        uint64_t x = 0;
+        for (int i = 0; i < 8; i++) x |= (uint64_t)p[pos + i] << (8 * i);
+        pos += 8;
+        *v = x;
+        return true;
+    }
+    bool u32(uint32_t* v) {
+        if (pos + 4 > len) return false;
+        *v = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16) | ((uint32_t)p[pos + 3] << 24);
+        pos += 4;
+        return true;
+    }
+};
+}  // namespace
+
+int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* |ic| - 1 */, uint32_t n_aux /* |l| */,
+                  PkR1cs* out) {
+    Reader rd{pk, len};
+    uint32_t n;
+    const uint8_t* b;
+    if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated AST blob");
+    uint32_t nc;
+    if (!rd.u32be(&nc)) return fail(ctx, ZG_E_IO, "pk: truncated constraint count");
+    struct Term { uint64_t sig; Fr coeff; };
+    std::vector<std::vector<Term>> lcs[3];
+    for (int k = 0; k < 3; k++) lcs[k].resize(nc);
+    uint64_t max_sig = 0;
+    for (uint32_t i = 0; i < nc; i++) {
+        if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated constraint %u", i);
+        LeReader lr{b, n, 0};
+        for (int k = 0; k < 3; k++) {
+            uint64_t cnt;
+            if (!lr.u64(&cnt) || cnt > n) return fail(ctx, ZG_E_BAD_FORMAT, "pk: bad LC in constraint %u", i);
+            for (uint64_t t = 0; t < cnt; t++) {
+                uint64_t sig, nw;
+                if (!lr.u64(&sig) || !lr.u64(&nw) || nw > 8) return fail(ctx, ZG_E_BAD_FORMAT, "pk: bad term in constraint %u", i);
+                Fr c = Fr::zero();
+                for (uint64_t w = 0; w < nw; w++)
+                    if (!lr.u32(&c.l[w])) return fail(ctx, ZG_E_BAD_FORMAT, "pk: truncated coefficient in constraint %u", i);
+                lcs[k][i].push_back(Term{sig, c});
+                if (sig > max_sig) max_sig = sig;
+            }
+        }
+        if (lr.pos != n) return fail(ctx, ZG_E_BAD_FORMAT, "pk: trailing bytes in constraint %u", i);
+    }
+    uint32_t ni;
+    if (!rd.u32be(&ni)) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
+    std::vector<uint32_t> ignore(ni);
+    for (uint32_t i = 0; i < ni; i++)
+        if (!rd.u32be(&ignore[i])) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
+    out->params_offset = rd.pos;
+    // variable numbering of CircomCircuit::synthesize (prover.rs:55-88): ONE, then signal ids in order;
+    // ignored ids get no variable; main public inputs (ids 1..n_public: the evaluator numbers outputs and public
+    // inputs first, compiler/src/evaluator/test.rs:739-768) are inputs; the rest are aux.
+    const uint64_t n_signals = 1ull + n_public + n_aux + ni;
+    if (max_sig >= n_signals)
+        return fail(ctx, ZG_E_BAD_FORMAT, "pk: signal id %llu but the key describes %llu signals",
+                    (unsigned long long)max_sig, (unsigned long long)n_signals);
+    out->n_inputs = n_public + 1;
+    out->n_aux = n_aux;
+    out->var_of_signal.assign(n_signals, UINT32_MAX);
+    out->var_of_signal[0] = 0;
+    size_t ig = 0;
+    uint32_t next_in = 1, next_aux = 0;
+    for (uint64_t id = 1; id < n_signals; id++) {
+        if (ig < ignore.size() && ignore[ig] == id) {
+            ig++;
+            if (id <= n_public) return fail(ctx, ZG_E_BAD_FORMAT, "pk: public signal %llu is in ignore_signals", (unsigned long long)id);
+            continue;
+        }
+        if (id <= n_public) out->var_of_signal[id] = next_in++;
+        else out->var_of_signal[id] = out->n_inputs + next_aux++;
+    }
+    if (ig != ignore.size()) return fail(ctx, ZG_E_BAD_FORMAT, "pk: ignore_signals is not sorted / in range");
+    if (next_aux != n_aux) return fail(ctx, ZG_E_BAD_FORMAT, "pk: aux count mismatch");
+    for (int k = 0; k < 3; k++) {
+        out->row_ptr[k].assign(1, 0);
+        out->col[k].clear();
+        out->coeff[k].clear();
+        for (uint32_t i = 0; i < nc; i++) {
+            for (const Term& t : lcs[k][i]) {
+                uint32_t v = out->var_of_signal[t.sig];
+                if (v == UINT32_MAX)
+                    return fail(ctx, ZG_E_BAD_FORMAT, "pk: constraint %u uses ignored signal %llu (signal not defined, format.rs:215)",
+                                i, (unsigned long long)t.sig);
+                Fr c = t.coeff;
+                if (k == 2) c = c.to_mont().neg().from_mont();   // bellman gets a*b = -c (prover.rs:98)
+                out->col[k].push_back(v);
+                const uint8_t* cb = reinterpret_cast<const uint8_t*>(&c);
+                out->coeff[k].insert(out->coeff[k].end(), cb, cb + 32);
+            }
+            out->row_ptr[k].push_back(out->col[k].size());
+        }
+    }
+    out->n_constraints = nc;
+    return ZG_OK;
+}
+
+// .binwitness (compiler/src/tester/embeeded.rs:47-57): 256-bit values written by FS::write_256_w32
+// (fs.rs:116-126: 32 big-endian bytes, 4-byte groups emitted last-to-first): first the signal count, then the
+// value of every signal id 0.. (id 0 = ONE).
+static void read_w32(const uint8_t* p, uint8_t out_le[32]) {
+    // group g (0..7) holds big-endian bytes of 32-bit word g counted from the least significant
+    for (int g = 0; g < 8; g++)
+        for (int k = 0; k < 4; k++) out_le[4 * g + k] = p[4 * g + (3 - k)];
+}
+int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal, uint32_t n_vars, const uint8_t* bw,
+                            size_t len, uint8_t* witness_out) {
+    if (len < 32 || len % 32) return fail(ctx, ZG_E_BAD_FORMAT, "binwitness: length %zu is not a multiple of 32", len);
+    uint8_t tmp[32];
+    read_w32(bw, tmp);
+    uint64_t count = 0;
+    for (int i = 0; i < 8; i++) count |= (uint64_t)tmp[i] << (8 * i);
+    if (count != var_of_signal.size() || len != 32 * (count + 1))
+        return fail(ctx, ZG_E_BAD_FORMAT, "binwitness: %llu signals, the key describes %zu", (unsigned long long)count,
+                    var_of_signal.size());
+    memset(witness_out, 0, (size_t)n_vars * 32);
+    for (uint64_t id = 0; id < count; id++) {
+        uint32_t v = var_of_signal[id];
+        if (v == UINT32_MAX) continue;
+        read_w32(bw + 32 * (id + 1), witness_out + 32 * (size_t)v);
+    }
+    return ZG_OK;
+}
+
+}  // namespace zg

@@ -13,6 +13,7 @@ struct zg_r1cs {
     zg::DevBuf a_index, b_index;
     uint64_t n_a = 0, n_b = 0;
     uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
+    std::vector<uint32_t> var_of_signal;   // only for circuits loaded from a za proving key
 };
 
 struct zg_params {

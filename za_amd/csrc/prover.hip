@@ -435,6 +435,45 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
     *out = r.release();
     return ZG_OK;
 }
+// za proving key -> (R1CS, Parameters) in one call
+extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checked, int rank, int world, zg_r1cs** r1cs_out,
+                          zg_params** params_out) {
+    if (!ctx || !pk || !r1cs_out || !params_out) return ZG_E_INVALID_ARG;
+    *r1cs_out = nullptr;
+    *params_out = nullptr;
+    size_t off = 0;
+    if (pk_params_offset(pk, len, &off) != ZG_OK) return fail(ctx, ZG_E_IO, "pk: truncated container header");
+    // the key itself tells how many public inputs (|ic| - 1) and aux variables (|l|) the circuit has
+    ParsedParams pp;
+    size_t used = 0;
+    ZG_TRY(parse_bellman_params(ctx, pk + off, len - off, checked != 0, &pp, &used));
+    if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
+    PkR1cs pr;
+    ZG_TRY(parse_pk_r1cs(ctx, pk, len, (uint32_t)pp.ic.size() - 1, (uint32_t)pp.l.size(), &pr));
+    const uint64_t* rp[3] = {pr.row_ptr[0].data(), pr.row_ptr[1].data(), pr.row_ptr[2].data()};
+    const uint32_t* cl[3] = {pr.col[0].data(), pr.col[1].data(), pr.col[2].data()};
+    const uint8_t* cf[3] = {pr.coeff[0].data(), pr.coeff[1].data(), pr.coeff[2].data()};
+    zg_r1cs* r = nullptr;
+    ZG_TRY(zg_r1cs_load(ctx, pr.n_inputs, pr.n_aux, pr.n_constraints, rp, cl, cf, &r));
+    r->var_of_signal = pr.var_of_signal;
+    zg_params* p = nullptr;
+    int rc = zg_params_load(ctx, pk + off, len - off, 0 /* already validated above */, rank, world, &p, nullptr);
+    if (rc) {
+        delete r;
+        return rc;
+    }
+    *r1cs_out = r;
+    *params_out = p;
+    return ZG_OK;
+}
+extern "C" int zg_witness_from_binwitness(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* binwitness, size_t len,
+                                          uint8_t* witness32_out, size_t cap) {
+    if (!ctx || !r || !binwitness || !witness32_out) return ZG_E_INVALID_ARG;
+    if (r->var_of_signal.empty()) return fail(ctx, ZG_E_INVALID_ARG, "this R1CS was not loaded from a za proving key");
+    const size_t nv = (size_t)r->n_inputs + r->n_aux;
+    if (cap < nv * 32) return ZG_E_BUFFER_TOO_SMALL;
+    return witness_from_binwitness(ctx, r->var_of_signal, (uint32_t)nv, binwitness, len, witness32_out);
+}
 extern "C" void zg_r1cs_free(zg_r1cs* r) { delete r; }
 extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) {
     if (!r || !info) return ZG_E_INVALID_ARG;
