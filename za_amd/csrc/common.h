@@ -117,9 +117,10 @@ void msm_scratch_free(Ctx* ctx);
 
 // ---- ntt.hip
 int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
-// a,b,c: m Montgomery elements each in HBM (already zero padded); d_h_out: m canonical scalars
-// (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
+// a,b,c: m device-form elements each in HBM, zero padded, row i at index bitrev(i); d_h_out: m plain
+// integers in natural order (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
+int bitrev_dev(Ctx* ctx, Fr* d_data, uint32_t log_m);   // in-place bit-reversal permutation
 void ntt_tables_free(Ctx* ctx);
 
 // ---- M261 (device memory form, x*2^261) <-> host Montgomery form (x*2^256), host side.

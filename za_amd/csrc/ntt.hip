@@ -10,6 +10,7 @@
 // Algorithmic HBM bytes: 64 B per element per transform (one read + one write).
 // Field work uses the lazy 9x29-limb arithmetic (fd.h): HBM holds M261 residues (x*2^261) packed in
 // 8 x u32; the LDS tile holds 9 limbs per element (36-byte stride: conflict-free for ds_read_b32).
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -23,7 +24,7 @@ static constexpr int GEOM_LO = 10;        // low-table bits for the g^i two-leve
 struct NttTables {
     uint32_t log_m = 0;
     DevBuf tw_fwd, tw_inv;              // omega^i, omega^-i, i < m/2   (Montgomery)
-    DevBuf g_lo, g_hi;                  // g^j (j < 2^lo), g^(k 2^lo)                    (Montgomery)
+    DevBuf g_lo, g_hi, g_hi_minv;       // g^j (j < 2^lo), g^(k 2^lo), g^(k 2^lo)/m       (M261)
     DevBuf gi_lo, gi_hi, gi_hi_canon;   // g^-j, g^-(k 2^lo)/m (Montgomery) and the same hi table in canonical form
     Fr minv;                            // 1/m          (M261, for kernels)
     Fr zinv;                            // 1/(g^m - 1)  (M261, for kernels)
@@ -103,12 +104,13 @@ static int get_tables(Ctx* ctx, uint32_t log_m, NttTables** out) {
     T->lo_bits = (int)log_m < GEOM_LO ? (int)log_m : GEOM_LO;
     const size_t nlo = (size_t)1 << T->lo_bits, nhi = m >> T->lo_bits;
     A(T->tw_fwd, half); A(T->tw_inv, half);
-    A(T->g_lo, nlo); A(T->g_hi, nhi); A(T->gi_lo, nlo); A(T->gi_hi, nhi); A(T->gi_hi_canon, nhi);
+    A(T->g_lo, nlo); A(T->g_hi, nhi); A(T->g_hi_minv, nhi); A(T->gi_lo, nlo); A(T->gi_hi, nhi); A(T->gi_hi_canon, nhi);
     if (rc != ZG_OK) { delete T; return rc; }
     rc = launch_powers(ctx, T->tw_fwd.as<Fr>(), half, omega, Fr::one());
     if (!rc) rc = launch_powers(ctx, T->tw_inv.as<Fr>(), half, omega_inv, Fr::one());
     if (!rc) rc = launch_powers(ctx, T->g_lo.as<Fr>(), nlo, g, Fr::one());
     if (!rc) rc = launch_powers(ctx, T->g_hi.as<Fr>(), nhi, g.pow_u64(nlo), Fr::one());
+    if (!rc) rc = launch_powers(ctx, T->g_hi_minv.as<Fr>(), nhi, g.pow_u64(nlo), T->minv_host);
     if (!rc) rc = launch_powers(ctx, T->gi_lo.as<Fr>(), nlo, g_inv, Fr::one());
     if (!rc) rc = launch_powers(ctx, T->gi_hi.as<Fr>(), nhi, g_inv.pow_u64(nlo), T->minv_host);
     if (!rc) rc = launch_powers(ctx, T->gi_hi_canon.as<Fr>(), nhi, g_inv.pow_u64(nlo), T->minv_host);
@@ -131,15 +133,36 @@ void ntt_tables_free(Ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------------ transform pass
-// One in-place pass of decimation-in-frequency stages s_hi, s_hi-1, ..., s_hi-k+1 over data[0..2^log_m).
-// A workgroup owns 2^(k+j) elements.  If s_lo = s_hi-k+1 >= j ("strided" form) they are 2^k rows (the
-// k butterfly bits) of 2^j adjacent columns, so global accesses are 2^j*32 B contiguous runs; otherwise
+// One in-place pass of k butterfly stages s_lo .. s_lo+k-1 over data[0..2^log_m) on an LDS tile.
+// A workgroup owns 2^(k+j) elements.  If s_lo >= j ("strided" form) they are 2^k rows (the k butterfly
+// bits) of 2^j adjacent columns, so global accesses are 2^j*32 B contiguous runs; otherwise
 // (s_lo == 0, "contiguous" form) the tile is 2^(k+j) consecutive elements.
-__global__ void __launch_bounds__(256) k_ntt_dif_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int log_m,
-                                                      int s_hi, int k, int j, int contiguous) {
+//   DIT = false: decimation in frequency (Gentleman-Sande), stages high -> low, natural in / bit-reversed out:
+//                (u, v) -> (u + v, (u - v) w).  The sum path doubles its bound every stage: reduce() every 2nd.
+//   DIT = true : decimation in time (Cooley-Tukey), stages low -> high, bit-reversed in / natural out:
+//                (u, v) -> (u + v w, u - v w).  v always passes through a multiplication, so bounds grow by
+//                +2 p per stage only: no reduction inside the pass.
+// Fused element-wise work (uniform switches):
+//   pre  1: x *= hi[i >> lo_bits] * lo[i & mask]  (coset / 1/m distribution by natural index i)
+//        2: x = (a*b - c) * zinv                  (the pointwise step of H; a is `data`)
+//   post 1: x *= s                                (1/m)
+//        2: x *= hi[i >> lo_bits] * lo[i & mask]
+//        3: out[i] = integer(x * lo[..] * hi_int[..])   (final scaling fused with leaving Montgomery form)
+struct PassFuse {
+    int pre, post, lo_bits;
+    const Fr *hi, *lo;      // pre tables
+    const Fr *b, *c;        // pre 2
+    Fr s;                   // pre 2: zinv; post 1: constant
+    const Fr *phi, *plo;    // post tables
+    Fr* out;                // post 3
+};
+
+template <bool DIT>
+__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int log_m, int s_lo,
+                                                  int k, int j, int contiguous, PassFuse fz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem);   // 9 limbs per element
-    const int s_lo = s_hi - k + 1;
+    const int s_hi = s_lo + k - 1;
     const uint32_t tile_elems = 1u << (k + j);
     const size_t tile = blockIdx.x;
     size_t hbase, lblock;
@@ -165,25 +188,59 @@ __global__ void __launch_bounds__(256) k_ntt_dif_pass(Fr* __restrict__ data, con
 #pragma unroll
         for (int q = 0; q < 9; q++) lds[9 * li + q] = v.l[q];
     };
-    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) lds_put(li, FrD::load_red(&data[gidx(li)]));
+    const size_t lomask = ((size_t)1 << fz.lo_bits) - 1;
+    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+        const size_t g = gidx(li);
+        FrD x = FrD::load_red(&data[g]);
+        if (fz.pre == 1) {
+            x = x * (FrD::load_canon(&fz.hi[g >> fz.lo_bits]) * FrD::load_canon(&fz.lo[g & lomask]));
+        } else if (fz.pre == 2) {
+            FrD ab = x * FrD::load_red(&fz.b[g]);
+            x = FrD::sub<3>(ab, FrD::load_red(&fz.c[g])) * FrD::load_canon(&fz.s);
+        }
+        lds_put(li, x);
+    }
     __syncthreads();
     const int sh = contiguous ? 0 : j;  // position of the butterfly bits inside the local index
     const uint32_t half = tile_elems >> 1;
-    for (int q = k - 1; q >= 0; q--) {
+    for (int it = 0; it < k; it++) {
+        const int q = DIT ? it : k - 1 - it;
         const int s = s_lo + q;          // global stage: butterfly span 2^s
         const int bit = sh + q;
+        const bool red = (it & 1) != 0 || it == k - 1;   // DIF: reduce the sums every 2nd stage
         for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
             uint32_t i0 = ((b >> bit) << (bit + 1)) | (b & ((1u << bit) - 1u));
             uint32_t i1 = i0 | (1u << bit);
             size_t e0 = gidx(i0);
             size_t texp = (e0 & (((size_t)1 << s) - 1)) << (log_m - 1 - s);
-            FrD u = lds_get(i0), v = lds_get(i1);   // both < 2.01 p
-            lds_put(i0, (u + v).reduce());
-            lds_put(i1, FrD::sub<3>(u, v) * FrD::load_canon(&tw[texp]));
+            FrD u = lds_get(i0), v = lds_get(i1);
+            const FrD w = FrD::load_canon(&tw[texp]);
+            if (DIT) {
+                FrD t = v * w;                       // < 1.2 p whatever v's bound (<= 18 p)
+                lds_put(i0, u + t);                  // bounds grow by at most 2 p per stage: <= 2.01 + 2k
+                lds_put(i1, FrD::sub<2>(u, t));
+            } else {
+                FrD sm = u + v;                      // <= 4.02 (after a reducing stage) or 8.04
+                lds_put(i1, FrD::sub<5>(u, v) * w);  // v <= 4.02
+                lds_put(i0, red ? sm.reduce() : sm);
+            }
         }
         __syncthreads();
     }
-    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) lds_get(li).reduce().store(&data[gidx(li)]);
+    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+        const size_t g = gidx(li);
+        FrD x = lds_get(li);
+        if (fz.post == 0) {
+            x.reduce().store(&data[g]);
+        } else if (fz.post == 1) {
+            (x * FrD::load_canon(&fz.s)).reduce().store(&data[g]);
+        } else if (fz.post == 2) {
+            (x * (FrD::load_canon(&fz.phi[g >> fz.lo_bits]) * FrD::load_canon(&fz.plo[g & lomask]))).reduce().store(&data[g]);
+        } else {
+            FrD t = x * FrD::load_canon(&fz.plo[g & lomask]);
+            (t * FrD::load_canon(&fz.phi[g >> fz.lo_bits])).canonical().store(&fz.out[g]);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_bitrev(Fr* __restrict__ data, int log_m) {
@@ -230,19 +287,41 @@ __global__ void __launch_bounds__(256) k_mul_sub_scale(Fr* __restrict__ a, const
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
-// natural order in -> bit-reversed order out
-static int dif_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m) {
+static PassFuse no_fuse() {
+    PassFuse f;
+    memset(&f, 0, sizeof(f));
+    return f;
+}
+
+// All passes of one transform.  DIF: natural in -> bit-reversed out (stages high -> low); DIT: bit-reversed in ->
+// natural out (stages low -> high).  `first` / `last` carry the element-wise work fused into the first pass's
+// loads / the last pass's stores.
+template <bool DIT>
+static int run_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m, const PassFuse& first, const PassFuse& last) {
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
-        ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_dif_pass, hipFuncAttributeMaxDynamicSharedMemorySize,
+        ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        36 << NTT_LOG_TILE));
+        ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         36 << NTT_LOG_TILE));
         lds_attr_set = true;
     }
-    int remaining = (int)log_m, s_hi = (int)log_m - 1;
-    while (remaining > 0) {
-        int np = (remaining + NTT_KMAX - 1) / NTT_KMAX;
-        int k = (remaining + np - 1) / np;
-        int s_lo = s_hi - k + 1;
+    // split the log_m stages into passes of (nearly) equal size <= NTT_KMAX
+    int np = ((int)log_m + NTT_KMAX - 1) / NTT_KMAX;
+    if (np < 1) np = 1;
+    std::vector<int> ks;
+    int remaining = (int)log_m;
+    for (int p = np; p > 0; p--) {
+        int k = (remaining + p - 1) / p;
+        ks.push_back(k);
+        remaining -= k;
+    }
+    // DIF walks the stages from the top, DIT from the bottom
+    int s_next = DIT ? 0 : (int)log_m;
+    for (size_t pi = 0; pi < ks.size(); pi++) {
+        const int k = ks[pi];
+        const int s_lo = DIT ? s_next : s_next - k;
+        s_next = DIT ? s_next + k : s_next - k;
         int j, contiguous;
         if (s_lo == 0) {
             contiguous = 1;
@@ -254,16 +333,30 @@ static int dif_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m) {
             if (j > s_lo) j = s_lo;
         }
         if (j < 0) j = 0;
+        PassFuse fz = no_fuse();
+        if (pi == 0) {
+            fz.pre = first.pre; fz.hi = first.hi; fz.lo = first.lo; fz.b = first.b; fz.c = first.c; fz.lo_bits = first.lo_bits;
+            if (first.pre == 2) fz.s = first.s;
+        }
+        if (pi + 1 == ks.size()) {
+            fz.post = last.post; fz.phi = last.phi; fz.plo = last.plo; fz.out = last.out;
+            if (last.post) fz.lo_bits = last.lo_bits;
+            if (last.post == 1) fz.s = last.s;
+        }
+        if (fz.pre == 2 && fz.post == 1) return fail(ctx, ZG_E_INVALID_ARG, "internal: PassFuse.s used twice");
         size_t tiles = ((size_t)1 << log_m) >> (k + j);
         size_t lds_bytes = (size_t)36 << (k + j);   // 9 u32 limbs per element
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);  // units: butterflies
-        hipLaunchKernelGGL(k_ntt_dif_pass, dim3((unsigned)tiles), dim3(256), lds_bytes, ctx->stream, d, tw, (int)log_m,
-                           s_hi, k, j, contiguous);
+        hipLaunchKernelGGL((k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(256), lds_bytes, ctx->stream, d, tw, (int)log_m,
+                           s_lo, k, j, contiguous, fz);
         ZG_HIP(ctx, hipGetLastError());
-        s_hi -= k;
-        remaining -= k;
     }
     return ZG_OK;
+}
+
+// natural order in -> bit-reversed order out
+static int dif_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m) {
+    return run_passes<false>(ctx, d, tw, log_m, no_fuse(), no_fuse());
 }
 
 static int ntt_core(Ctx* ctx, NttTables* T, Fr* d, bool inverse, bool coset) {
@@ -289,6 +382,13 @@ static int ntt_core(Ctx* ctx, NttTables* T, Fr* d, bool inverse, bool coset) {
     return ZG_OK;
 }
 
+int bitrev_dev(Ctx* ctx, Fr* d_data, uint32_t log_m) {
+    if (log_m == 0) return ZG_OK;
+    hipLaunchKernelGGL(k_bitrev, dim3(blocks_for((size_t)1 << log_m)), dim3(256), 0, ctx->stream, d_data, (int)log_m);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
 int convert_mont_dev(Ctx* ctx, void* d_elems, size_t n, int which, int dir, hipStream_t st) {
     if (n == 0) return ZG_OK;
     if (!st) st = ctx->stream;
@@ -310,26 +410,30 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset) {
     return convert_mont_dev(ctx, d_data, m, 1, 1);
 }
 
-// a, b, c in the device form (M261, reduce()d); d_h_out receives plain integers
+// H = (A*B - C)/Z.  a, b, c: device form (M261, reduce()d) with row i stored at index bitrev(i)
+// (k_r1cs_eval scatters them that way), zero padded.  d_h_out receives the m coefficients as plain integers in
+// natural order.  Bellman's sequence ifft, coset_fft (x3), mul/sub/divide-by-Z, icoset_fft becomes
+//   DIT(omega^-1)            bit-reversed evaluations -> natural coefficients       [x3]
+//   DIF(omega), pre-scaled   coefficients * g^i / m   -> bit-reversed coset evaluations   [x3]
+//   DIT(omega^-1), pre = (a*b - c)/Z(g), post = * g^-i / m -> integer coefficients of H, natural order
+// i.e. 21 LDS passes and no separate permutation or scaling pass.
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out) {
     NttTables* T;
     ZG_TRY(get_tables(ctx, log_m, &T));
-    const size_t m = (size_t)1 << log_m;
-    hipStream_t st = ctx->stream;
     Fr* v[3] = {d_a, d_b, d_c};
+    PassFuse pre_g = no_fuse();   // coefficients * g^i * (1/m): the 1/m of the preceding inverse transform rides along
+    pre_g.pre = 1; pre_g.hi = T->g_hi_minv.as<Fr>(); pre_g.lo = T->g_lo.as<Fr>(); pre_g.lo_bits = T->lo_bits;
     for (int k = 0; k < 3; k++) {
-        ZG_TRY(ntt_core(ctx, T, v[k], /*inverse=*/true, /*coset=*/false));
-        ZG_TRY(ntt_core(ctx, T, v[k], /*inverse=*/false, /*coset=*/true));
+        ZG_TRY(run_passes<true>(ctx, v[k], T->tw_inv.as<Fr>(), log_m, no_fuse(), no_fuse()));
+        ZG_TRY(run_passes<false>(ctx, v[k], T->tw_fwd.as<Fr>(), log_m, pre_g, no_fuse()));
     }
-    hipLaunchKernelGGL(k_mul_sub_scale, dim3(blocks_for(m)), dim3(256), 0, st, d_a, d_b, d_c, m, T->zinv);
-    // icoset_fft with the final g^-i/m scaling fused with the Montgomery -> canonical conversion
-    if (log_m > 0) {
-        ZG_TRY(dif_passes(ctx, d_a, T->tw_inv.as<Fr>(), log_m));
-        hipLaunchKernelGGL(k_bitrev, dim3(blocks_for(m)), dim3(256), 0, st, d_a, (int)log_m);
-    }
-    hipLaunchKernelGGL(k_scale_geom_to_repr, dim3(blocks_for(m)), dim3(256), 0, st, d_a, d_h_out, m,
-                       T->gi_hi_canon.as<Fr>(), T->gi_lo.as<Fr>(), T->lo_bits);
-    ZG_HIP(ctx, hipGetLastError());
+    PassFuse pre_m = no_fuse();
+    pre_m.pre = 2; pre_m.b = d_b; pre_m.c = d_c; pre_m.s = T->zinv;
+    PassFuse post = no_fuse();
+    post.post = 3; post.phi = T->gi_hi_canon.as<Fr>(); post.plo = T->gi_lo.as<Fr>(); post.lo_bits = T->lo_bits;
+    post.out = d_h_out;
+    if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
+    ZG_TRY(run_passes<true>(ctx, d_a, T->tw_inv.as<Fr>(), log_m, pre_m, post));
     return ZG_OK;
 }
 

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_
 // out[row] = sum_e coeff[e] * w[col[e]]  for one CSR matrix; one thread per row
 __global__ void __launch_bounds__(256) k_r1cs_eval(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                    const Fr* __restrict__ coeff, const Fr* __restrict__ w,
-                                                   uint64_t n_rows, Fr* __restrict__ out) {
+                                                   uint64_t n_rows, Fr* __restrict__ out, int rev_bits) {
     uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     FrD acc = FrD::zero();
@@ -60,12 +60,18 @@ __global__ void __launch_bounds__(256) k_r1cs_eval(const uint64_t* __restrict__ 
             since = 0;
         }
     }
-    acc.reduce().store(&out[row]);
+    // rev_bits > 0: row i goes to index bitrev(i) -- the order the decimation-in-time inverse NTT consumes
+    const uint64_t dst = rev_bits ? (uint64_t)(__brev((uint32_t)row) >> (32 - rev_bits)) : row;
+    acc.reduce().store(&out[dst]);
 }
 // the `input_i * 0 = 0` rows: a[n + i] = w_i; b, c stay zero
-__global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, Fr* __restrict__ a_tail) {
+__global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, uint64_t first_row, Fr* __restrict__ a,
+                             int rev_bits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_inputs) FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a_tail[i]);
+    if (i >= n_inputs) return;
+    const uint64_t row = first_row + i;
+    const uint64_t dst = rev_bits ? (uint64_t)(__brev((uint32_t)row) >> (32 - rev_bits)) : row;
+    FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a[dst]);
 }
 
 }  // namespace zg
@@ -357,7 +363,10 @@ extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, con
         ZG_HIP(ctx, hipMemcpyAsync(d[k].p, src[k], n_rows * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     ZG_HIP(ctx, dh.alloc(m * 32));
-    for (int k = 0; k < 3; k++) ZG_TRY(convert_mont_dev(ctx, d[k].p, n_rows, 1, 0));  // ABI form -> device form
+    for (int k = 0; k < 3; k++) {
+        ZG_TRY(convert_mont_dev(ctx, d[k].p, n_rows, 1, 0));   // ABI form -> device form
+        ZG_TRY(bitrev_dev(ctx, d[k].as<Fr>(), log_m));         // h_poly_dev consumes bit-reversed rows
+    }
     ZG_TRY(h_poly_dev(ctx, d[0].as<Fr>(), d[1].as<Fr>(), d[2].as<Fr>(), log_m, dh.as<Fr>()));
     if (m > 1) ZG_HIP(ctx, hipMemcpyAsync(h_out, dh.p, (m - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -482,23 +491,27 @@ extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) {
     return ZG_OK;
 }
 
-// d_abc[k]: m Montgomery elements (zero padded), rows = n_constraints + n_inputs
-static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3]) {
+// d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
+// stored at index bitrev(i) (what h_poly_dev consumes)
+static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev) {
     const size_t m = (size_t)1 << r->log_m;
     hipStream_t st = ctx->stream;
+    const int rev_bits = bitrev ? (int)r->log_m : 0;
     uint64_t nnz_total = 0;
     for (int k = 0; k < 3; k++) nnz_total += r->col[k].bytes / 4;
     ProfScope ps(ctx, PROF_R1CS_EVAL, 36 * nnz_total + 96 * (r->n_constraints + r->n_inputs));
     for (int k = 0; k < 3; k++) {
-        // only the padding and the input rows need clearing, but a full memset is one cheap launch
-        ZG_HIP(ctx, hipMemsetAsync(d_abc[k] + r->n_constraints, 0, (m - r->n_constraints) * sizeof(Fr), st));
+        if (bitrev || r->n_constraints == 0)
+            ZG_HIP(ctx, hipMemsetAsync(d_abc[k], 0, m * sizeof(Fr), st));   // padding is scattered
+        else
+            ZG_HIP(ctx, hipMemsetAsync(d_abc[k] + r->n_constraints, 0, (m - r->n_constraints) * sizeof(Fr), st));
         if (r->n_constraints)
             hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, st,
                                r->row_ptr[k].as<uint64_t>(), r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), d_w,
-                               r->n_constraints, d_abc[k]);
+                               r->n_constraints, d_abc[k], rev_bits);
     }
     hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
-                       d_abc[0] + r->n_constraints);
+                       r->n_constraints, d_abc[0], rev_bits);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -517,7 +530,7 @@ extern "C" int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witnes
         ZG_HIP(ctx, d[k].alloc(m * 32));
         abc[k] = d[k].as<Fr>();
     }
-    ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc));
+    ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc, /*bitrev=*/false));
     for (int k = 0; k < 3; k++) ZG_TRY(convert_mont_dev(ctx, d[k].p, rows, 1, 1));  // device form -> ABI form
     uint8_t* outs[3] = {a_out, b_out, c_out};
     for (int k = 0; k < 3; k++)
@@ -636,7 +649,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
         ZG_HIP(ctx, ws.abc[k].reserve(m * sizeof(Fr)));
         abc[k] = ws.abc[k].as<Fr>();
     }
-    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc));
+    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
