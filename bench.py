@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
-    ap.add_argument("--cpu-log-m", type=int, default=17, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-log-m", type=int, default=22, help="size of the bounded CPU-baseline sample (2^22 = the GPU workload itself, ~10 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-only", action="store_true", help="also time a standalone 2^log_m G1 MSM (uniform scalars)")
     return ap.parse_args()
