@@ -158,6 +158,18 @@ int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checked, int rank
 int zg_witness_from_binwitness(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* binwitness, size_t len,
                                uint8_t* witness32_out, size_t cap);
 
+/* ---- set-up -------------------------------------------------------------------
+ * zg_setup replaces bellman_ce::groth16::generate_parameters(circuit, g1, g2, alpha, beta, gamma, delta, tau), the
+ * deterministic core of generate_random_parameters (prover/src/groth16/prover.rs:122), with the standard generators.
+ * toxic = alpha, beta, gamma, delta, tau as five canonical-LE scalars.  The key stays resident in *out; if
+ * params_out != NULL the bellman Parameters::write bytes (format.rs:250) are stored there (ZG_E_BUFFER_TOO_SMALL if
+ * cap is insufficient; *written always receives the needed size).  Errors: ZG_E_UNCONSTRAINED_VARIABLE (an aux
+ * variable's l query is the identity), ZG_E_DIVISION_BY_ZERO (gamma or delta = 0), ZG_E_BAD_FORMAT (a query polynomial
+ * vanishes at tau although the variable is mentioned: the key would not match the prover's density maps). */
+int zg_setup(zg_ctx* ctx, const zg_r1cs* r1cs, const uint8_t toxic[160], zg_params** out, uint8_t* params_out,
+             size_t cap, size_t* written);
+int zg_setup_random(zg_ctx* ctx, const zg_r1cs* r1cs, zg_params** out, uint8_t* params_out, size_t cap, size_t* written);
+
 /* ---- prove -----------------------------------------------------------------------------------
  * Replaces bellman_ce::groth16::create_proof(circuit, params, r, s) -- the deterministic core of
  * create_random_proof (prover/src/groth16/prover.rs:173).  witness32 = (n_inputs + n_aux)

@@ -262,3 +262,50 @@ def test_pk_load_rejects_inconsistent_containers(ctx):
     with pytest.raises(za_amd.ZaAmdError) as e:
         ctx.witness_from_binwitness(R, bw[:-32])
     assert e.value.code == za_amd.ZG_E_BAD_FORMAT if hasattr(za_amd, "ZG_E_BAD_FORMAT") else True
+
+
+@pytest.mark.parametrize("name", ["proof_factor.json", "proof_chain7.json"])
+def test_gpu_setup_reproduces_the_golden_key(ctx, name):
+    """generate_parameters with the fixture's toxic waste gives the same
+    Parameters::write bytes as the oracle, and proving with the resident key gives the golden proof."""
+    fx = golden(name)
+    r1 = r1cs_from_fixture(fx)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    td = [int(x, 16) for x in fx["trapdoor"]]
+    P, pbytes = ctx.setup(R, *td)
+    assert pbytes.hex() == fx["params"]
+    w = co.witness_bytes([int(x, 16) for x in fx["witness"]])
+    assert ctx.prove(P, R, w, int(fx["r"], 16), int(fx["s"], 16)).hex() == fx["proof"]
+
+
+def test_gpu_setup_then_prove_verifies_under_the_pairing(ctx):
+    """setup -> prove -> verify round trip (the reference's prover test, prover.rs:225-306) at 2^11 rows,
+    everything heavy on the GPU, verification by the oracle's pairing."""
+    from oracle.circuits import chain_r1cs
+    r1, w = chain_r1cs(11, n_inputs=3, seed=5, bit_fraction=0.7)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, pbytes = ctx.setup(R, 0x1111, 0x2222, 0x3333, 0x4444, 0x5555)
+    params, used = g.params_read(pbytes)
+    assert used == len(pbytes)
+    pb = ctx.prove(P, R, co.witness_bytes(w), 0xABCDEF, 0x123456)
+    v = [int.from_bytes(pb[32 * i:32 * i + 32], "big") for i in range(8)]
+    proof = ((bn.Fq(v[0]), bn.Fq(v[1])), (bn.Fq2(v[2], v[3]), bn.Fq2(v[4], v[5])), (bn.Fq(v[6]), bn.Fq(v[7])))
+    pub = w[1:r1.num_inputs]
+    assert g.verify_proof(params.vk, proof, pub)
+    assert not g.verify_proof(params.vk, proof, [pub[0], (pub[1] + 1) % bn.R])
+    # the oracle, proving with the GPU-made key, produces the same bytes
+    mp = co.MontParams.from_params(params)
+    assert co.prove(mp, csr, co.witness_bytes(w), 0xABCDEF, 0x123456, threads=8) == pb
+
+
+def test_setup_rejects_unconstrained_variable(ctx):
+    import za_amd
+    # variable aux[1] appears in no constraint: bellman's generator returns UnconstrainedVariable
+    r1 = g.R1CS(2, 3, [([(2, 1)], [(2, 1)], [(4, 1)])])
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.setup(R, 3, 5, 7, 11, 13)
+    assert e.value.code == za_amd.ZG_E_UNCONSTRAINED_VARIABLE

@@ -20,6 +20,7 @@ ZG_E_ASSIGNMENT_MISSING = 1
 ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE = 4
 ZG_E_UNEXPECTED_IDENTITY = 5
 ZG_E_IO = 6
+ZG_E_UNCONSTRAINED_VARIABLE = 8
 ZG_E_BAD_FORMAT = 20
 ZG_E_QUERY_SIZE = 21
 ZG_E_INVALID_ARG = 22
@@ -36,7 +37,7 @@ ABI_SYMBOLS = [
     "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
-    "zg_pk_load", "zg_witness_from_binwitness",
+    "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_proof_json", "zg_last_timings",
@@ -230,6 +231,20 @@ class Context:
         self._check(self.lib.zg_params_load(self.h, _ptr(b), C.c_size_t(b.size), C.c_int(int(checked)), C.c_int(rank),
                                             C.c_int(world), C.byref(hd), C.byref(used)))
         return Params(self, hd), used.value
+
+    def setup(self, r1cs, alpha, beta, gamma, delta, tau, want_bytes=True):
+        """generate_parameters with explicit toxic waste -> (Params, bellman Parameters bytes or None)."""
+        tox = _u8(b"".join(int(x).to_bytes(32, "little") for x in (alpha, beta, gamma, delta, tau)))
+        ph = C.c_void_p()
+        need = C.c_size_t()
+        if not want_bytes:
+            self._check(self.lib.zg_setup(self.h, r1cs.h, _ptr(tox), C.byref(ph), None, C.c_size_t(0), None))
+            return Params(self, ph), None
+        m = 1 << r1cs.log_m
+        cap = 1024 + 64 * (r1cs.n_inputs + m + 3 * (r1cs.n_inputs + r1cs.n_aux)) + 128 * (r1cs.n_inputs + r1cs.n_aux)
+        buf = np.zeros(cap, dtype=np.uint8)
+        self._check(self.lib.zg_setup(self.h, r1cs.h, _ptr(tox), C.byref(ph), _ptr(buf), C.c_size_t(cap), C.byref(need)))
+        return Params(self, ph), buf[:need.value].tobytes()
 
     def pk_load(self, pk_bytes, checked=True, rank=0, world=1):
         """A whole za `proving.key` -> (R1CS, Params)."""

@@ -120,6 +120,11 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 // a,b,c: m device-form elements each in HBM, zero padded, row i at index bitrev(i); d_h_out: m plain
 // integers in natural order (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
+int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out);
+int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host);
+// out[row] = sum_e coeff[e] * x[idx[e]] over CSR/CSC rows; coeff pre-multiplied by 2^522, x plain integers -> M261
+int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d_coeff, const Fr* d_x, uint64_t n_rows,
+             Fr* d_out);
 int bitrev_dev(Ctx* ctx, Fr* d_data, uint32_t log_m);   // in-place bit-reversal permutation
 void ntt_tables_free(Ctx* ctx);
 

@@ -382,6 +382,27 @@ static int ntt_core(Ctx* ctx, NttTables* T, Fr* d, bool inverse, bool coset) {
     return ZG_OK;
 }
 
+// out[j] = L_j(tau) (Lagrange basis of the 2^log_m domain at tau) as plain integers, natural order:
+// the inverse transform of the powers of tau, exactly how bellman's generator obtains them.
+int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out) {
+    NttTables* T;
+    ZG_TRY(get_tables(ctx, log_m, &T));
+    const size_t m = (size_t)1 << log_m;
+    ZG_TRY(launch_powers(ctx, d_out, m, tau_host, Fr::one()));
+    ZG_TRY(ntt_core(ctx, T, d_out, /*inverse=*/true, /*coset=*/false));
+    hipLaunchKernelGGL(k_from_mont, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, d_out, m);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+// out[i] = integer(scale * base^i), i < n
+int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host) {
+    if (n == 0) return ZG_OK;
+    ZG_TRY(launch_powers(ctx, d_out, n, base_host, scale_host));
+    hipLaunchKernelGGL(k_from_mont, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_out, n);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
 int bitrev_dev(Ctx* ctx, Fr* d_data, uint32_t log_m) {
     if (log_m == 0) return ZG_OK;
     hipLaunchKernelGGL(k_bitrev, dim3(blocks_for((size_t)1 << log_m)), dim3(256), 0, ctx->stream, d_data, (int)log_m);

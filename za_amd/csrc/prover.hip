@@ -74,6 +74,15 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, uint64
     FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a[dst]);
 }
 
+int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d_coeff, const Fr* d_x, uint64_t n_rows,
+             Fr* d_out) {
+    if (n_rows == 0) return ZG_OK;
+    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, d_ptr, d_idx,
+                       d_coeff, d_x, n_rows, d_out, 0);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
 }  // namespace zg
 
 using namespace zg;
