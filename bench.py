@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
     ap.add_argument("--cpu-log-m", type=int, default=22, help="size of the bounded CPU-baseline sample (2^22 = the GPU workload itself, ~10 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--synthetic-key", action="store_true", help="skip the set-up; use bases with known discrete logs")
     ap.add_argument("--msm-only", action="store_true", help="also time a standalone 2^log_m G1 MSM (uniform scalars)")
     return ap.parse_args()
 
@@ -52,8 +53,11 @@ def cpu_baseline(ctx, args):
     m = 1 << lg
     n_a = 2 + r1.a_aux_total
     n_b = r1.b_input_total + r1.b_aux_total
-    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 1000)
-    # download the synthetic key for the CPU run
+    if args.synthetic_key:
+        P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 1000)
+    else:
+        P = ctx.setup(r1, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+    # bring the key to the host for the CPU run
     import ctypes as C
     vk5 = np.zeros(448, dtype=np.uint8)
     ctx._check(ctx.lib.zg_params_download(P.h, C.c_int(-1), vk5.ctypes.data_as(C.c_void_p), C.c_size_t(448)))
@@ -115,7 +119,16 @@ def main():
     m = 1 << args.log_m
     n_a = sr.n_inputs + r1.a_aux_total
     n_b = r1.b_input_total + r1.b_aux_total
-    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 7000, rank=rank, world=world)
+    if args.synthetic_key:
+        # bases = k_i * G with known discrete logs (tests use this form); same sizes, same prover work
+        P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 7000, rank=rank, world=world)
+    else:
+        # a valid proving key from the GPU trapdoor set-up (fixed toxic waste so runs are reproducible)
+        P = ctx.setup(r1, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+        if world > 1:
+            full = P
+            P = synth.params_shard(ctx, full, rank, world)
+            full.close()
     d_w = ctx.upload(sr.witness)
     n_constraints = sr.n_constraints
     nnz = list(sr.nnz)
@@ -201,8 +214,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 Montgomery (256-bit modular integer)", "data": "synthetic",
             "config": {"workload": "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
-                                   "seed 0x%x), n_constraints + n_inputs = 2^%d, synthetic proving key with known "
-                                   "discrete logs" % (100 * args.bit_fraction, args.seed, args.log_m),
+                                   "seed 0x%x), n_constraints + n_inputs = 2^%d, %s"
+                                   % (100 * args.bit_fraction, args.seed, args.log_m,
+                                      "synthetic proving key with known discrete logs" if args.synthetic_key
+                                      else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,

@@ -37,6 +37,8 @@ int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);
  * exercises exactly the prover's arithmetic, with every discrete log known to the tests. */
 int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t seed,
                         int rank, int world, zg_params** out);
+/* Chunk `rank` of `world` of every query of an unsharded resident key, as a new handle (multi-GPU bench). */
+int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int world, zg_params** out);
 /* k_i for the generators above */
 uint64_t zg_synth_dlog(uint64_t seed, uint64_t i);
 /* d_out[i] = uniform scalar below 2^253 from splitmix64 (canonical LE), for standalone MSM runs */

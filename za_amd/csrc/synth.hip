@@ -90,6 +90,19 @@ extern "C" int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_f
     }
     for (uint64_t i = 0; i < n; i++) {
         const uint32_t c = n_inputs + n_seed + (uint32_t)i;
+        if (i < n_seed / 4) {
+            // the first rows tie the seed variables in (a valid set-up rejects unconstrained aux variables)
+            const uint32_t s0 = n_inputs + 4 * (uint32_t)i;
+            Fr k1 = rng.fr(), k2 = rng.fr(), k3 = rng.fr(), k4 = rng.fr();
+            push_term(s.get(), 0, s0, k1);
+            push_term(s.get(), 0, s0 + 1, k2);
+            push_term(s.get(), 1, s0 + 2, k3);
+            push_term(s.get(), 1, s0 + 3, k4);
+            push_term(s.get(), 2, c, one);
+            w[c] = (k1 * w[s0] + k2 * w[s0 + 1]) * (k3 * w[s0 + 2] + k4 * w[s0 + 3]);
+            for (int k = 0; k < 3; k++) s->row_ptr[k].push_back(s->col[k].size());
+            continue;
+        }
         const bool bit_row = bit_fraction > 0.0 && rng.next() <= thresh;
         if (bit_row) {
             uint32_t a = bits[rng.next() % bits.size()];
@@ -226,6 +239,33 @@ extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t
     hipLaunchKernelGGL(k_synth_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_out, n,
                        seed);
     ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+// A sharded view of a resident key: chunk `rank` of `world` of every query, copied into a new handle.
+extern "C" int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int world, zg_params** out) {
+    if (!ctx || !full || !out || world < 1 || rank < 0 || rank >= world || full->world != 1) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<zg_params> p(new zg_params());
+    p->alpha_g1 = full->alpha_g1; p->beta_g1 = full->beta_g1; p->delta_g1 = full->delta_g1;
+    p->beta_g2 = full->beta_g2; p->delta_g2 = full->delta_g2;
+    p->rank = rank;
+    p->world = world;
+    for (int k = 0; k < 5; k++) {
+        auto& q = p->q[k];
+        q.total = full->q[k].total;
+        uint64_t chunk = (q.total + world - 1) / world;
+        q.lo = std::min<uint64_t>(q.total, (uint64_t)rank * chunk);
+        q.hi = std::min<uint64_t>(q.total, q.lo + chunk);
+        const size_t elem = k == 4 ? 128 : 64;
+        ZG_HIP(ctx, q.buf.alloc((q.hi - q.lo) * elem));
+        if (q.hi > q.lo)
+            ZG_HIP(ctx, hipMemcpyAsync(q.buf.p, (const uint8_t*)full->q[k].buf.p + q.lo * elem, (q.hi - q.lo) * elem,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = p.release();
     return ZG_OK;
 }
 

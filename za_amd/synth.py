@@ -11,7 +11,7 @@ from . import Context, Params, ZaAmdError, load_library
 
 SYNTH_SYMBOLS = ["zg_synth_r1cs_new", "zg_synth_r1cs_info", "zg_synth_ptr", "zg_synth_free",
                  "zg_synth_bases_g1_dev", "zg_synth_bases_g2_dev", "zg_synth_params_dev", "zg_synth_dlog",
-                 "zg_synth_scalars_dev", "zg_params_download",
+                 "zg_synth_scalars_dev", "zg_params_download", "zg_params_shard",
                  "zg_selftest_field_host", "zg_selftest_field_dev", "zg_selftest_curve_host", "zg_params_inspect"]
 
 MASK64 = (1 << 64) - 1
@@ -92,6 +92,12 @@ def synth_scalars(ctx: Context, n, seed):
     ctx._check(ctx.lib.zg_synth_scalars_dev(ctx.h, C.c_void_p(d), C.c_size_t(n), C.c_uint64(seed)))
     ctx.sync()
     return d
+
+
+def params_shard(ctx: Context, full: Params, rank, world):
+    h = C.c_void_p()
+    ctx._check(ctx.lib.zg_params_shard(ctx.h, full.h, C.c_int(rank), C.c_int(world), C.byref(h)))
+    return Params(ctx, h)
 
 
 def synth_params(ctx: Context, n_h, n_l, n_a, n_b, seed, rank=0, world=1):
