@@ -204,6 +204,19 @@ int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t*
 /* Full (unsharded) length of query `which`. */
 int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
 
+/* ---- verify (host CPU) ---------------------------------------------------------
+ * zg_verify replaces bellman_ce::groth16::{prepare_verifying_key, verify_proof} (prover/src/groth16/prover.rs:191-200,
+ * helper.rs:149-159; za2c `verify`, binding/c/native/src/lib.rs:101-117).  vk_bytes: bellman VerifyingKey::write
+ * bytes -- which is also the prefix of Parameters::write, so a whole key may be passed.  public_inputs32: n_public
+ * canonical-LE scalars (ONE excluded).  *ok = 1 if e(A,B) = e(alpha,beta) e(sum ic_i x_i, gamma) e(C,delta), else 0.
+ * ZG_E_MALFORMED_VERIFYING_KEY if n_public + 1 != |ic| (as bellman); ZG_E_BAD_FORMAT for off-curve proof points.
+ * Needs no GPU and no ctx. */
+int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t proof[256], const uint8_t* public_inputs32,
+              size_t n_public, int* ok);
+/* vk JSON exactly as JsonVerifyingKey::to_json emits it (prover/src/groth16/format.rs:130-167): fields alpha_g1,
+ * beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2, ic, input_names; names = n_names NUL-terminated strings back to back. */
+int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out, size_t cap);
+
 /* ---- formats ---------------------------------------------------------------------------------
  * proof.json exactly as JsonProofAndInput::write emits it (prover/src/groth16/format.rs:80-128):
  * {"a":[x,y],"b":[[x.c0,x.c1],[y.c0,y.c1]],"c":[x,y],"public_inputs":[...]} with 0x-prefixed

@@ -181,3 +181,40 @@ def test_density_bitmap():
     import za_amd
     bm = za_amd.density_bitmap([1, 0, 1] + [0] * 62 + [1])
     assert bm.dtype == np.dtype("<u8") and list(bm) == [5, 2]
+
+
+def test_host_verifier_accepts_golden_proofs_and_rejects_wrong_inputs(lib_built):
+    """zg_verify (CPU pairing) on the golden proofs: the reference's acceptance test, prover.rs:291-305."""
+    import json
+    import time
+    import za_amd
+    for name in ("proof_factor.json", "proof_chain7.json"):
+        fx = golden(name)
+        params = bytes.fromhex(fx["params"])
+        proof = bytes.fromhex(fx["proof"])
+        w = [int(x, 16) for x in fx["witness"]]
+        pub = w[1:fx["n_inputs"]]
+        t0 = time.time()
+        assert za_amd.verify(params, proof, pub) is True
+        dt = time.time() - t0
+        assert dt < 5.0
+        bad = list(pub)
+        bad[-1] = (bad[-1] + 1) % bn.R
+        assert za_amd.verify(params, proof, bad) is False
+        # a tampered proof point is either off the curve (BadFormat) or fails the pairing check
+        tam = bytearray(proof); tam[255] ^= 1
+        try:
+            assert za_amd.verify(params, bytes(tam), pub) is False
+        except za_amd.ZaAmdError as e:
+            assert e.code == za_amd.ZG_E_BAD_FORMAT
+        with pytest.raises(za_amd.ZaAmdError) as e:
+            za_amd.verify(params, proof, pub + [1])
+        assert e.value.code == za_amd.ZG_E_MALFORMED_VERIFYING_KEY
+        # vk JSON: same numbers as the proof.json convention, serde field order of JsonVerifyingKey
+        vj = json.loads(za_amd.vk_json(params, ["main.x%d" % i for i in range(len(pub))]))
+        assert list(vj.keys()) == ["alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "gamma_g2", "ic", "input_names"]
+        assert len(vj["ic"]) == fx["n_inputs"] and len(vj["input_names"]) == len(pub)
+        from oracle import groth16 as g
+        pr, _ = g.params_read(params)
+        assert int(vj["alpha_g1"][0], 16) == pr.vk.alpha_g1[0].v
+        assert int(vj["gamma_g2"][1][1], 16) == pr.vk.gamma_g2[1].c1

@@ -309,3 +309,19 @@ def test_setup_rejects_unconstrained_variable(ctx):
     with pytest.raises(za_amd.ZaAmdError) as e:
         ctx.setup(R, 3, 5, 7, 11, 13)
     assert e.value.code == za_amd.ZG_E_UNCONSTRAINED_VARIABLE
+
+
+def test_setup_prove_verify_entirely_through_the_abi(ctx):
+    """za's setup -> prove -> verify cycle (prover.rs:225-306) through the C ABI only: GPU set-up and proof,
+    host pairing check (zg_verify), wrong public input rejected."""
+    import za_amd
+    from za_amd import synth
+    sr = synth.SynthR1CS(13, 4, 0.9, 2024)
+    R = sr.load(ctx)
+    P, pbytes = ctx.setup(R, 101, 202, 303, 404, 505)
+    proof = ctx.prove(P, R, sr.witness, 0x77, 0x99)
+    w = np.frombuffer(bytes(sr.witness), dtype=np.uint8).reshape(-1, 32)
+    pub = [int.from_bytes(bytes(w[i]), "little") for i in range(1, sr.n_inputs)]
+    assert za_amd.verify(pbytes, proof, pub) is True
+    assert za_amd.verify(pbytes, proof, [pub[0] ^ 1] + pub[1:]) is False
+    sr.close()

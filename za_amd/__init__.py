@@ -20,6 +20,7 @@ ZG_E_ASSIGNMENT_MISSING = 1
 ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE = 4
 ZG_E_UNEXPECTED_IDENTITY = 5
 ZG_E_IO = 6
+ZG_E_MALFORMED_VERIFYING_KEY = 7
 ZG_E_UNCONSTRAINED_VARIABLE = 8
 ZG_E_BAD_FORMAT = 20
 ZG_E_QUERY_SIZE = 21
@@ -40,7 +41,7 @@ ABI_SYMBOLS = [
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
-    "zg_proof_json", "zg_last_timings",
+    "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
 
@@ -371,6 +372,31 @@ def pk_params_offset(pk_bytes):
     if rc:
         raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
     return off.value
+
+
+def verify(vk_bytes, proof, public_inputs):
+    """Groth16 verification on the host CPU (no GPU needed).  vk_bytes: bellman vk or whole Parameters bytes."""
+    lib = load_library()
+    v, p = _u8(vk_bytes), _u8(proof)
+    pi = _u8(b"".join(int(x).to_bytes(32, "little") for x in public_inputs)) if public_inputs else np.zeros(1, np.uint8)
+    ok = C.c_int()
+    rc = lib.zg_verify(_ptr(v), C.c_size_t(v.size), _ptr(p), _ptr(pi), C.c_size_t(len(public_inputs)), C.byref(ok))
+    if rc:
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return bool(ok.value)
+
+
+def vk_json(vk_bytes, input_names=()):
+    lib = load_library()
+    v = _u8(vk_bytes)
+    names = b"".join(n.encode() + b"\0" for n in input_names)
+    cap = 4096 + 200 * (len(v) // 64)
+    buf = C.create_string_buffer(cap)
+    rc = lib.zg_vk_json(_ptr(v), C.c_size_t(v.size), names if input_names else None, C.c_size_t(len(input_names)), buf,
+                        C.c_size_t(cap))
+    if rc:
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return buf.value.decode()
 
 
 def proof_json(proof, public_inputs):

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libza_amd.so")
-SOURCES = ["msm.hip", "ntt.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip"]
+SOURCES = ["msm.hip", "ntt.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip"]
 HEADERS = ["fp.h", "fd.h", "ec.h", "ecd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc"]

@@ -1,0 +1,277 @@
+// Groth16 verification on the host CPU.
+//
+// Replaces bellman_ce::groth16::{prepare_verifying_key, verify_proof} as za uses them to self-verify every proof
+// (prover/src/groth16/prover.rs:191-200) and in helper::verify (helper.rs:149-159).  Not on the GPU hot path: a
+// straightforward optimal-ate pairing over the tower Fq2[v]/(v^3 - (9+u)), Fq6[w]/(w^2 - v), with the Miller loop in
+// affine coordinates over Fq12 and a plain final exponentiation by (q^12 - 1)/r.  ~60 ms per verification.
+//   e(A, B) = e(alpha, beta) * e(sum ic_i x_i, gamma) * e(C, delta)
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "formats.h"
+
+namespace zg {
+namespace {
+
+// ---------------------------------------------------------------- Fq6 = Fq2[v]/(v^3 - xi), xi = 9 + u
+static Fq2 mul_xi(const Fq2& a) {   // (9 + u)(a0 + a1 u) = (9 a0 - a1) + (9 a1 + a0) u
+    Fq n0 = a.c0.dbl().dbl().dbl() + a.c0, n1 = a.c1.dbl().dbl().dbl() + a.c1;
+    return Fq2{n0 - a.c1, n1 + a.c0};
+}
+struct Fq6 {
+    Fq2 c0, c1, c2;
+    static Fq6 zero() { return Fq6{Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+    static Fq6 one() { return Fq6{Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero() && c2.is_zero(); }
+    bool operator==(const Fq6& o) const { return c0 == o.c0 && c1 == o.c1 && c2 == o.c2; }
+    Fq6 operator+(const Fq6& o) const { return Fq6{c0 + o.c0, c1 + o.c1, c2 + o.c2}; }
+    Fq6 operator-(const Fq6& o) const { return Fq6{c0 - o.c0, c1 - o.c1, c2 - o.c2}; }
+    Fq6 neg() const { return Fq6{c0.neg(), c1.neg(), c2.neg()}; }
+    Fq6 operator*(const Fq6& o) const {   // schoolbook with v^3 = xi
+        Fq2 t0 = c0 * o.c0, t1 = c1 * o.c1, t2 = c2 * o.c2;
+        Fq2 r0 = t0 + mul_xi(c1 * o.c2 + c2 * o.c1);
+        Fq2 r1 = c0 * o.c1 + c1 * o.c0 + mul_xi(t2);
+        Fq2 r2 = c0 * o.c2 + c2 * o.c0 + t1;
+        return Fq6{r0, r1, r2};
+    }
+    Fq6 mul_v() const { return Fq6{mul_xi(c2), c0, c1}; }   // times v
+    Fq6 inv() const {
+        Fq2 a = c0.sqr() - mul_xi(c1 * c2);
+        Fq2 b = mul_xi(c2.sqr()) - c0 * c1;
+        Fq2 c = c1.sqr() - c0 * c2;
+        Fq2 d = (c0 * a + mul_xi(c2 * b + c1 * c)).inv();
+        return Fq6{a * d, b * d, c * d};
+    }
+};
+// ---------------------------------------------------------------- Fq12 = Fq6[w]/(w^2 - v)
+struct Fq12 {
+    Fq6 c0, c1;
+    static Fq12 zero() { return Fq12{Fq6::zero(), Fq6::zero()}; }
+    static Fq12 one() { return Fq12{Fq6::one(), Fq6::zero()}; }
+    bool operator==(const Fq12& o) const { return c0 == o.c0 && c1 == o.c1; }
+    Fq12 operator+(const Fq12& o) const { return Fq12{c0 + o.c0, c1 + o.c1}; }
+    Fq12 operator-(const Fq12& o) const { return Fq12{c0 - o.c0, c1 - o.c1}; }
+    Fq12 neg() const { return Fq12{c0.neg(), c1.neg()}; }
+    Fq12 operator*(const Fq12& o) const {
+        Fq6 aa = c0 * o.c0, bb = c1 * o.c1;
+        return Fq12{aa + bb.mul_v(), (c0 + c1) * (o.c0 + o.c1) - aa - bb};
+    }
+    Fq12 sqr() const { return *this * *this; }
+    Fq12 inv() const {
+        Fq6 d = (c0 * c0 - (c1 * c1).mul_v()).inv();
+        return Fq12{c0 * d, (c1 * d).neg()};
+    }
+    Fq12 pow(const uint64_t* e, int words) const {
+        Fq12 acc = one();
+        bool started = false;
+        for (int i = words * 64 - 1; i >= 0; i--) {
+            if (started) acc = acc.sqr();
+            if ((e[i >> 6] >> (i & 63)) & 1) {
+                acc = started ? acc * *this : *this;
+                started = true;
+            }
+        }
+        return acc;
+    }
+};
+static Fq12 from_fq(const Fq& a) {
+    Fq12 r = Fq12::zero();
+    r.c0.c0.c0 = a;
+    return r;
+}
+struct Pt12 {
+    Fq12 x, y;
+};
+// D-type twist: (x', y') on y^2 = x^3 + 3/xi  ->  (x' w^2, y' w^3) = (x' v, y' v w) on y^2 = x^3 + 3 over Fq12
+static Pt12 untwist(const G2Affine& q) {
+    Pt12 r{Fq12::zero(), Fq12::zero()};
+    r.x.c0.c1 = q.x;   // x' * v
+    r.y.c1.c1 = q.y;   // y' * v * w
+    return r;
+}
+static Pt12 embed(const G1Affine& p) { return Pt12{from_fq(p.x), from_fq(p.y)}; }
+
+static Fq12 times3(const Fq12& a) { return a + a + a; }
+static Pt12 pt_double(const Pt12& p) {
+    Fq12 m = times3(p.x.sqr()) * (p.y + p.y).inv();
+    Fq12 nx = m.sqr() - p.x - p.x;
+    return Pt12{nx, m * (p.x - nx) - p.y};
+}
+static Pt12 pt_add(const Pt12& p, const Pt12& s) {   // distinct x (always the case in the Miller loop)
+    Fq12 m = (s.y - p.y) * (s.x - p.x).inv();
+    Fq12 nx = m.sqr() - p.x - s.x;
+    return Pt12{nx, m * (p.x - nx) - p.y};
+}
+// line through p1, p2 evaluated at t
+static Fq12 line(const Pt12& p1, const Pt12& p2, const Pt12& t) {
+    if (!(p1.x == p2.x)) {
+        Fq12 m = (p2.y - p1.y) * (p2.x - p1.x).inv();
+        return m * (t.x - p1.x) - (t.y - p1.y);
+    }
+    if (p1.y == p2.y) {
+        Fq12 m = times3(p1.x.sqr()) * (p1.y + p1.y).inv();
+        return m * (t.x - p1.x) - (t.y - p1.y);
+    }
+    return t.x - p1.x;
+}
+static const uint64_t Q_WORDS[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull,
+                                    0x30644e72e131a029ull};
+static Fq12 frobenius(const Fq12& a) { return a.pow(Q_WORDS, 4); }
+
+static Fq12 miller_loop(const G2Affine& qa, const G1Affine& pa) {
+    if (qa.is_inf() || pa.is_inf()) return Fq12::one();
+    const Pt12 q = untwist(qa), p = embed(pa);
+    const unsigned __int128 ate = ((unsigned __int128)1 << 64) | 0x9d797039be763ba8ull;   // 6u + 2 = 29793968203157093288
+    Pt12 r = q;
+    Fq12 f = Fq12::one();
+    for (int i = 63; i >= 0; i--) {
+        f = f.sqr() * line(r, r, p);
+        r = pt_double(r);
+        if ((ate >> i) & 1) {
+            f = f * line(r, q, p);
+            r = pt_add(r, q);
+        }
+    }
+    Pt12 q1{frobenius(q.x), frobenius(q.y)};
+    Pt12 nq2{frobenius(q1.x), frobenius(q1.y).neg()};
+    f = f * line(r, q1, p);
+    r = pt_add(r, q1);
+    f = f * line(r, nq2, p);
+    return f;
+}
+static const uint64_t FINAL_EXP[44] = {
+    0x86964b64ca86f120ull, 0x40a4efb7e54523a4ull, 0x837fa97896e84abbull,
+    0x361102b6b9b2b918ull, 0xc0de81def35692daull, 0xbe04c7e8a6c3c760ull,
+    0xd766f9c9d570bb7full, 0xc230974d83561841ull, 0x5bba1668c3be69a3ull,
+    0x7f3811c410526294ull, 0x29baee7ddadda71cull, 0xbf813b8d145da900ull,
+    0x641bbadf423f9a2cull, 0xa80bb4ea44eacc5eull, 0xcd65664814fde37cull,
+    0x4a0364b9580291d2ull, 0xee93dfb10826f0ddull, 0x6b42db8dc5514724ull,
+    0xbb10cf430b0f3785ull, 0x40494e406f804216ull, 0x55cfe107acf3aafbull,
+    0x2088ec80e0ebae87ull, 0x846a3ed011a337a0ull, 0x48a45a4a1e3a5195ull,
+    0xe5664568dfc50e16ull, 0xab6a41294c0cc4ebull, 0x82d0d602d268c7daull,
+    0x6668449aed3cc48aull, 0x5062cd0fb2015dfcull, 0x7f2940a8b1ddb3d1ull,
+    0x77f5b63a2a226448ull, 0xfef0781361e443aeull, 0xf977870e88d5c6c8ull,
+    0x790364a61f676baaull, 0x5887e72eceaddea3ull, 0x1377e563a09a1b70ull,
+    0x0c54efee1bd8c3b2ull, 0x3ec3d15ad524d8f7ull, 0xdaf15466b2383a5dull,
+    0xe1e30a73bb94fec0ull, 0x6a1c71015f3f7be2ull, 0x842d43bf6369b1ffull,
+    0x20fddadf107d20bcull, 0x0000002f4b6dc970ull};   // (q^12 - 1) / r
+
+struct Vk {
+    G1Affine alpha_g1, beta_g1, delta_g1;
+    G2Affine beta_g2, gamma_g2, delta_g2;
+    std::vector<G1Affine> ic;
+};
+
+}  // namespace
+
+// bellman VerifyingKey::read == the prefix of Parameters::write (format.rs:250): alpha_g1, beta_g1, beta_g2,
+// gamma_g2, delta_g1, delta_g2, u32be |ic|, ic
+static int parse_vk(Ctx* ctx, const uint8_t* buf, size_t len, Vk* vk) {
+    // reuse the Parameters parser on a buffer that ends after ic by appending five empty queries
+    size_t need = 64 + 64 + 128 + 128 + 64 + 128 + 4;
+    if (len < need) return fail(ctx, ZG_E_IO, "verifying key: unexpected end");
+    uint32_t n = ((uint32_t)buf[need - 4] << 24) | ((uint32_t)buf[need - 3] << 16) | ((uint32_t)buf[need - 2] << 8) | buf[need - 1];
+    if ((size_t)n * 64 > len - need) return fail(ctx, ZG_E_IO, "verifying key: ic exceeds the buffer");
+    std::vector<uint8_t> tmp(buf, buf + need + (size_t)n * 64);
+    tmp.resize(tmp.size() + 20, 0);   // h, l, a, b_g1, b_g2 with zero entries
+    ParsedParams pp;
+    ZG_TRY(parse_bellman_params(ctx, tmp.data(), tmp.size(), true, &pp, nullptr));
+    vk->alpha_g1 = pp.alpha_g1; vk->beta_g1 = pp.beta_g1; vk->delta_g1 = pp.delta_g1;
+    vk->beta_g2 = pp.beta_g2; vk->gamma_g2 = pp.gamma_g2; vk->delta_g2 = pp.delta_g2;
+    vk->ic = pp.ic;
+    return ZG_OK;
+}
+
+static void fq_hex(std::string* s, const Fq& m) {
+    uint8_t be[32];
+    fq_to_be(be, m);
+    static const char* d = "0123456789abcdef";
+    *s += "\"0x";
+    for (int i = 0; i < 32; i++) { s->push_back(d[be[i] >> 4]); s->push_back(d[be[i] & 15]); }
+    *s += "\"";
+}
+static int g1_json(std::string* s, const G1Affine& p) {
+    if (p.is_inf()) return ZG_E_BAD_FORMAT;   // BadFormat("invalid point"), format.rs:49-50
+    *s += "["; fq_hex(s, p.x); *s += ","; fq_hex(s, p.y); *s += "]";
+    return ZG_OK;
+}
+static int g2_json(std::string* s, const G2Affine& p) {
+    if (p.is_inf()) return ZG_E_BAD_FORMAT;
+    *s += "[["; fq_hex(s, p.x.c0); *s += ","; fq_hex(s, p.x.c1); *s += "],["; fq_hex(s, p.y.c0); *s += ",";
+    fq_hex(s, p.y.c1); *s += "]]";
+    return ZG_OK;
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+// proof: 256 bytes (A.x A.y B.x.c0 B.x.c1 B.y.c0 B.y.c1 C.x C.y canonical big-endian)
+extern "C" int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t proof[256], const uint8_t* public_inputs32,
+                         size_t n_public, int* ok) {
+    if (!vk_bytes || !proof || !ok || (n_public && !public_inputs32)) return ZG_E_INVALID_ARG;
+    *ok = 0;
+    Ctx tmp;
+    Vk vk;
+    ZG_TRY(parse_vk(&tmp, vk_bytes, vk_len, &vk));
+    if (n_public + 1 != vk.ic.size()) return ZG_E_MALFORMED_VERIFYING_KEY;
+    G1Affine A, C;
+    G2Affine B;
+    if (!fq_from_be(proof, &A.x) || !fq_from_be(proof + 32, &A.y) || !fq_from_be(proof + 64, &B.x.c0) ||
+        !fq_from_be(proof + 96, &B.x.c1) || !fq_from_be(proof + 128, &B.y.c0) || !fq_from_be(proof + 160, &B.y.c1) ||
+        !fq_from_be(proof + 192, &C.x) || !fq_from_be(proof + 224, &C.y))
+        return ZG_E_BAD_FORMAT;
+    if (!on_curve(A, Fq::from_u64(3)) || !on_curve(C, Fq::from_u64(3)) || !on_curve(B, g2_coeff_b()))
+        return ZG_E_BAD_FORMAT;   // try_from_coordinates fails: "bad coordinates" (format.rs:41-44)
+    G1XYZZ acc = G1XYZZ::from_affine(vk.ic[0]);
+    for (size_t i = 0; i < n_public; i++) {
+        uint32_t k[8];
+        memcpy(k, public_inputs32 + 32 * i, 32);
+        acc = acc.add(G1XYZZ::from_affine(vk.ic[i + 1]).mul(k));
+    }
+    Fq12 f = miller_loop(B, A);
+    f = f * miller_loop(vk.beta_g2, vk.alpha_g1.neg());
+    f = f * miller_loop(vk.gamma_g2, acc.to_affine().neg());
+    f = f * miller_loop(vk.delta_g2, C.neg());
+    *ok = f.pow(FINAL_EXP, 44) == Fq12::one() ? 1 : 0;
+    return ZG_OK;
+}
+
+// vk JSON as JsonVerifyingKey serialises it (prover/src/groth16/format.rs:130-167): alpha_g1, beta_g1, beta_g2,
+// delta_g1, delta_g2, gamma_g2, ic, input_names.  names: n_names NUL-terminated strings back to back (may be NULL).
+extern "C" int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out, size_t cap) {
+    if (!vk_bytes || !out) return ZG_E_INVALID_ARG;
+    Ctx tmp;
+    Vk vk;
+    ZG_TRY(parse_vk(&tmp, vk_bytes, vk_len, &vk));
+    std::string j = "{\"alpha_g1\":";
+    ZG_TRY(g1_json(&j, vk.alpha_g1));
+    j += ",\"beta_g1\":"; ZG_TRY(g1_json(&j, vk.beta_g1));
+    j += ",\"beta_g2\":"; ZG_TRY(g2_json(&j, vk.beta_g2));
+    j += ",\"delta_g1\":"; ZG_TRY(g1_json(&j, vk.delta_g1));
+    j += ",\"delta_g2\":"; ZG_TRY(g2_json(&j, vk.delta_g2));
+    j += ",\"gamma_g2\":"; ZG_TRY(g2_json(&j, vk.gamma_g2));
+    j += ",\"ic\":[";
+    for (size_t i = 0; i < vk.ic.size(); i++) {
+        if (i) j += ",";
+        ZG_TRY(g1_json(&j, vk.ic[i]));
+    }
+    j += "],\"input_names\":[";
+    const char* p = names;
+    for (size_t i = 0; i < n_names && p; i++) {
+        if (i) j += ",";
+        j += "\"";
+        for (; *p; p++) {
+            if (*p == '"' || *p == '\\') j.push_back('\\');
+            j.push_back(*p);
+        }
+        p++;
+        j += "\"";
+    }
+    j += "]}";
+    if (j.size() >= cap) return ZG_E_BUFFER_TOO_SMALL;
+    memcpy(out, j.c_str(), j.size() + 1);
+    return ZG_OK;
+}
