@@ -197,6 +197,12 @@ int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void
 int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs,
                           const void* d_witness, const void* d_h_shard,
                           uint8_t partials[ZG_PARTIALS_BYTES]);
+/* The same with a subset of the five sums (mask bit 0 h, 1 l, 2 a, 3 b_g1, 4 b_g2; skipped ones are returned as the
+ * identity), and a non-blocking form of zg_prove_h_dev: lets every rank run its witness MSMs (bits 1-4, no H needed)
+ * while rank 0's NTT pipeline is still in flight; zg_sync before reading d_h_out. */
+int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
+                         const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]);
+int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_h_out);
 int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partials_all, int world,
                      const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */

@@ -34,7 +34,10 @@ class OracleEngine:
         self.shard_range = shard_range
         _, _, _, self.ad, self.bi, self.bd = g.eval_constraints(self.r1, self.w)
 
-    def compute_h(self):
+    def start_h(self):
+        pass
+
+    def finish_h(self):
         h = g.h_coefficients(self.r1, self.w) + [0]
         n = self.world * self.h_chunk_entries
         h = h + [0] * (max(n, self.m) - len(h))
@@ -48,12 +51,17 @@ class OracleEngine:
         one = bn.le32(bn.mont(1, bn.Q)) + (b"\0" * 32 if fb == 64 else b"")
         return enc + one
 
-    def partials(self, h_shard):
+    def partials(self, h_shard, mask):
         p, ni = self.params, self.r1.num_inputs
-        hs = [bn.from_le32(bytes(h_shard[32 * i:32 * i + 32].tolist())) for i in range(h_shard.numel() // 32)]
-        lo, hi = self.shard_range(self.n_h, self.rank, self.world)
-        hi = min(hi, self.m - 1)
-        h_acc = bn.msm_naive(p.h[lo:hi], hs[:max(hi - lo, 0)])
+        h_acc = None
+        if mask & 1:
+            hs = [bn.from_le32(bytes(h_shard[32 * i:32 * i + 32].tolist())) for i in range(h_shard.numel() // 32)]
+            lo, hi = self.shard_range(self.n_h, self.rank, self.world)
+            hi = min(hi, self.m - 1)
+            h_acc = bn.msm_naive(p.h[lo:hi], hs[:max(hi - lo, 0)])
+        if not (mask & 0x1e):
+            buf = self._jac(h_acc, 32) + self._jac(None, 32) * 3 + self._jac(None, 64)
+            return torch.frombuffer(bytearray(buf), dtype=torch.uint8)
         aux = self.w[ni:]
         lo, hi = self.shard_range(len(p.l), self.rank, self.world)
         l_acc = bn.msm_naive(p.l[lo:hi], aux[lo:hi])

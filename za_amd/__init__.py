@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
-    "zg_prove_h_dev", "zg_prove_partials_dev", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
@@ -280,10 +280,15 @@ class Context:
     def prove_h_dev(self, r1cs, d_witness, d_h_out):
         self._check(self.lib.zg_prove_h_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
 
-    def prove_partials_dev(self, params, r1cs, d_witness, d_h_shard):
+    def prove_h_enqueue_dev(self, r1cs, d_witness, d_h_out):
+        """Non-blocking: queue R1CS evaluation + H; call sync() before using d_h_out."""
+        self._check(self.lib.zg_prove_h_enqueue_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
+
+    def prove_partials_dev(self, params, r1cs, d_witness, d_h_shard, mask=0x1f):
+        """mask bit 0 h, 1 l, 2 a, 3 b_g1, 4 b_g2; skipped sums come back as the identity."""
         out = np.zeros(ZG_PARTIALS_BYTES, dtype=np.uint8)
-        self._check(self.lib.zg_prove_partials_dev(self.h, params.h, r1cs.h, C.c_void_p(d_witness),
-                                                   C.c_void_p(d_h_shard), _ptr(out)))
+        self._check(self.lib.zg_prove_partials_ex(self.h, params.h, r1cs.h, C.c_void_p(d_witness),
+                                                  C.c_void_p(d_h_shard), C.c_uint(mask), _ptr(out)))
         return out
 
     def prove_combine(self, params, partials_all, world, r, s):

@@ -675,6 +675,18 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
 
 extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
                                      const void* d_h_shard, uint8_t partials[ZG_PARTIALS_BYTES]) {
+    return zg_prove_partials_ex(ctx, p, r, d_witness, d_h_shard, 0x1f, partials);
+}
+
+extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+    if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    return prove_h_enqueue(ctx, r, d_witness, d_h_out);
+}
+
+extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
+                                    const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -689,26 +701,27 @@ extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r
         const auto& q = p->q[0];
         uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
         uint64_t n = hi > q.lo ? hi - q.lo : 0;
+        if (!(mask & 1u)) n = 0;
         if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
         d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n};
     }
     {   // l: aux assignment, full density
         const auto& q = p->q[1];
         uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
-        uint64_t n = hi > q.lo ? hi - q.lo : 0;
+        uint64_t n = hi > q.lo && (mask & 2u) ? hi - q.lo : 0;
         d1[1] = MsmDesc{q.buf.p, w + 8 * ((size_t)r->n_inputs + q.lo), nullptr, (size_t)n};
     }
     {   // a: inputs (full density) then aux by a_aux_density
         const auto& q = p->q[2];
-        d1[2] = MsmDesc{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
+        d1[2] = MsmDesc{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (mask & 4u) ? (size_t)(q.hi - q.lo) : 0};
     }
     {
         const auto& q = p->q[3];
-        d1[3] = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
+        d1[3] = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 8u) ? (size_t)(q.hi - q.lo) : 0};
     }
     {
         const auto& q = p->q[4];
-        d2 = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (size_t)(q.hi - q.lo)};
+        d2 = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 16u) ? (size_t)(q.hi - q.lo) : 0};
     }
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ctx->ev_witness, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];

@@ -2,8 +2,9 @@
 
 The MSMs shard by base/scalar chunk: every rank keeps its chunk of the h, l, a, b_g1, b_g2 queries
 resident in HBM.  The NTT pipeline stays on rank 0, whose H scalars are scattered in equal chunks
-(the one bulk exchange, (m*32 B)/world per peer over xGMI).  Each rank then computes five partial
-sums (576 bytes) which are all-gathered; rank 0 adds them and applies r, s.  RCCL cannot add curve
+(the one bulk exchange, (m*32 B)/world per peer over xGMI).  Each rank computes five partial sums
+(576 bytes: the witness MSMs while the NTT is still running, the h MSM after the scatter) which are
+all-gathered; rank 0 adds them and applies r, s.  RCCL cannot add curve
 points, so the "reduce" is gather + local point adds.
 
 `engine` abstracts the per-rank compute so the same orchestration runs on GPUs (GpuEngine, RCCL)
@@ -20,19 +21,36 @@ def shard_range(total, rank, world):
     return lo, min(total, lo + chunk)
 
 
+H_MASK, WITNESS_MASK = 0x01, 0x1e
+
+
+def _merge_partials(h_part, w_part):
+    """h sum from one buffer, l / a / b_g1 / b_g2 from the other (576-byte layout of zg_prove_partials_*)."""
+    out = w_part.clone()
+    out[:96] = h_part[:96]
+    return out
+
+
 def sharded_prove(engine, r, s, group=None):
     """Collective: every rank calls it; rank 0 returns the 256-byte proof, the others None.
 
     engine.h_chunk_entries          number of H scalars per rank (ceil(n_h / world))
-    engine.compute_h()              rank 0: uint8 tensor [world * chunk * 32] (zero padded) on engine.device
-    engine.partials(h_shard)        uint8 tensor [576] on engine.device
+    engine.start_h()                rank 0: queue R1CS evaluation + the 7 NTTs, do not wait
+    engine.finish_h()               rank 0: wait; uint8 tensor [world * chunk * 32] (zero padded) on engine.device
+    engine.partials(h_shard, mask)  uint8 tensor [576] on engine.device (masked-out sums = identity)
     engine.combine(partials, world, r, s) -> bytes  (rank 0)
+
+    The witness MSMs (l, a, b_g1, b_g2) need no H, so every rank runs its shards of them while rank 0's NTT
+    pipeline is in flight; only the h MSM waits for the scatter.
     """
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nbytes = engine.h_chunk_entries * 32
+    if rank == 0:
+        engine.start_h()
+    w_part = engine.partials(None, WITNESS_MASK)
     mine = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
     if rank == 0:
-        h_all = engine.compute_h()
+        h_all = engine.finish_h()
         assert h_all.numel() == world * nbytes
         scatter_list = list(h_all.view(world, nbytes).unbind(0))
     else:
@@ -44,7 +62,7 @@ def sharded_prove(engine, r, s, group=None):
             torch.cuda.current_stream(mine.device).synchronize()
     else:
         mine = scatter_list[0]
-    part = engine.partials(mine)
+    part = _merge_partials(engine.partials(mine, H_MASK), w_part)
     if world > 1:
         gathered = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(gathered, part, group=group)
@@ -75,16 +93,21 @@ class GpuEngine:
         # caller stores it on the params object (synth_params / params_load know it)
         return self.params.total_h
 
-    def compute_h(self):
+    def start_h(self):
         n = self.world * self.h_chunk_entries
         need = max(n, self.m)
         if self._h_all is None or self._h_all.numel() != need * 32:
             self._h_all = torch.zeros(need * 32, dtype=torch.uint8, device=self.device)
-        self.ctx.prove_h_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
-        return self._h_all[: n * 32]
+            torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.prove_h_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
 
-    def partials(self, h_shard):
-        out = self.ctx.prove_partials_dev(self.params, self.r1cs, self.d_witness, h_shard.data_ptr())
+    def finish_h(self):
+        self.ctx.sync()
+        return self._h_all[: self.world * self.h_chunk_entries * 32]
+
+    def partials(self, h_shard, mask):
+        ptr = 0 if h_shard is None else h_shard.data_ptr()
+        out = self.ctx.prove_partials_dev(self.params, self.r1cs, self.d_witness, ptr, mask)
         return torch.from_numpy(out).to(self.device)
 
     def combine(self, partials_all, world, r, s):
