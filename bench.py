@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
     ap.add_argument("--cpu-log-m", type=int, default=22, help="size of the bounded CPU-baseline sample (2^22 = the GPU workload itself, ~10 s of CPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo stages through host memory (debugging only)")
     ap.add_argument("--synthetic-key", action="store_true", help="skip the set-up; use bases with known discrete logs")
     ap.add_argument("--msm-only", action="store_true", help="also time a standalone 2^log_m G1 MSM (uniform scalars)")
     return ap.parse_args()
@@ -103,12 +105,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU fallback)", file=sys.stderr)
         sys.exit(1)
+    # ZA_BENCH_DEVICE pins every rank to one device: lets the N > 1 code path be exercised on a 1-GPU box
+    # (with --dist-backend gloo; RCCL itself needs one GPU per rank)
+    if "ZA_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ZA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = za_amd.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -167,7 +176,7 @@ def main():
     ctx.profile_enable(False)
     phases = ctx.last_timings()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

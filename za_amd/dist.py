@@ -55,8 +55,15 @@ def sharded_prove(engine, r, s, group=None):
         scatter_list = list(h_all.view(world, nbytes).unbind(0))
     else:
         scatter_list = None
+    # gloo (CPU tests, or a debugging run of several ranks on one GPU) moves bytes through host memory
+    staged = world > 1 and dist.get_backend(group) == "gloo" and mine.is_cuda
     if world > 1:
-        dist.scatter(mine, scatter_list, src=0, group=group)
+        if staged:
+            host = torch.empty(nbytes, dtype=torch.uint8)
+            dist.scatter(host, [t.cpu() for t in scatter_list] if rank == 0 else None, src=0, group=group)
+            mine.copy_(host)
+        else:
+            dist.scatter(mine, scatter_list, src=0, group=group)
         # the library launches on its own HIP streams: make the received chunk visible to them
         if mine.is_cuda:
             torch.cuda.current_stream(mine.device).synchronize()
@@ -64,6 +71,8 @@ def sharded_prove(engine, r, s, group=None):
         mine = scatter_list[0]
     part = _merge_partials(engine.partials(mine, H_MASK), w_part)
     if world > 1:
+        if staged:
+            part = part.cpu()
         gathered = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(gathered, part, group=group)
     else:
