@@ -325,3 +325,64 @@ def test_setup_prove_verify_entirely_through_the_abi(ctx):
     assert za_amd.verify(pbytes, proof, pub) is True
     assert za_amd.verify(pbytes, proof, [pub[0] ^ 1] + pub[1:]) is False
     sr.close()
+
+
+def test_ragged_circuit_shapes_against_the_python_oracle(ctx):
+    """Edge shapes: empty linear combinations, a variable repeated inside one LC, a constant row (ONE * ONE = ONE),
+    more inputs than constraints, an aux variable used only in C.  Key from the GPU set-up, proof vs the oracle."""
+    R_ = bn.R
+    w = [1, 5, 7, 3, 4, 12, 35, 6]          # ONE, two public inputs, five aux
+    # var: 0 ONE, 1 x=5, 2 y=7 | 3 a=3, 4 b=4, 5 c=12, 6 d=35, 7 e=6
+    cons = [
+        ([(3, 1)], [(4, 1)], [(5, 1)]),                         # a*b = c
+        ([(1, 1)], [(2, 1)], [(6, 1)]),                         # x*y = d
+        ([(3, 1), (3, 1)], [(0, 1)], [(7, 1)]),                 # (a + a)*ONE = e   (duplicate term)
+        ([], [(5, 1)], []),                                     # 0 * c = 0         (empty A and C)
+        ([(0, 1)], [(0, 1)], [(0, 1)]),                         # ONE*ONE = ONE
+        ([(7, 2)], [(0, 1)], [(5, 1)]),                         # 2e * ONE = c
+    ]
+    r1 = g.R1CS(3, 5, cons)
+    assert r1.is_satisfied(w)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    td = (0x11, 0x22, 0x33, 0x44, 0x55)
+    P, pbytes = ctx.setup(R, *td)
+    params, _ = g.generate_parameters(r1, *td)
+    assert pbytes == g.params_write(params)
+    exp = g.create_proof(r1, params, w, 9, 10)
+    got = ctx.prove(P, R, co.witness_bytes(w), 9, 10)
+    assert got == g.proof_bytes(exp)
+    import za_amd
+    assert za_amd.verify(pbytes, got, w[1:3])
+
+
+def test_setup_rejects_a_key_that_would_not_match_the_density_maps(ctx):
+    """A zero coefficient is still a *mention* for bellman's prover (density bit set) while the generator drops the
+    identity point: the sharp edge of SURVEY section 8a.  zg_setup refuses such a circuit instead of emitting a key
+    whose a/b queries are misaligned."""
+    import za_amd
+    r1 = g.R1CS(2, 2, [([(2, 1), (3, 0)], [(3, 1)], [(1, 1)])])   # aux 1 mentioned in A with coefficient 0
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.setup(R, 3, 5, 7, 11, 13)
+    assert e.value.code == za_amd.ZG_E_BAD_FORMAT
+
+
+def test_witness_of_all_zero_aux_and_of_all_ones(ctx):
+    """Degenerate scalar sets: every MSM bucket empty except ONE's, and the all-ones bucket path."""
+    from oracle.circuits import chain_r1cs
+    for val in (0, 1):
+        n_aux = 6
+        cons = [([(1 + i, 1)], [(2 + i, 1)], [(1 + i, 1)]) for i in range(0, n_aux)]   # v*v' = v for v in {0,1}
+        r1 = g.R1CS(1, n_aux + 1, cons)
+        w = [1] + [val] * (n_aux + 1)
+        assert r1.is_satisfied(w)
+        csr = co.CsrR1CS.from_r1cs(r1)
+        R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+        td = (5, 6, 7, 8, 9)
+        P, pbytes = ctx.setup(R, *td)
+        params, _ = g.generate_parameters(r1, *td)
+        assert pbytes == g.params_write(params)
+        exp = g.create_proof(r1, params, w, 3, 4)
+        assert ctx.prove(P, R, co.witness_bytes(w), 3, 4) == g.proof_bytes(exp)
