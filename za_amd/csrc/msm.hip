@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_xscan_final(uint32_t* __restri
 }
 
 // level 2: one workgroup per bin; segment [tile_off[bin*ntiles], tile_off[(bin+1)*ntiles]) of A
-__global__ void __launch_bounds__(256) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
+__global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
                                                     uint32_t ntiles, uint32_t nbins, int lb,
                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, then 8 words of scan scratch
@@ -624,7 +624,7 @@ struct MsmJob : MsmJobBase {
                            ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
-        hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(256), lds2, st, S.abuf.as<uint2>(),
+        hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                            S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, S.counts.as<uint32_t>(),
                            S.sorted.as<uint32_t>());
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals

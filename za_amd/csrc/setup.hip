@@ -154,8 +154,6 @@ extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160],
     DevBuf abct[3];
     std::vector<uint8_t> mention_a(nv, 0), mention_b(nv, 0);
     for (int k = 0; k < 3; k++) {
-        const size_t nnz = r->col[k].bytes / 4 ? (size_t)0 : 0;
-        (void)nnz;
         std::vector<uint64_t> rp(nc + 1);
         ZG_HIP(ctx, hipMemcpyAsync(rp.data(), r->row_ptr[k].p, (nc + 1) * 8, hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipStreamSynchronize(st));
