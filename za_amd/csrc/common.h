@@ -109,6 +109,7 @@ struct MsmDesc {
     const uint32_t* scalars;
     const uint32_t* index;
     size_t n;
+    bool dense = false;   // scalars known to be essentially all "real" (H coefficients): skip the classification pass
 };
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,

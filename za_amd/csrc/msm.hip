@@ -548,6 +548,7 @@ struct MsmJob : MsmJobBase {
     const uint32_t* d_index;
     size_t n;
     XYZZ<F>* out;
+    bool dense = false;   // plan from n directly, no k_classify round trip
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
     int grid = 1;
@@ -570,6 +571,11 @@ struct MsmJob : MsmJobBase {
         if (!S.host) ZG_HIP(ctx, hipHostMalloc((void**)&S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
         grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
         ZG_HIP(ctx, S.meta.reserve(64));
+        if (dense) {   // counts are taken as (0 zeros, 0 ones): the plan and the buffer bounds stay valid for any data
+            uint32_t* cls = reinterpret_cast<uint32_t*>(S.host);
+            cls[0] = cls[1] = 0;
+            return ZG_OK;
+        }
         ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, S.meta.as<uint32_t>() + 8);
@@ -814,6 +820,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     }
     MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
     MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
+    j0.dense = g1[0].dense;
     MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
     MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
     MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);

@@ -703,7 +703,7 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
         uint64_t n = hi > q.lo ? hi - q.lo : 0;
         if (!(mask & 1u)) n = 0;
         if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
-        d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n};
+        d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n, /*dense=*/true};
     }
     {   // l: aux assignment, full density
         const auto& q = p->q[1];
