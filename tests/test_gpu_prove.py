@@ -386,3 +386,43 @@ def test_witness_of_all_zero_aux_and_of_all_ones(ctx):
         assert pbytes == g.params_write(params)
         exp = g.create_proof(r1, params, w, 3, 4)
         assert ctx.prove(P, R, co.witness_bytes(w), 3, 4) == g.proof_bytes(exp)
+
+
+@pytest.mark.parametrize("lg", [12, 15, 20])
+def test_poseidon_chain_circuit_setup_prove_verify(ctx, lg):
+    """BASELINE config 3 (circomlib Poseidon t=6 chain up to 2^20 rows: dense 6-term mix rows, no bit signals, so every
+    scalar takes the full-width Pippenger path): GPU set-up, GPU proof equal to the C oracle's bytes with the same
+    key, host pairing check on the public hash."""
+    import za_amd
+    from oracle.circuits import poseidon_chain_r1cs
+    r1, w, hs = poseidon_chain_r1cs(lg)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, pbytes = ctx.setup(R, 0xA1, 0xB2, 0xC3, 0xD4, 0xE5)
+    wb = co.witness_bytes(w)
+    got = ctx.prove(P, R, wb, 0x1234567, 0x7654321)
+    mp = download_params(ctx, P)
+    assert co.prove(mp, csr, wb, 0x1234567, 0x7654321, threads=32) == got
+    assert za_amd.verify(pbytes, got, [hs[-1]]) is True
+    assert za_amd.verify(pbytes, got, [hs[0]]) is (len(hs) == 1)
+
+
+def test_fixed_base_window_table_gives_the_same_proof_as_the_plain_schedule(ctx, monkeypatch):
+    """The h multiexp through the per-key window table (one bucket set, digits folded) and through the plain
+    per-window schedule (ZA_AMD_FBW=0) must agree byte for byte; both against the C oracle."""
+    from za_amd import synth
+    lg = 13
+    sr = synth.SynthR1CS(lg, 2, 0.5, 77)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P_tab = synth.synth_params(ctx, *sizes, 31)
+    P_tab.prepare(R)
+    with_table = ctx.prove(P_tab, R, sr.witness, 5, 6)
+    monkeypatch.setenv("ZA_AMD_FBW", "0")
+    P_plain = synth.synth_params(ctx, *sizes, 31)
+    plain = ctx.prove(P_plain, R, sr.witness, 5, 6)
+    assert with_table == plain
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    assert co.prove(download_params(ctx, P_plain), csr, sr.witness, 5, 6, threads=8) == plain
+    sr.close()

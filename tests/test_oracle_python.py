@@ -115,3 +115,17 @@ def test_bellman_multiexp_equals_definition():
         pts = [bn.pt_mul(bn.G1_GEN, rng.randrange(1, bn.R)) for _ in range(n)]
         sc = [rng.choice([0, 1, bn.R - 1, rng.randrange(bn.R)]) for _ in range(n)]
         assert g.multiexp_bellman(pts, None, sc) == bn.msm_naive(pts, sc)
+
+
+def test_poseidon_chain_generator_is_pinned_by_the_reference_known_answers():
+    """BASELINE config 3's circuit family.  The hash values are the reference's own
+    (interop/circuits/circomlib/test/poseidoncircuit.js:41,54)."""
+    from oracle import circuits as ci
+    assert ci.poseidon_hash([1, 2]) == 12242166908188651009877250812424843524687801523336557272219921456462821518061
+    assert ci.poseidon_hash([3, 4]) == 17185195740979599334254027721507328033796809509313949281114643312710535000993
+    r1, w, hs = ci.poseidon_chain_r1cs(12)
+    assert len(r1.constraints) + r1.num_inputs == 1 << 12
+    assert hs[0] == ci.poseidon_hash([2, 1]) and w[1] == hs[-1]
+    assert r1.is_satisfied(w)
+    bad = list(w); bad[1] = (bad[1] + 1) % ci.R
+    assert not r1.is_satisfied(bad)

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_params_prepare",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
@@ -362,6 +363,10 @@ class Params:
     @property
     def total_h(self):
         return self.query_total(0)
+
+    def prepare(self, r1cs):
+        """Build the h query's fixed-base window table now (otherwise the first prove with this key does it)."""
+        self.ctx._check(self.ctx.lib.zg_params_prepare(self.ctx.h, self.h, r1cs.h))
 
     def close(self):
         if self.h:

@@ -24,5 +24,10 @@ struct zg_params {
         uint64_t total = 0, lo = 0, hi = 0;
     } q[5];  // h, l, a, b_g1, b_g2
     int rank = 0, world = 1;
+    // fixed-base window table of the h query (msm.hip), built on first use for the first `fbw_n` points
+    mutable zg::DevBuf fbw;
+    mutable int fbw_c = 0, fbw_nwin = 0;
+    mutable uint64_t fbw_n = 0;
+    mutable int fbw_state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit
 };
 

@@ -45,9 +45,10 @@ struct MsmScratch {
 };
 
 struct MsmPlan {
-    int c, nwin;
+    int c, nwin;     // digit width, digits per scalar
+    int kw;          // windows in the key space: nwin, or 1 when a fixed-base window table folds them
     uint32_t B;      // buckets per window = 2^(c-1)
-    uint32_t nkeys;  // nwin * B
+    uint32_t nkeys;  // kw * B
     uint32_t T;      // max points per item
 };
 
@@ -69,6 +70,7 @@ static MsmPlan plan_msm(size_t n_real, size_t n_ones) {
             best.B = 1u << (c - 1);
         }
     }
+    best.kw = best.nwin;
     best.nkeys = (uint32_t)best.nwin * best.B;
     size_t mean = (n_real + best.B - 1) / best.B;
     size_t T = 2 * mean;
@@ -76,6 +78,45 @@ static MsmPlan plan_msm(size_t n_real, size_t n_ones) {
     if (T > 512) T = 512;
     best.T = (uint32_t)T;
     return best;
+}
+
+// Fixed-base window table (fbw): the table holds 2^(c*w) * P_i for every digit position w, so ALL digits of a
+// scalar fall into ONE set of 2^(c-1) buckets.  The bucket reduction is paid once instead of once per window,
+// which moves the optimum to a wider digit (c = 20 instead of 16 at n = 2^22: 13 instead of 16 mixed adds per
+// scalar).  Costs nwin x the key's HBM footprint -- the trade 288 GB of HBM3E is there for.
+static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
+    MsmPlan p{};
+    p.c = c;
+    p.nwin = nwin;
+    p.kw = 1;
+    p.B = 1u << (c - 1);
+    p.nkeys = p.B;
+    size_t mean = (n * (size_t)nwin + p.B - 1) / p.B;
+    size_t T = 2 * mean;
+    if (T < 16) T = 16;
+    if (T > 512) T = 512;
+    p.T = (uint32_t)T;
+    return p;
+}
+bool msm_fbw_plan(size_t n, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out) {
+    double best_cost = 1e300;
+    int bc = 0, bw = 0;
+    for (int c = 4; c <= 23; c++) {
+        int nwin = (255 + c - 1) / c;
+        if (nwin > MAXWIN) continue;
+        if ((double)n * nwin >= 2.0e9) continue;                       // value = w * n + i must fit 31 bits
+        if ((double)n * nwin * (double)elem_bytes > (double)max_bytes) continue;
+        double cost = (double)n * nwin + 4.8 * (double)(1u << (c - 1)) + 3000.0 * ((c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
+        if (cost < best_cost) {
+            best_cost = cost;
+            bc = c;
+            bw = nwin;
+        }
+    }
+    if (!bc) return false;
+    *c_out = bc;
+    *nwin_out = bw;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,11 +201,12 @@ __device__ __forceinline__ bool scalar_is_one(const Scalar256& s) {
 // MODE 1: tile_tab holds the exclusive scan of that table; pairs are written to A[pos] = {val, low bits}
 template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
-                                              size_t n, int c, int nwin, int hb, int lb, uint32_t ntiles,
-                                              uint32_t* __restrict__ tile_tab, uint2* __restrict__ A,
+                                              size_t n, int c, int nwin, int kw, uint32_t vstride, int hb, int lb,
+                                              uint32_t ntiles, uint32_t* __restrict__ tile_tab, uint2* __restrict__ A,
                                               uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_bins[];
-    const uint32_t nbins = ((uint32_t)nwin << hb) + 1u;  // last bin: scalars == 1
+    const uint32_t nbins = ((uint32_t)kw << hb) + 1u;  // last bin: scalars == 1
+    const uint32_t wsel = kw == 1 ? 0u : ~0u;            // folded windows (fbw table): the window goes into the value
     const uint32_t tile = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x)
         lds_bins[b] = MODE == 0 ? 0u : tile_tab[(size_t)b * ntiles + tile];
@@ -186,8 +228,9 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
             int32_t d = next_digit(s, c, carry);
             if (d == 0) continue;
             const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1u;
-            uint32_t pos = atomicAdd(&lds_bins[((uint32_t)w << hb) | (mag >> lb)], 1u);
-            if (MODE == 1) A[pos] = make_uint2((uint32_t)i | (d < 0 ? 0x80000000u : 0u), mag & lomask);
+            uint32_t pos = atomicAdd(&lds_bins[(((uint32_t)w & wsel) << hb) | (mag >> lb)], 1u);
+            if (MODE == 1)
+                A[pos] = make_uint2(((uint32_t)i + (uint32_t)w * vstride) | (d < 0 ? 0x80000000u : 0u), mag & lomask);
         }
     }
     if (MODE == 0) {
@@ -411,11 +454,11 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ item_off,
-                                                    const uint32_t* __restrict__ item_key, uint32_t total_items,
+                                                    const uint32_t* __restrict__ item_key, uint32_t nkeys,
                                                     uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
     using L = typename LazyOf<F>::L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_items) return;
+    if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
     uint32_t key = item_key[t];
     uint32_t Tk = key == ones_key ? T_ONES : T;
     uint32_t seg = t - item_off[key];
@@ -549,6 +592,12 @@ struct MsmJob : MsmJobBase {
     size_t n;
     XYZZ<F>* out;
     bool dense = false;   // plan from n directly, no k_classify round trip
+    const Affine<F>* fbw_table = nullptr;   // fixed-base window table: [fbw_nwin][fbw_stride] affine points
+    int fbw_c = 0, fbw_nwin = 0;
+    size_t fbw_stride = 0;
+    uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
+    bool chained = false;          // phase_c was queued by phase_b
+    int acc_prof = -1;
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
     int grid = 1;
@@ -591,16 +640,17 @@ struct MsmJob : MsmJobBase {
             done = true;
             return ZG_OK;
         }
-        P = plan_msm(n_real, n_ones);
-        ones_key = P.nkeys;  // one extra bucket after the nwin * B regular ones
+        P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : plan_msm(n_real, n_ones);
+        ones_key = P.nkeys;  // one extra bucket after the kw * B regular ones
         nkeys = P.nkeys + 1;
         // bucket bits split into high (level-1 bins) and low (level-2, in LDS) parts
         const int bbits = P.c - 1;
         int hb = (bbits + 1) / 2;
         if (hb > 8) hb = 8;
-        while (hb > 0 && (((size_t)P.nwin << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
+        if (P.kw == 1 && bbits > 12) hb = std::min(bbits - 7, 12);   // folded windows: keep about 4096 level-1 bins
+        while (hb > 0 && (((size_t)P.kw << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
         const int lb = bbits - hb;
-        const uint32_t nbins = ((uint32_t)P.nwin << hb) + 1u;
+        const uint32_t nbins = ((uint32_t)P.kw << hb) + 1u;
         const uint32_t ntiles = (uint32_t)((n + PART_TP - 1) / PART_TP);
         const size_t tab_n = (size_t)nbins * ntiles;
         const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
@@ -614,8 +664,9 @@ struct MsmJob : MsmJobBase {
         ZG_HIP(ctx, S.sorted.reserve(max_entries * 4));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
-        hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
-                           ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
+        const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
+        hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
+                           hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -626,8 +677,8 @@ struct MsmJob : MsmJobBase {
             hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
                                S.bsum.as<uint32_t>());
         }
-        hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, hb, lb,
-                           ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
+        hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
+                           hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
@@ -645,14 +696,21 @@ struct MsmJob : MsmJobBase {
                            S.meta.as<uint32_t>());
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
+        if (dense) {   // no ones bucket and a known bound on the item count: queue the rest without the read-back
+            items_bound = (uint32_t)std::min<size_t>(max_entries / P.T + nkeys, 0xffffffffu);
+            chained = true;
+            return phase_c();
+        }
         return ZG_OK;
     }
 
     int phase_c() override {
         if (done) return ZG_OK;
+        if (chained && !items_bound) return ZG_OK;   // already queued by phase_b
         const uint32_t* meta = reinterpret_cast<const uint32_t*>(S.host);
-        const uint32_t total_items = meta[1];
-        const uint32_t ones_lo = meta[2], ones_hi = meta[3];
+        const uint32_t total_items = items_bound ? items_bound : meta[1];
+        const uint32_t ones_lo = items_bound ? 0 : meta[2], ones_hi = items_bound ? 0 : meta[3];
+        items_bound = 0;
         if (total_items == 0) {
             done = true;
             return ZG_OK;
@@ -668,10 +726,13 @@ struct MsmJob : MsmJobBase {
                                               ones_hi - ones_lo, st));
         }
         {
-            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st, meta[0]);  // units: mixed adds
-            hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, d_bases,
+            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
+                         chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
+            acc_prof = ps.idx;
+            hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
+                               fbw_table ? fbw_table : d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.item_key.as<uint32_t>(), total_items, P.T, ones_key, S.partial.as<XYZZ<F>>());
+                               S.item_key.as<uint32_t>(), nkeys, P.T, ones_key, S.partial.as<XYZZ<F>>());
         }
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
         // ---- bucket tree over the regular keys: fan-in 2^TREE_LAMBDA per level until one node per window remains
@@ -706,7 +767,7 @@ struct MsmJob : MsmJobBase {
             sbits += f;
             bits -= f;
         }
-        // n_nodes == nwin now; curW[w] = sum_b (b+1) * bucket_{w,b}
+        // n_nodes == kw now; curW[w] = sum_b (b+1) * bucket_{w,b}
         // ---- ones bucket: fan-in-16 passes over its partial sums
         ones_ptr = nullptr;
         if (ones_hi > ones_lo) {
@@ -724,24 +785,26 @@ struct MsmJob : MsmJobBase {
             }
             ones_ptr = in;
         }
-        static_assert((MAXWIN + 1) * sizeof(XYZZ<F>) <= MsmScratch::HOST_BYTES, "pinned buffer too small");
-        XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host);
-        ZG_HIP(ctx, hipMemcpyAsync(hw, curW, (size_t)P.nwin * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.nwin, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        static_assert((MAXWIN + 1) * sizeof(XYZZ<F>) + 64 <= MsmScratch::HOST_BYTES, "pinned buffer too small");
+        XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host + 64);   // the first 64 bytes keep the meta words
+        ZG_HIP(ctx, hipMemcpyAsync(hw, curW, (size_t)P.kw * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
 
     int finish() override {
         if (done) return ZG_OK;
-        const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(S.host);
+        const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(S.host + 64);
+        if (chained && acc_prof >= 0 && acc_prof < (int)ctx->prof_pending.size())
+            ctx->prof_pending[acc_prof].units = reinterpret_cast<const uint32_t*>(S.host)[0];
         XYZZ<F> acc = XYZZ<F>::inf();
         // the device works in the 2^261 Montgomery domain; window sums come back reduce()d in that form
-        for (int w = P.nwin - 1; w >= 0; w--) {
+        for (int w = P.kw - 1; w >= 0; w--) {
             for (int k = 0; k < P.c; k++) acc = acc.dbl();
             if (!hw[w].is_inf()) acc = acc.add(m261_to_host(hw[w]));
         }
-        if (ones_ptr && !hw[P.nwin].is_inf()) acc = acc.add(m261_to_host(hw[P.nwin]));
+        if (ones_ptr && !hw[P.kw].is_inf()) acc = acc.add(m261_to_host(hw[P.kw]));
         *out = acc;
         done = true;
         return ZG_OK;
@@ -821,12 +884,42 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
     MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
     j0.dense = g1[0].dense;
+    if (g1[0].fbw_table) {
+        j0.fbw_table = (const G1Affine*)g1[0].fbw_table;
+        j0.fbw_c = g1[0].fbw_c;
+        j0.fbw_nwin = g1[0].fbw_nwin;
+        j0.fbw_stride = g1[0].fbw_stride;
+    }
     MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
     MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
     MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
     // the G2 job has the longest chain: first; h (gated on the NTT) last
     MsmJobBase* jobs[5] = {&j2, &j1, &j3, &j4, &j0};
     return run_jobs(ctx, jobs, 5);
+}
+
+// table[w * stride + i] = 2^(c*w) * bases[i], affine, w = 0 .. nwin-1 (row 0 is a copy of the bases)
+__global__ void __launch_bounds__(256) k_fbw_build(const G1Affine* __restrict__ bases, size_t n, size_t stride, int c,
+                                                   int nwin, G1Affine* __restrict__ table) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine cur = bases[i];
+    table[i] = cur;
+    for (int w = 1; w < nwin; w++) {
+        AffD<FqL> a = AffD<FqL>::load(&cur);
+        G1L p = G1L::dbl_affine(a);
+        for (int k = 1; k < c; k++) p = p.dbl();
+        p.to_affine_mem(&cur);
+        table[(size_t)w * stride + i] = cur;
+    }
+}
+
+int msm_fbw_build(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL(k_fbw_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride, c, nwin,
+                       d_table);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
 }
 
 void msm_scratch_free(Ctx* ctx) {

@@ -685,6 +685,43 @@ extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void*
     return prove_h_enqueue(ctx, r, d_witness, d_h_out);
 }
 
+// Fixed-base window table for this rank's part of the h query (n points), built once per key: every proof
+// with the key re-uses it.  Budget: ZA_AMD_FBW_MAX_GB (default: 60% of the free HBM); ZA_AMD_FBW=0 turns it off.
+static int ensure_h_table(Ctx* ctx, const zg_params* p, uint64_t n) {
+    if (p->fbw_state == 1 && p->fbw_n == n) return ZG_OK;
+    if (p->fbw_state == -1) return ZG_OK;
+    p->fbw.release();
+    p->fbw_state = -1;
+    const char* off = getenv("ZA_AMD_FBW");
+    if ((off && off[0] == '0') || n < 64) return ZG_OK;
+    size_t free_b = 0, total_b = 0;
+    ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)((double)free_b * 0.6);
+    if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
+    int c = 0, nwin = 0;
+    if (!msm_fbw_plan(n, budget, sizeof(G1Affine), &c, &nwin)) return ZG_OK;
+    if (p->fbw.alloc((size_t)nwin * n * sizeof(G1Affine)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZG_OK;   // no room: the plain per-window schedule is used
+    }
+    ZG_TRY(msm_fbw_build(ctx, p->q[0].buf.as<G1Affine>(), n, n, c, nwin, p->fbw.as<G1Affine>()));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->fbw_c = c;
+    p->fbw_nwin = nwin;
+    p->fbw_n = n;
+    p->fbw_state = 1;
+    return ZG_OK;
+}
+
+extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) {
+    if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t m = (uint64_t)1 << r->log_m;
+    const auto& q = p->q[0];
+    uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
+    return ensure_h_table(ctx, p, hi > q.lo ? hi - q.lo : 0);
+}
+
 extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
                                     const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
@@ -704,6 +741,13 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
         if (!(mask & 1u)) n = 0;
         if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
         d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n, /*dense=*/true};
+        if (n) ZG_TRY(ensure_h_table(ctx, p, n));
+        if (n && p->fbw_state == 1 && p->fbw_n == n) {
+            d1[0].fbw_table = p->fbw.p;
+            d1[0].fbw_c = p->fbw_c;
+            d1[0].fbw_nwin = p->fbw_nwin;
+            d1[0].fbw_stride = (size_t)n;
+        }
     }
     {   // l: aux assignment, full density
         const auto& q = p->q[1];
