@@ -9,6 +9,7 @@ struct zg_r1cs {
     uint64_t n_constraints = 0;
     uint32_t log_m = 0;
     zg::DevBuf row_ptr[3], col[3], coeff[3];
+    zg::DevBuf ccls[3];   // per-term coefficient class (prover.hip k_coeff_prepare)
     // dense position -> flat variable index for the a and b queries
     zg::DevBuf a_index, b_index;
     uint64_t n_a = 0, n_b = 0;

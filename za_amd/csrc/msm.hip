@@ -7,19 +7,17 @@
 // GPU schedule (all kernels on ctx->stream):
 //   0. k_classify   counts scalars equal to 0, equal to 1, and the rest; the window size c is planned
 //                   from the number of "real" scalars (a 97%-bit witness needs far fewer buckets)
-//   1. k_digits<0>  signed c-bit digits of every scalar -> per-bucket counts (global atomics, the lanes
-//                   sharing the wave's leading key are aggregated); scalars == 1 go to one extra
-//                   "ones" bucket, as bellman special-cases them
+//   1. k_part<0/1>, k_part_local   signed c-bit digits of every scalar, sorted by bucket with a two-level LDS
+//                   partition (no global atomics); scalars == 1 go to one extra "ones" bucket, as bellman
+//                   special-cases them.  With a fixed-base window table (plan_fbw_for) all digit positions of a
+//                   scalar share ONE bucket set and the position selects the table row.
 //   2. scans        exclusive prefix sums: bucket offsets and "item" offsets (an item = up to T points
 //                   of one bucket, so work per thread is bounded for any scalar distribution)
-//   3. k_digits<1>  counting-sort scatter of (base index | sign) into bucket order
 //   4. k_accumulate one thread per item: gather affine bases (dwordx4 loads), XYZZ mixed adds   [dominant]
-//   5. k_tree_leaf / k_tree_level   hierarchical bucket reduction over FIXED bucket ranges:
-//                   a node over L children of span s has  R = sum R_t,  W = sum W_t + s * sum t R_t,
-//                   with sum t R_t from the running-sum trick; the root's W is  sum_b (b+1) bucket_b.
-//                   No scalar multiplications, log_L(2^(c-1)) short launches.
-//   6. k_sum_array  fan-in-16 passes over the partial sums of the "ones" bucket
-//   7. host: Horner over <= 128 window sums (c doublings each) + the ones sum.
+//   5. k_bits_level / k_rowsum   bucket reduction by bit planes: per window S = sum of buckets and
+//                   T_j = sum of the buckets with index bit j set; plain sums only, four adds per thread and level
+//   6. k_rowsum     also sums the partial sums of the "ones" bucket
+//   7. host: one Horner pass over the 254 bit positions (window value = S + sum_j 2^j T_j) + the ones sum.
 // Bases live in HBM in the device field's M261 form (fd.h); field work uses the lazy 9x29-limb arithmetic.
 // Algorithmic HBM bytes: 64 B base + 32 B scalar per point (G1), 128 + 32 (G2).  The kernel is
 // integer-ALU bound (about 10 field multiplications per point per window), not HBM bound.
@@ -39,8 +37,8 @@ static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, node[4], ones[2], bsum, meta, heavy;
-    static constexpr size_t HOST_BYTES = 64 * 1024;
+    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, lvl[2], dbuf[2], ones[2], bsum, meta, heavy;
+    static constexpr size_t HOST_BYTES = 256 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
 
@@ -93,6 +91,7 @@ static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
     p.nkeys = p.B;
     size_t mean = (n * (size_t)nwin + p.B - 1) / p.B;
     size_t T = 2 * mean;
+    if (const char* e = getenv("ZG_X_FBW_T")) T = atoi(e);   // EXPERIMENT
     if (T < 16) T = 16;
     if (T > 512) T = 512;
     p.T = (uint32_t)T;
@@ -113,6 +112,7 @@ bool msm_fbw_plan(size_t n, size_t max_bytes, size_t elem_bytes, int* c_out, int
             bw = nwin;
         }
     }
+    if (const char* e = getenv("ZG_X_FBW_C")) { bc = atoi(e); bw = (255 + bc - 1) / bc; }   // EXPERIMENT
     if (!bc) return false;
     *c_out = bc;
     *nwin_out = bw;
@@ -513,59 +513,99 @@ __global__ void __launch_bounds__(128) k_heavy_fold(XYZZ<F>* __restrict__ partia
     }
 }
 
-// Leaf level: node g covers buckets [g << fbits, (g+1) << fbits).  Bucket b of the node has weight t+1
-// (t = b - first bucket):  R = sum bucket_t,  W = sum (t+1) bucket_t  via the running sum.
-template <class F>
-__global__ void __launch_bounds__(128) k_tree_leaf(const XYZZ<F>* __restrict__ partial,
-                                                   const uint32_t* __restrict__ item_off, uint32_t n_nodes, int fbits,
-                                                   XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
-    using L = typename LazyOf<F>::L;
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_nodes) return;
-    const uint32_t first = g << fbits;
-    XYZZd<L> run = XYZZd<L>::inf(), acc = XYZZd<L>::inf();
-    for (int t = (1 << fbits) - 1; t >= 0; t--) {
-        uint32_t lo = item_off[first + t], hi = item_off[first + t + 1];
-        if (hi - lo > HEAVY_ITEMS) hi = lo + 1;   // folded into partial[lo] by k_heavy_fold
-        for (uint32_t i = lo; i < hi; i++) run = run.add(XYZZd<L>::load(&partial[i]));
-        acc = acc.add(run);
-    }
-    run.store(&outR[g]);
-    acc.store(&outW[g]);
+// Bucket reduction by bit planes.  A window's sum  sum_b (b+1) bucket_b  equals  S + sum_j 2^j T_j  with
+// S = sum of all buckets and T_j = sum of the buckets whose index has bit j set: only plain sums, no doublings
+// and no long dependent chains on the device (the 2^j weights are applied by the host's final Horner pass).
+// Level l folds groups of 2^f consecutive entries (f = 2, or 1 for a last odd bit): the group sums feed the next
+// level and are what S ends up as; per group and per bit j < f it emits D_j = sum of the entries with bit j set,
+// and k_rowsum adds the D rows up.  Four adds per thread and level instead of a 24-add running-sum chain.
+struct RowMeta {
+    int nlev;
+    uint32_t d_off[16], len[16], rows[16], chunks[16], block_base[16];
+};
+static constexpr uint32_t ROWSUM_CH = 1024;   // entries per k_rowsum block
+
+// one bucket's sum from its items (heavy buckets were folded into their first item)
+template <class L, class F>
+__device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
+                                               uint32_t key) {
+    uint32_t lo = item_off[key], hi = item_off[key + 1];
+    if (hi - lo > HEAVY_ITEMS) hi = lo + 1;
+    XYZZd<L> r = XYZZd<L>::inf();
+    for (uint32_t i = lo; i < hi; i++) r = r.add(XYZZd<L>::load(&partial[i]));
+    return r;
 }
-// Inner level: children [k << fbits, (k+1) << fbits) each spanning 2^sbits buckets.
-//   R = sum R_t,   W = sum W_t + 2^sbits * sum t R_t,   sum t R_t = (sum (t+1) R_t) - R.
+
+// in == nullptr: leaf level, children are buckets.  n_out = number of groups over all windows; len = groups per window.
 template <class F>
-__global__ void __launch_bounds__(128) k_tree_level(const XYZZ<F>* __restrict__ inR, const XYZZ<F>* __restrict__ inW,
-                                                    uint32_t n_nodes, int fbits, int sbits,
-                                                    XYZZ<F>* __restrict__ outR, XYZZ<F>* __restrict__ outW) {
+__global__ void __launch_bounds__(128) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
+                                                    const uint32_t* __restrict__ item_off, uint32_t n_out, uint32_t len,
+                                                    int f, XYZZ<F>* __restrict__ outS, XYZZ<F>* __restrict__ outD) {
     using L = typename LazyOf<F>::L;
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_nodes) return;
-    const uint32_t first = k << fbits;
-    XYZZd<L> run = XYZZd<L>::inf(), acc = XYZZd<L>::inf(), sw = XYZZd<L>::inf();
-    for (int t = (1 << fbits) - 1; t >= 0; t--) {
-        run = run.add(XYZZd<L>::load(&inR[first + t]));
-        acc = acc.add(run);
-        sw = sw.add(XYZZd<L>::load(&inW[first + t]));
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_out) return;
+    const uint32_t w = g / len, idx = g - w * len;
+    const uint32_t first = g << f;
+    XYZZd<L> c0, c1;
+    if (in) {
+        c0 = XYZZd<L>::load(&in[first]);
+        c1 = XYZZd<L>::load(&in[first + 1]);
+    } else {
+        c0 = bucket_sum<L, F>(partial, item_off, first);
+        c1 = bucket_sum<L, F>(partial, item_off, first + 1);
     }
-    XYZZd<L> tr = acc.add(run.neg());
-    for (int d = 0; d < sbits; d++) tr = tr.dbl();
-    run.store(&outR[k]);
-    sw.add(tr).store(&outW[k]);
+    if (f == 1) {
+        c0.add(c1).store(&outS[g]);
+        c1.store(&outD[(size_t)w * len + idx]);
+        return;
+    }
+    XYZZd<L> c2, c3;
+    if (in) {
+        c2 = XYZZd<L>::load(&in[first + 2]);
+        c3 = XYZZd<L>::load(&in[first + 3]);
+    } else {
+        c2 = bucket_sum<L, F>(partial, item_off, first + 2);
+        c3 = bucket_sum<L, F>(partial, item_off, first + 3);
+    }
+    c1.add(c3).store(&outD[((size_t)w * 2) * len + idx]);        // bit 0
+    XYZZd<L> p1 = c2.add(c3);
+    p1.store(&outD[((size_t)w * 2 + 1) * len + idx]);             // bit 1
+    c0.add(c1).add(p1).store(&outS[g]);
 }
-// out[i] = in[16 i] + ... + in[16 i + 15]
+
+// One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
+// (RowMeta).  Output: one entry per block, in block order -- again rows of `chunks` entries, so the kernel is
+// applied until every row has length 1.
 template <class F>
-__global__ void __launch_bounds__(128) k_sum_array(const XYZZ<F>* __restrict__ in, uint32_t n_in,
-                                                   XYZZ<F>* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_rowsum(const XYZZ<F>* __restrict__ in, RowMeta M, XYZZ<F>* __restrict__ out) {
     using L = typename LazyOf<F>::L;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t lo = i * 16;
-    if (lo >= n_in) return;
-    uint32_t hi = lo + 16 < n_in ? lo + 16 : n_in;
-    XYZZd<L> acc = XYZZd<L>::load(&in[lo]);
-    for (uint32_t j = lo + 1; j < hi; j++) acc = acc.add(XYZZd<L>::load(&in[j]));
-    acc.store(&out[i]);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_r);
+    int lv = 0;
+    while (lv + 1 < M.nlev && blockIdx.x >= M.block_base[lv + 1]) lv++;
+    const uint32_t local = blockIdx.x - M.block_base[lv];
+    const uint32_t row = local / M.chunks[lv], chunk = local - row * M.chunks[lv];
+    const uint32_t len = M.len[lv];
+    const size_t base = (size_t)M.d_off[lv] + (size_t)row * len;
+    const uint32_t lo = chunk * ROWSUM_CH, hi = lo + ROWSUM_CH < len ? lo + ROWSUM_CH : len;
+    XYZZd<L> acc = XYZZd<L>::inf();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = acc.add(XYZZd<L>::load(&in[base + i]));
+    uint32_t active = hi - lo < blockDim.x ? hi - lo : blockDim.x;   // threads holding a term
+    if (active > 1) {
+        acc.store(&lds[threadIdx.x]);
+        __syncthreads();
+        uint32_t span = 1;
+        while (span < active) span <<= 1;
+        for (uint32_t st = span >> 1; st > 0; st >>= 1) {
+            if (threadIdx.x < st && threadIdx.x + st < active) {
+                acc = acc.add(XYZZd<L>::load(&lds[threadIdx.x + st]));
+                acc.store(&lds[threadIdx.x]);
+            }
+            __syncthreads();
+            if (active > st) active = st;
+        }
+    }
+    if (threadIdx.x == 0) acc.store(&out[blockIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -601,8 +641,9 @@ struct MsmJob : MsmJobBase {
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
     int grid = 1;
-    XYZZ<F>* curW = nullptr;
     const XYZZ<F>* ones_ptr = nullptr;
+    int red_nlev = 0, red_f[16], red_bitbase[16];   // bit-plane reduction levels (bits folded per level)
+    uint32_t red_rowbase[16];
     static constexpr bool IS_G1 = sizeof(F) == sizeof(Fq);
     static constexpr uint64_t ALG_BYTES = sizeof(Affine<F>) + 32;  // base + scalar, each read once
 
@@ -735,15 +776,7 @@ struct MsmJob : MsmJobBase {
                                S.item_key.as<uint32_t>(), nkeys, P.T, ones_key, S.partial.as<XYZZ<F>>());
         }
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
-        // ---- bucket tree over the regular keys: fan-in 2^TREE_LAMBDA per level until one node per window remains
-        int bits = P.c - 1;
-        int f1 = std::min(bits, TREE_LAMBDA);
-        uint32_t n_nodes = P.nkeys >> f1;
-        for (int k = 0; k < 4; k++) ZG_HIP(ctx, S.node[k].reserve((size_t)n_nodes * sizeof(XYZZ<F>)));
-        XYZZ<F>* curR = S.node[0].template as<XYZZ<F>>();
-        curW = S.node[1].template as<XYZZ<F>>();
-        XYZZ<F>* nxtR = S.node[2].template as<XYZZ<F>>();
-        XYZZ<F>* nxtW = S.node[3].template as<XYZZ<F>>();
+        // ---- bit-plane reduction over the regular keys (see k_bits_level)
         {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
             ZG_HIP(ctx, S.heavy.reserve(((size_t)P.nkeys + 1) * 4));
             uint32_t* hcnt = S.heavy.as<uint32_t>();
@@ -753,42 +786,106 @@ struct MsmJob : MsmJobBase {
             hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
                                S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hcnt + 1);
         }
-        hipLaunchKernelGGL((k_tree_leaf<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, S.partial.as<XYZZ<F>>(),
-                           S.item_off.as<uint32_t>(), n_nodes, f1, curR, curW);
-        int sbits = f1;
-        bits -= f1;
-        while (bits > 0) {
-            int f = std::min(bits, TREE_LAMBDA);
-            n_nodes >>= f;
-            hipLaunchKernelGGL((k_tree_level<F>), dim3((n_nodes + 127) / 128), dim3(128), 0, st, curR, curW, n_nodes, f,
-                               sbits, nxtR, nxtW);
-            std::swap(curR, nxtR);
-            std::swap(curW, nxtW);
-            sbits += f;
-            bits -= f;
+        const int bits = P.c - 1;
+        red_nlev = 0;
+        for (int left = bits; left > 0;) {
+            red_f[red_nlev] = left >= 2 ? 2 : 1;
+            left -= red_f[red_nlev++];
         }
-        // n_nodes == kw now; curW[w] = sum_b (b+1) * bucket_{w,b}
-        // ---- ones bucket: fan-in-16 passes over its partial sums
+        RowMeta M{};
+        M.nlev = red_nlev;
+        size_t d_total = 0, blocks = 0;
+        {
+            uint32_t len = P.B;   // entries per window entering the level
+            for (int l = 0; l < red_nlev; l++) {
+                len >>= red_f[l];
+                M.d_off[l] = (uint32_t)d_total;
+                M.len[l] = len;
+                M.rows[l] = (uint32_t)P.kw * red_f[l];
+                M.chunks[l] = (len + ROWSUM_CH - 1) / ROWSUM_CH;
+                M.block_base[l] = (uint32_t)blocks;
+                d_total += (size_t)M.rows[l] * len;
+                blocks += (size_t)M.rows[l] * M.chunks[l];
+            }
+        }
+        ZG_HIP(ctx, S.dbuf[0].reserve(d_total * sizeof(XYZZ<F>)));
+        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve((size_t)(P.nkeys >> red_f[0]) * sizeof(XYZZ<F>)));
+        const XYZZ<F>* cur = nullptr;
+        {
+            uint32_t len = P.B;
+            for (int l = 0; l < red_nlev; l++) {
+                len >>= red_f[l];
+                const uint32_t n_out = (uint32_t)P.kw * len;
+                XYZZ<F>* outS = S.lvl[l & 1].template as<XYZZ<F>>();
+                hipLaunchKernelGGL((k_bits_level<F>), dim3((n_out + 127) / 128), dim3(128), 0, st, cur,
+                                   S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), n_out, len, red_f[l], outS,
+                                   S.dbuf[0].template as<XYZZ<F>>() + M.d_off[l]);
+                cur = outS;
+            }
+        }
+        // cur[w] = S_w.  Row sums of the D planes: repeat until every row is a single entry.
+        const XYZZ<F>* dcur = S.dbuf[0].template as<XYZZ<F>>();
+        int dpp = 1;
+        for (;;) {
+            bool more = false;
+            for (int l = 0; l < red_nlev; l++) more |= M.len[l] > 1;
+            if (!more) break;
+            ZG_HIP(ctx, S.dbuf[dpp].reserve(blocks * sizeof(XYZZ<F>)));
+            XYZZ<F>* dout = S.dbuf[dpp].template as<XYZZ<F>>();
+            hipLaunchKernelGGL((k_rowsum<F>), dim3((unsigned)blocks), dim3(256), 256 * sizeof(XYZZ<F>), st, dcur, M, dout);
+            size_t nb = 0;
+            for (int l = 0; l < red_nlev; l++) {
+                M.d_off[l] = M.block_base[l];
+                M.len[l] = M.chunks[l];
+                M.chunks[l] = (M.len[l] + ROWSUM_CH - 1) / ROWSUM_CH;
+                M.block_base[l] = (uint32_t)nb;
+                nb += (size_t)M.rows[l] * M.chunks[l];
+            }
+            blocks = nb;
+            dcur = dout;
+            dpp ^= 1;
+        }
+        // dcur: one entry per row, rows ordered [level][window][bit within level], starting at d_off[level]
+        // ---- ones bucket: its item sums form one row
         ones_ptr = nullptr;
         if (ones_hi > ones_lo) {
             uint32_t cnt = ones_hi - ones_lo;
             const XYZZ<F>* in = S.partial.as<XYZZ<F>>() + ones_lo;
             int pp = 0;
             while (cnt > 1) {
-                uint32_t nout = (cnt + 15) / 16;
-                ZG_HIP(ctx, S.ones[pp].reserve((size_t)nout * sizeof(XYZZ<F>)));
-                hipLaunchKernelGGL((k_sum_array<F>), dim3((nout + 127) / 128), dim3(128), 0, st, in, cnt,
+                RowMeta O{};
+                O.nlev = 1;
+                O.len[0] = cnt;
+                O.rows[0] = 1;
+                O.chunks[0] = (cnt + ROWSUM_CH - 1) / ROWSUM_CH;
+                ZG_HIP(ctx, S.ones[pp].reserve((size_t)O.chunks[0] * sizeof(XYZZ<F>)));
+                hipLaunchKernelGGL((k_rowsum<F>), dim3(O.chunks[0]), dim3(256), 256 * sizeof(XYZZ<F>), st, in, O,
                                    S.ones[pp].as<XYZZ<F>>());
                 in = S.ones[pp].template as<XYZZ<F>>();
-                cnt = nout;
+                cnt = O.chunks[0];
                 pp ^= 1;
             }
             ones_ptr = in;
         }
-        static_assert((MAXWIN + 1) * sizeof(XYZZ<F>) + 64 <= MsmScratch::HOST_BYTES, "pinned buffer too small");
+        // read-back layout: [kw] S, [kw * bits] T in (level, window, bit) order, [1] ones
+        const size_t n_t = (size_t)P.kw * bits;
+        if (((size_t)P.kw + n_t + 1) * sizeof(XYZZ<F>) + 64 > MsmScratch::HOST_BYTES)
+            return fail(ctx, ZG_E_INVALID_ARG, "msm: read-back of %zu window sums exceeds the pinned buffer", n_t);
         XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host + 64);   // the first 64 bytes keep the meta words
-        ZG_HIP(ctx, hipMemcpyAsync(hw, curW, (size_t)P.kw * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        ZG_HIP(ctx, hipMemcpyAsync(hw, cur, (size_t)P.kw * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        {   // after the last pass d_off[l] is the level's first row; the host copy keeps the level order
+            size_t rb = 0;
+            int bb = 0;
+            for (int l = 0; l < red_nlev; l++) {
+                red_rowbase[l] = (uint32_t)rb;
+                red_bitbase[l] = bb;
+                ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + rb, dcur + M.d_off[l], (size_t)M.rows[l] * sizeof(XYZZ<F>),
+                                           hipMemcpyDeviceToHost, st));
+                rb += M.rows[l];
+                bb += red_f[l];
+            }
+        }
+        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + n_t, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
@@ -800,11 +897,23 @@ struct MsmJob : MsmJobBase {
             ctx->prof_pending[acc_prof].units = reinterpret_cast<const uint32_t*>(S.host)[0];
         XYZZ<F> acc = XYZZ<F>::inf();
         // the device works in the 2^261 Montgomery domain; window sums come back reduce()d in that form
+        // window value = S_w + sum_j 2^j T_{w,j}; one Horner pass over all bit positions
+        const int bits = P.c - 1;
+        const XYZZ<F>* ht = hw + P.kw;
         for (int w = P.kw - 1; w >= 0; w--) {
-            for (int k = 0; k < P.c; k++) acc = acc.dbl();
+            for (int j = P.c - 1; j >= 0; j--) {
+                acc = acc.dbl();
+                if (j < bits) {
+                    int l = 0;
+                    while (l + 1 < red_nlev && red_bitbase[l + 1] <= j) l++;
+                    const XYZZ<F>& t = ht[red_rowbase[l] + (size_t)w * red_f[l] + (j - red_bitbase[l])];
+                    if (!t.is_inf()) acc = acc.add(m261_to_host(t));
+                }
+            }
             if (!hw[w].is_inf()) acc = acc.add(m261_to_host(hw[w]));
         }
-        if (ones_ptr && !hw[P.kw].is_inf()) acc = acc.add(m261_to_host(hw[P.kw]));
+        const XYZZ<F>& ho = hw[P.kw + (size_t)P.kw * bits];
+        if (ones_ptr && !ho.is_inf()) acc = acc.add(m261_to_host(ho));
         *out = acc;
         done = true;
         return ZG_OK;

@@ -40,9 +40,41 @@ static double now_ms() {
 // Device field values are M261 residues (x * 2^261, fd.h).
 // coefficient c (plain integer) -> c * 2^522 mod r, so that coeff * w_integer (one Montgomery
 // multiplication) is c*w in M261 form with no per-proof conversion of the witness
-__global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_t n) {
+// Also classifies the coefficient: cls 0 = generic, 1 + s = +2^s, 65 + s = -2^s (s < 64).  Circuits are dominated
+// by +-1 / +-2^k coefficients on bit signals; k_r1cs_eval_tiled sums those terms as plain integers.
+__device__ __forceinline__ uint32_t pow2_class(const uint32_t v[8]) {
+    if (v[2] | v[3] | v[4] | v[5] | v[6] | v[7]) return 0;
+    const uint64_t x = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    if (x == 0 || (x & (x - 1)) != 0) return 0;
+    return 1u + (uint32_t)__builtin_ctzll(x);
+}
+__global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_t n, uint8_t* __restrict__ cls) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) (FrD::to_mont(FrD::load_canon(&c[i])) * FrD::r2()).canonical().store(&c[i]);
+    if (i >= n) return;
+    const Fr v = c[i];
+    uint32_t k = pow2_class(v.l);
+    if (!k) {   // r - v
+        uint32_t d[8];
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t t = (uint64_t)FrParams::MOD[j] - v.l[j] - borrow;
+            d[j] = (uint32_t)t;
+            borrow = (t >> 32) & 1;
+        }
+        k = pow2_class(d);
+        if (k) k += 64;
+    }
+    cls[i] = (uint8_t)k;
+    (FrD::to_mont(FrD::load_canon(&c[i])) * FrD::r2()).canonical().store(&c[i]);
+}
+// witness classes: 0 = zero, 1 = one, 2 = anything else
+__global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ w, size_t n, uint8_t* __restrict__ cls) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr v = w[i];
+    const uint32_t hi = v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7];
+    cls[i] = (hi == 0 && v.l[0] <= 1) ? (uint8_t)v.l[0] : (uint8_t)2;
 }
 
 // out[row] = sum_e coeff[e] * w[col[e]]  for one CSR matrix; one thread per row
@@ -74,6 +106,76 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, uint64
     FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a[dst]);
 }
 
+struct ProveWs {
+    DevBuf abc[3], h, wcls;
+};
+static ProveWs& prove_ws(Ctx* ctx) {
+    if (!ctx->prove_ws) ctx->prove_ws = new ProveWs();
+    return *ctx->prove_ws;
+}
+
+// The prove path's evaluator: one thread per row of the 2^log_m padded domain (rows >= n_rows are written as
+// zero, so no memset), result stored at bitrev(row).  A block owns rows (a, mid, b) with a = top 4 bits, b = low 4
+// bits, and exchanges through LDS so that both the CSR reads (b fastest) and the bit-reversed stores (rev(a)
+// fastest) touch 512-byte runs instead of one 32-byte element per DRAM page.
+// Terms whose coefficient is +-2^s and whose witness value is 0 or 1 are summed in two 128-bit integers (no gather
+// of the 32-byte operands, no field multiplication); everything else takes the Montgomery path.
+__device__ __forceinline__ uint32_t rev4(uint32_t x) { return __brev(x) >> 28; }
+__global__ void __launch_bounds__(256) k_r1cs_eval_tiled(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                         const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
+                                                         const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
+                                                         uint64_t n_rows, Fr* __restrict__ out, int log_m) {
+    __shared__ Fr tile[256];
+    const uint32_t t = threadIdx.x, ta = t >> 4, tb = t & 15, mid = blockIdx.x;
+    const uint64_t row = ((uint64_t)ta << (log_m - 4)) | ((uint64_t)mid << 4) | tb;
+    FrD acc = FrD::zero();
+    if (row < n_rows) {
+        uint64_t pos_lo = 0, pos_hi = 0, neg_lo = 0, neg_hi = 0;
+        uint32_t since = 0;
+        for (uint64_t e = row_ptr[row], end = row_ptr[row + 1]; e < end; e++) {
+            const uint32_t c = col[e];
+            const uint32_t wc = wcls[c];
+            if (wc == 0) continue;
+            const uint32_t k = ccls[e];
+            if (wc == 1 && k != 0) {
+                const uint64_t bit = 1ull << ((k - 1) & 63);
+                if (k <= 64) {
+                    pos_lo += bit;
+                    pos_hi += pos_lo < bit;
+                } else {
+                    neg_lo += bit;
+                    neg_hi += neg_lo < bit;
+                }
+                continue;
+            }
+            acc = acc + FrD::load_canon(&coeff[e]) * FrD::load_canon(&w[c]);
+            if (++since == 64) {  // each term adds < 1.01 p to the lazy bound
+                acc = acc.reduce();
+                since = 0;
+            }
+        }
+        acc = acc.reduce();
+        if (pos_lo | pos_hi) {
+            Fr v = Fr::zero();
+            v.l[0] = (uint32_t)pos_lo; v.l[1] = (uint32_t)(pos_lo >> 32);
+            v.l[2] = (uint32_t)pos_hi; v.l[3] = (uint32_t)(pos_hi >> 32);
+            acc = acc + FrD::to_mont(FrD::load_canon(&v));
+        }
+        if (neg_lo | neg_hi) {
+            Fr v = Fr::zero();
+            v.l[0] = (uint32_t)neg_lo; v.l[1] = (uint32_t)(neg_lo >> 32);
+            v.l[2] = (uint32_t)neg_hi; v.l[3] = (uint32_t)(neg_hi >> 32);
+            acc = FrD::sub<2>(acc, FrD::to_mont(FrD::load_canon(&v)));
+        }
+    }
+    acc.reduce().store(&tile[t]);
+    __syncthreads();
+    const uint32_t src = (rev4(t & 15) << 4) | rev4(t >> 4);
+    const uint32_t rmid = log_m > 8 ? (__brev(mid) >> (32 - (log_m - 8))) : 0u;
+    const uint64_t dst = ((uint64_t)(t >> 4) << (log_m - 4)) | ((uint64_t)rmid << 4) | (t & 15);
+    out[dst] = tile[src];
+}
+
 int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d_coeff, const Fr* d_x, uint64_t n_rows,
              Fr* d_out) {
     if (n_rows == 0) return ZG_OK;
@@ -86,16 +188,6 @@ int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d
 }  // namespace zg
 
 using namespace zg;
-
-namespace zg {
-struct ProveWs {
-    DevBuf abc[3], h;
-};
-}  // namespace zg
-static ProveWs& prove_ws(zg_ctx* ctx) {
-    if (!ctx->prove_ws) ctx->prove_ws = new ProveWs();
-    return *ctx->prove_ws;
-}
 
 // ------------------------------------------------------------------------------------------------ ctx
 extern "C" int zg_init(int device, zg_ctx** out) {
@@ -444,8 +536,9 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
         if (nnz) {
             ZG_HIP(ctx, hipMemcpyAsync(r->col[k].p, col[k], nnz * 4, hipMemcpyHostToDevice, st));
             ZG_HIP(ctx, hipMemcpyAsync(r->coeff[k].p, coeff[k], nnz * 32, hipMemcpyHostToDevice, st));
+            ZG_HIP(ctx, r->ccls[k].alloc(nnz));
             hipLaunchKernelGGL(k_coeff_prepare, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
-                               r->coeff[k].as<Fr>(), (size_t)nnz);
+                               r->coeff[k].as<Fr>(), (size_t)nnz, r->ccls[k].as<uint8_t>());
         }
     }
     ZG_HIP(ctx, hipStreamSynchronize(st));
@@ -509,6 +602,21 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
     uint64_t nnz_total = 0;
     for (int k = 0; k < 3; k++) nnz_total += r->col[k].bytes / 4;
     ProfScope ps(ctx, PROF_R1CS_EVAL, 36 * nnz_total + 96 * (r->n_constraints + r->n_inputs));
+    if (bitrev && r->log_m >= 8 && r->n_constraints && !getenv("ZG_X_OLDEVAL")) {   // EXPERIMENT
+        ProveWs& ws = prove_ws(ctx);
+        const size_t nv = (size_t)r->n_inputs + r->n_aux;
+        ZG_HIP(ctx, ws.wcls.reserve(nv));
+        hipLaunchKernelGGL(k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_w, nv,
+                           ws.wcls.as<uint8_t>());
+        for (int k = 0; k < 3; k++)
+            hipLaunchKernelGGL(k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
+                               r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
+                               ws.wcls.as<uint8_t>(), r->n_constraints, d_abc[k], (int)r->log_m);
+        hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
+                           r->n_constraints, d_abc[0], rev_bits);
+        ZG_HIP(ctx, hipGetLastError());
+        return ZG_OK;
+    }
     for (int k = 0; k < 3; k++) {
         if (bitrev || r->n_constraints == 0)
             ZG_HIP(ctx, hipMemsetAsync(d_abc[k], 0, m * sizeof(Fr), st));   // padding is scattered
