@@ -209,13 +209,16 @@ int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partia
 int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi);
 /* Full (unsharded) length of query `which`. */
 int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
-/* Optional, once per (key, circuit): builds the fixed-base window table of the h query now instead of inside the
- * first zg_prove* call with this key (bellman has no equivalent: its multiexp takes the bases as they are,
- * prover.rs:173).  The table holds 2^(c*w) * h_i for every digit position w, so the h multiexp needs one bucket
- * set instead of one per window; it costs nwin (about 13 at 2^22) times the h query's HBM footprint.  Environment:
- * ZA_AMD_FBW=0 disables it, ZA_AMD_FBW_MAX_GB caps its size (default 60% of the free HBM); without room the plain
- * per-window schedule is used.  Results are identical either way. */
-int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs);
+/* Optional, once per (key, circuit): builds the fixed-base window tables now instead of inside the first
+ * zg_prove* call with this key (bellman has no equivalent: its multiexp takes the bases as they are,
+ * prover.rs:173).  A table holds 2^(c*w) * P_i for every digit position w, so a multiexp needs one bucket set
+ * instead of one per window; it costs nwin (about 13 at 2^22) times the query's HBM footprint.  d_witness (device,
+ * as for zg_prove_dev) sizes the l / a / b tables from its share of 0/1 values; NULL builds the h table only.
+ * Call it before sharing `params` between host threads.  Environment: ZA_AMD_FBW=0 disables the tables (any
+ * other value is a bit mask of the queries that may have one: 1 h, 2 l, 4 a, 8 b_g1, 16 b_g2),
+ * ZA_AMD_FBW_MAX_GB caps them (default 60% of the free HBM); without room the plain per-window schedule is used.
+ * Results are identical either way. */
+int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness);
 
 /* ---- verify (host CPU) ---------------------------------------------------------
  * zg_verify replaces bellman_ce::groth16::{prepare_verifying_key, verify_proof} (prover/src/groth16/prover.rs:191-200,

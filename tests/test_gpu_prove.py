@@ -417,8 +417,10 @@ def test_fixed_base_window_table_gives_the_same_proof_as_the_plain_schedule(ctx,
     m = 1 << lg
     sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
     P_tab = synth.synth_params(ctx, *sizes, 31)
-    P_tab.prepare(R)
-    with_table = ctx.prove(P_tab, R, sr.witness, 5, 6)
+    d_w = ctx.upload(sr.witness)
+    P_tab.prepare(R, d_w)          # h, l, a, b_g1 and b_g2 tables, sized from this witness
+    with_table = ctx.prove_dev(P_tab, R, d_w, 5, 6)
+    ctx.free(d_w)
     monkeypatch.setenv("ZA_AMD_FBW", "0")
     P_plain = synth.synth_params(ctx, *sizes, 31)
     plain = ctx.prove(P_plain, R, sr.witness, 5, 6)

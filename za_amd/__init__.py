@@ -364,9 +364,10 @@ class Params:
     def total_h(self):
         return self.query_total(0)
 
-    def prepare(self, r1cs):
-        """Build the h query's fixed-base window table now (otherwise the first prove with this key does it)."""
-        self.ctx._check(self.ctx.lib.zg_params_prepare(self.ctx.h, self.h, r1cs.h))
+    def prepare(self, r1cs, d_witness=None):
+        """Build the fixed-base window tables now (otherwise the first prove with this key does it); without a
+        device witness only the h query's table."""
+        self.ctx._check(self.ctx.lib.zg_params_prepare(self.ctx.h, self.h, r1cs.h, C.c_void_p(d_witness)))
 
     def close(self):
         if self.h:

@@ -110,13 +110,16 @@ struct MsmDesc {
     const uint32_t* index;
     size_t n;
     bool dense = false;   // scalars known to be essentially all "real" (H coefficients): skip the classification pass
-    // optional fixed-base window table for a dense job: [fbw_nwin][fbw_stride] affine points, row w = 2^(fbw_c*w) * bases
+    // optional fixed-base window table: [fbw_nwin][fbw_stride] affine points, row w = 2^(fbw_c*w) * bases
     const void* fbw_table = nullptr;
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
 };
-bool msm_fbw_plan(size_t n, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out);
-int msm_fbw_build(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table);
+bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out);
+int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table);
+int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table);
+int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,
+                        uint64_t* ones);
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
                hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr);

@@ -1,5 +1,7 @@
 // Opaque handle layouts behind include/za_amd.h (shared by prover.hip and synth.hip).
 #pragma once
+#include <mutex>
+
 #include "common.h"
 
 struct zg_ctx : public zg::Ctx {};
@@ -25,10 +27,14 @@ struct zg_params {
         uint64_t total = 0, lo = 0, hi = 0;
     } q[5];  // h, l, a, b_g1, b_g2
     int rank = 0, world = 1;
-    // fixed-base window table of the h query (msm.hip), built on first use for the first `fbw_n` points
-    mutable zg::DevBuf fbw;
-    mutable int fbw_c = 0, fbw_nwin = 0;
-    mutable uint64_t fbw_n = 0;
-    mutable int fbw_state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit
+    // fixed-base window tables (msm.hip), one per query, built on first use / by zg_params_prepare
+    struct Fbw {
+        zg::DevBuf buf;
+        int c = 0, nwin = 0;
+        uint64_t n = 0;
+        int state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit / does not pay
+    };
+    mutable Fbw fbw[5];
+    mutable std::mutex fbw_mu;
 };
 

@@ -97,23 +97,28 @@ static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
     p.T = (uint32_t)T;
     return p;
 }
-bool msm_fbw_plan(size_t n, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out) {
+// n_real scalars (neither 0 nor 1) out of n_table points.  Returns false when no table fits the budget or when
+// it would not beat the plain per-window plan by at least 8%.
+bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out) {
     double best_cost = 1e300;
     int bc = 0, bw = 0;
     for (int c = 4; c <= 23; c++) {
         int nwin = (255 + c - 1) / c;
         if (nwin > MAXWIN) continue;
-        if ((double)n * nwin >= 2.0e9) continue;                       // value = w * n + i must fit 31 bits
-        if ((double)n * nwin * (double)elem_bytes > (double)max_bytes) continue;
-        double cost = (double)n * nwin + 4.8 * (double)(1u << (c - 1)) + 3000.0 * ((c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
+        if ((double)n_table * nwin >= 2.0e9) continue;                 // value = w * n + i must fit 31 bits
+        if ((double)n_table * nwin * (double)elem_bytes > (double)max_bytes) continue;
+        double cost = (double)n_real * nwin + 4.8 * (double)(1u << (c - 1)) + 3000.0 * ((c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
         if (cost < best_cost) {
             best_cost = cost;
             bc = c;
             bw = nwin;
         }
     }
-    if (const char* e = getenv("ZG_X_FBW_C")) { bc = atoi(e); bw = (255 + bc - 1) / bc; }   // EXPERIMENT
     if (!bc) return false;
+    const MsmPlan plain = plan_msm(n_real, 0);
+    const double plain_cost = (double)n_real * plain.nwin + 4.8 * plain.nwin * (double)plain.B +
+                              3000.0 * ((plain.c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
+    if (best_cost > 0.92 * plain_cost) return false;
     *c_out = bc;
     *nwin_out = bw;
     return true;
@@ -993,41 +998,78 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
     MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
     j0.dense = g1[0].dense;
-    if (g1[0].fbw_table) {
-        j0.fbw_table = (const G1Affine*)g1[0].fbw_table;
-        j0.fbw_c = g1[0].fbw_c;
-        j0.fbw_nwin = g1[0].fbw_nwin;
-        j0.fbw_stride = g1[0].fbw_stride;
-    }
     MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
     MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
     MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
     // the G2 job has the longest chain: first; h (gated on the NTT) last
+    {
+        MsmJob<Fq>* gj[4] = {&j0, &j1, &j3, &j4};
+        for (int k = 0; k < 4; k++)
+            if (g1[k].fbw_table) {
+                gj[k]->fbw_table = (const G1Affine*)g1[k].fbw_table;
+                gj[k]->fbw_c = g1[k].fbw_c;
+                gj[k]->fbw_nwin = g1[k].fbw_nwin;
+                gj[k]->fbw_stride = g1[k].fbw_stride;
+            }
+        if (g2.fbw_table) {
+            j2.fbw_table = (const G2Affine*)g2.fbw_table;
+            j2.fbw_c = g2.fbw_c;
+            j2.fbw_nwin = g2.fbw_nwin;
+            j2.fbw_stride = g2.fbw_stride;
+        }
+    }
     MsmJobBase* jobs[5] = {&j2, &j1, &j3, &j4, &j0};
     return run_jobs(ctx, jobs, 5);
 }
 
 // table[w * stride + i] = 2^(c*w) * bases[i], affine, w = 0 .. nwin-1 (row 0 is a copy of the bases)
-__global__ void __launch_bounds__(256) k_fbw_build(const G1Affine* __restrict__ bases, size_t n, size_t stride, int c,
-                                                   int nwin, G1Affine* __restrict__ table) {
+template <class F>
+__global__ void __launch_bounds__(256) k_fbw_build(const Affine<F>* __restrict__ bases, size_t n, size_t stride, int c,
+                                                   int nwin, Affine<F>* __restrict__ table) {
+    using L = typename LazyOf<F>::L;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    G1Affine cur = bases[i];
+    Affine<F> cur = bases[i];
     table[i] = cur;
     for (int w = 1; w < nwin; w++) {
-        AffD<FqL> a = AffD<FqL>::load(&cur);
-        G1L p = G1L::dbl_affine(a);
+        AffD<L> a = AffD<L>::load(&cur);
+        XYZZd<L> p = XYZZd<L>::dbl_affine(a);
         for (int k = 1; k < c; k++) p = p.dbl();
         p.to_affine_mem(&cur);
         table[(size_t)w * stride + i] = cur;
     }
 }
 
-int msm_fbw_build(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table) {
+int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table) {
     if (n == 0) return ZG_OK;
-    hipLaunchKernelGGL(k_fbw_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride, c, nwin,
-                       d_table);
+    hipLaunchKernelGGL((k_fbw_build<Fq>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride, c,
+                       nwin, d_table);
     ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table) {
+    if (n == 0) return ZG_OK;
+    hipLaunchKernelGGL((k_fbw_build<Fq2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride,
+                       c, nwin, d_table);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+// blocking: how many of the n scalars (through the index indirection) are 0 / 1
+int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,
+                        uint64_t* ones) {
+    *zeros = *ones = 0;
+    if (n == 0) return ZG_OK;
+    DevBuf cnt;
+    ZG_HIP(ctx, cnt.alloc(16));
+    ZG_HIP(ctx, hipMemsetAsync(cnt.p, 0, 16, ctx->stream));
+    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, n, cnt.as<uint32_t>());
+    uint32_t h[2] = {0, 0};
+    ZG_HIP(ctx, hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *zeros = h[0];
+    *ones = h[1];
     return ZG_OK;
 }
 

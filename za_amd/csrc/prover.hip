@@ -602,7 +602,7 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
     uint64_t nnz_total = 0;
     for (int k = 0; k < 3; k++) nnz_total += r->col[k].bytes / 4;
     ProfScope ps(ctx, PROF_R1CS_EVAL, 36 * nnz_total + 96 * (r->n_constraints + r->n_inputs));
-    if (bitrev && r->log_m >= 8 && r->n_constraints && !getenv("ZG_X_OLDEVAL")) {   // EXPERIMENT
+    if (bitrev && r->log_m >= 8 && r->n_constraints) {
         ProveWs& ws = prove_ws(ctx);
         const size_t nv = (size_t)r->n_inputs + r->n_aux;
         ZG_HIP(ctx, ws.wcls.reserve(nv));
@@ -793,41 +793,105 @@ extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void*
     return prove_h_enqueue(ctx, r, d_witness, d_h_out);
 }
 
-// Fixed-base window table for this rank's part of the h query (n points), built once per key: every proof
-// with the key re-uses it.  Budget: ZA_AMD_FBW_MAX_GB (default: 60% of the free HBM); ZA_AMD_FBW=0 turns it off.
-static int ensure_h_table(Ctx* ctx, const zg_params* p, uint64_t n) {
-    if (p->fbw_state == 1 && p->fbw_n == n) return ZG_OK;
-    if (p->fbw_state == -1) return ZG_OK;
-    p->fbw.release();
-    p->fbw_state = -1;
-    const char* off = getenv("ZA_AMD_FBW");
-    if ((off && off[0] == '0') || n < 64) return ZG_OK;
-    size_t free_b = 0, total_b = 0;
-    ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    size_t budget = (size_t)((double)free_b * 0.6);
-    if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
-    int c = 0, nwin = 0;
-    if (!msm_fbw_plan(n, budget, sizeof(G1Affine), &c, &nwin)) return ZG_OK;
-    if (p->fbw.alloc((size_t)nwin * n * sizeof(G1Affine)) != hipSuccess) {
-        (void)hipGetLastError();
-        return ZG_OK;   // no room: the plain per-window schedule is used
+// Fixed-base window tables for this rank's part of each query, built once per key: every proof with the key
+// re-uses them.  The digit width is planned from the number of scalars that are neither 0 nor 1 in the witness the
+// tables are first built for (a circuit's share of bit signals is structural), and a table is only built where it
+// beats the per-window schedule.  Budget: ZA_AMD_FBW_MAX_GB (default: 60% of the free HBM) in the order b_g2, h, l,
+// a, b_g1; ZA_AMD_FBW=0 turns the tables off.
+struct QueryUse {
+    const void* bases;
+    const uint32_t* scalars;
+    const uint32_t* index;
+    uint64_t n;
+};
+static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask) {
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    static const int order[5] = {4, 0, 1, 2, 3};
+    for (int oi = 0; oi < 5; oi++) {
+        const int k = order[oi];
+        auto& t = p->fbw[k];
+        const uint64_t n = use[k].n;
+        if (!(mask & (1u << k)) || n == 0) continue;
+        if (k != 0 && !use[k].scalars) continue;   // zg_params_prepare without a witness: only the h table
+        if ((t.state == 1 && t.n == n) || t.state == -1) continue;
+        t.buf.release();
+        t.state = -1;
+        const char* off = getenv("ZA_AMD_FBW");   // "0" = no tables, otherwise a bit mask over (h, l, a, b_g1, b_g2)
+        if (off && !((unsigned)atoi(off) & (1u << k))) continue;
+        if (n < 64) continue;
+        uint64_t n_real = n;
+        if (k != 0) {   // h is dense by construction
+            uint64_t zeros = 0, ones = 0;
+            ZG_TRY(msm_classify_counts(ctx, use[k].scalars, use[k].index, n, &zeros, &ones));
+            n_real = n - zeros - ones;
+        }
+        // a mostly-0/1 assignment leaves few digits to save, and gathering them from an nwin-times larger table
+        // costs more than that (measured at 2^22: b_g2 accumulation 1.5 -> 2.1 ms with 3% real scalars)
+        if (n_real < 64 || n_real * 2 < n) continue;
+        size_t free_b = 0, total_b = 0;
+        ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        size_t budget = (size_t)((double)free_b * 0.6);
+        if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
+        const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
+        int c = 0, nwin = 0;
+        if (!msm_fbw_plan(n_real, n, budget, elem, &c, &nwin)) continue;
+        if (t.buf.alloc((size_t)nwin * n * elem) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;   // no room: the plain per-window schedule is used
+        }
+        if (k == 4)
+            ZG_TRY(msm_fbw_build_g2(ctx, (const G2Affine*)use[k].bases, n, n, c, nwin, t.buf.as<G2Affine>()));
+        else
+            ZG_TRY(msm_fbw_build_g1(ctx, (const G1Affine*)use[k].bases, n, n, c, nwin, t.buf.as<G1Affine>()));
+        ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        t.c = c;
+        t.nwin = nwin;
+        t.n = n;
+        t.state = 1;
     }
-    ZG_TRY(msm_fbw_build(ctx, p->q[0].buf.as<G1Affine>(), n, n, c, nwin, p->fbw.as<G1Affine>()));
-    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    p->fbw_c = c;
-    p->fbw_nwin = nwin;
-    p->fbw_n = n;
-    p->fbw_state = 1;
     return ZG_OK;
 }
 
-extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) {
+// the five multiexps' operands for this rank's shard (n = 0 where the mask leaves a query out)
+static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const void* d_h_shard,
+                      unsigned mask, QueryUse use[5]) {
+    const uint64_t m = (uint64_t)1 << r->log_m;
+    const uint32_t* w = (const uint32_t*)d_witness;
+    {   // h: first m-1 points of the query; this shard holds [lo, hi)
+        const auto& q = p->q[0];
+        uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
+        uint64_t n = hi > q.lo && (mask & 1u) ? hi - q.lo : 0;
+        use[0] = QueryUse{q.buf.p, (const uint32_t*)d_h_shard, nullptr, n};
+    }
+    {   // l: aux assignment, full density
+        const auto& q = p->q[1];
+        uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
+        uint64_t n = hi > q.lo && (mask & 2u) ? hi - q.lo : 0;
+        use[1] = QueryUse{q.buf.p, w ? w + 8 * ((size_t)r->n_inputs + q.lo) : nullptr, nullptr, n};
+    }
+    {   // a: inputs (full density) then aux by a_aux_density
+        const auto& q = p->q[2];
+        use[2] = QueryUse{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (mask & 4u) ? q.hi - q.lo : 0};
+    }
+    {
+        const auto& q = p->q[3];
+        use[3] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 8u) ? q.hi - q.lo : 0};
+    }
+    {
+        const auto& q = p->q[4];
+        use[4] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 16u) ? q.hi - q.lo : 0};
+    }
+    (void)ctx;
+    return ZG_OK;
+}
+
+extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness) {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t m = (uint64_t)1 << r->log_m;
-    const auto& q = p->q[0];
-    uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
-    return ensure_h_table(ctx, p, hi > q.lo ? hi - q.lo : 0);
+    ZG_TRY(check_query_sizes(ctx, p, r));
+    QueryUse use[5];
+    ZG_TRY(query_uses(ctx, p, r, d_witness, nullptr, 0x1f, use));
+    return ensure_tables(ctx, p, use, 0x1f);
 }
 
 extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
@@ -836,44 +900,24 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_TRY(check_query_sizes(ctx, p, r));
-    const uint64_t m = (uint64_t)1 << r->log_m;
-    const uint32_t* w = (const uint32_t*)d_witness;
     double t0 = now_ms();
     G1XYZZ g1out[4];
     G2XYZZ b2_acc;
+    QueryUse use[5];
+    ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use));
+    if (use[0].n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
+    ZG_TRY(ensure_tables(ctx, p, use, mask));
     MsmDesc d1[4], d2;
-    {   // h: first m-1 points of the query; this shard holds [lo, hi)
-        const auto& q = p->q[0];
-        uint64_t hi = std::min<uint64_t>(q.hi, m - 1);
-        uint64_t n = hi > q.lo ? hi - q.lo : 0;
-        if (!(mask & 1u)) n = 0;
-        if (n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
-        d1[0] = MsmDesc{q.buf.p, (const uint32_t*)d_h_shard, nullptr, (size_t)n, /*dense=*/true};
-        if (n) ZG_TRY(ensure_h_table(ctx, p, n));
-        if (n && p->fbw_state == 1 && p->fbw_n == n) {
-            d1[0].fbw_table = p->fbw.p;
-            d1[0].fbw_c = p->fbw_c;
-            d1[0].fbw_nwin = p->fbw_nwin;
-            d1[0].fbw_stride = (size_t)n;
+    for (int k = 0; k < 5; k++) {
+        MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
+        const auto& t = p->fbw[k];
+        if (use[k].n && t.state == 1 && t.n == use[k].n) {
+            d.fbw_table = t.buf.p;
+            d.fbw_c = t.c;
+            d.fbw_nwin = t.nwin;
+            d.fbw_stride = (size_t)use[k].n;
         }
-    }
-    {   // l: aux assignment, full density
-        const auto& q = p->q[1];
-        uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
-        uint64_t n = hi > q.lo && (mask & 2u) ? hi - q.lo : 0;
-        d1[1] = MsmDesc{q.buf.p, w + 8 * ((size_t)r->n_inputs + q.lo), nullptr, (size_t)n};
-    }
-    {   // a: inputs (full density) then aux by a_aux_density
-        const auto& q = p->q[2];
-        d1[2] = MsmDesc{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (mask & 4u) ? (size_t)(q.hi - q.lo) : 0};
-    }
-    {
-        const auto& q = p->q[3];
-        d1[3] = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 8u) ? (size_t)(q.hi - q.lo) : 0};
-    }
-    {
-        const auto& q = p->q[4];
-        d2 = MsmDesc{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 16u) ? (size_t)(q.hi - q.lo) : 0};
+        if (k < 4) d1[k] = d; else d2 = d;
     }
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ctx->ev_witness, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
