@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--provers", type=int, default=2,
+                    help="extra line: throughput with this many concurrent provers on the GPU (1 = skip); the headline "
+                         "value is always one proof at a time")
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
@@ -182,6 +185,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    conc_line = None
+    if args.provers > 1 and world == 1:
+        # throughput with several provers sharing the GPU (one zg_ctx + host thread each, same resident key): the
+        # second prover's NTT phase fills the low-occupancy sort / reduction tails of the first one's h multiexp
+        import threading
+        ctxs = [ctx] + [za_amd.Context(local_rank) for _ in range(args.provers - 1)]
+        per = max(2, (2 * args.steps) // args.provers)
+        outs = [None] * args.provers
+
+        def work(i, k):
+            for _ in range(k):
+                outs[i] = ctxs[i].prove_dev(P, r1, d_w, r_blind, s_blind)
+        for i in range(args.provers):
+            work(i, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i, per)) for i in range(args.provers)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        conc_line = {"provers": args.provers, "proofs": per * args.provers, "ms_per_proof": 1e3 * el / (per * args.provers),
+                     "constraints_per_s": n_constraints * per * args.provers / el,
+                     "identical_proofs": all(bytes(o) == bytes(proof) for o in outs)}
+        for c in ctxs[1:]:
+            c.close()
+
     msm_line = None
     if not args.no_msm and world == 1:
         # second half of BASELINE.json's metric: G1 MSM points/s, bases resident in HBM (ABI form), uniform scalars
@@ -242,6 +274,8 @@ def main():
         }
         if msm_line:
             line["g1_msm"] = msm_line
+        if conc_line:
+            line["concurrent_provers"] = conc_line
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(ctx, args)

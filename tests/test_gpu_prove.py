@@ -428,3 +428,34 @@ def test_fixed_base_window_table_gives_the_same_proof_as_the_plain_schedule(ctx,
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
     assert co.prove(download_params(ctx, P_plain), csr, sr.witness, 5, 6, threads=8) == plain
     sr.close()
+
+
+def test_two_contexts_prove_concurrently_with_one_resident_key(ctx):
+    """Two zg_ctx handles on two host threads share the R1CS and key handles (read-only after zg_params_prepare):
+    every proof equals the single-threaded one."""
+    import threading
+    import za_amd
+    from za_amd import synth
+    lg = 14
+    sr = synth.SynthR1CS(lg, 2, 0.9, 4321)
+    R = sr.load(ctx)
+    m = 1 << lg
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 61)
+    d_w = ctx.upload(sr.witness)
+    P.prepare(R, d_w)
+    want = ctx.prove_dev(P, R, d_w, 11, 13)
+    other = za_amd.Context(0)
+    got = {0: [], 1: []}
+
+    def work(i, c):
+        for _ in range(4):
+            got[i].append(c.prove_dev(P, R, d_w, 11, 13))
+    th = [threading.Thread(target=work, args=(0, ctx)), threading.Thread(target=work, args=(1, other))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    other.close()
+    ctx.free(d_w)
+    assert all(bytes(p) == bytes(want) for p in got[0] + got[1]) and len(got[0]) == len(got[1]) == 4
+    sr.close()
