@@ -23,6 +23,7 @@ struct Ctx {
     bool prof_enabled = false;
     struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes, units; };
     std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per scope cost 0.3 ms per proof)
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
@@ -48,7 +49,14 @@ struct ProfScope {
         : c(ctx), st(stream ? stream : ctx->stream) {
         if (!ctx->prof_enabled) return;
         Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes, units};
-        if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+        for (hipEvent_t* e : {&p.e0, &p.e1}) {
+            if (!ctx->prof_pool.empty()) {
+                *e = ctx->prof_pool.back();
+                ctx->prof_pool.pop_back();
+            } else if (hipEventCreate(e) != hipSuccess) {
+                return;
+            }
+        }
         (void)hipEventRecord(p.e0, st);
         ctx->prof_pending.push_back(p);
         idx = (int)ctx->prof_pending.size() - 1;

@@ -625,6 +625,7 @@ struct MsmJobBase {
     virtual int finish() = 0;
     hipStream_t st = nullptr;
     bool done = false;
+    bool chained = false;   // phase_b also queued phase_c's work (dense jobs)
 };
 
 template <class F>
@@ -641,7 +642,6 @@ struct MsmJob : MsmJobBase {
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
     uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
-    bool chained = false;          // phase_c was queued by phase_b
     int acc_prof = -1;
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
@@ -933,6 +933,10 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
     int remaining = njobs;
     while (remaining > 0) {
         bool progressed = false;
+        // launches first: a job's host-side finish() (a few hundred point operations) must not delay another
+        // job's next phase, so it only runs once every job has its last device phase queued
+        bool launches_pending = false;
+        for (int j = 0; j < njobs; j++) launches_pending |= state[j] < 3;
         for (int j = 0; j < njobs; j++) {
             if (state[j] == 4) continue;
             if (state[j] == 0) {
@@ -941,11 +945,14 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
                 progressed = true;
                 continue;
             }
+            if (state[j] == 3 && launches_pending) continue;
             hipError_t q = hipStreamQuery(jobs[j]->st);
             if (q == hipErrorNotReady) continue;
             if (q != hipSuccess) return fail(ctx, ZG_E_HIP, "stream query failed: %s", hipGetErrorString(q));
-            if (state[j] == 1) ZG_TRY(jobs[j]->phase_b());
-            else if (state[j] == 2) ZG_TRY(jobs[j]->phase_c());
+            if (state[j] == 1) {
+                ZG_TRY(jobs[j]->phase_b());
+                if (jobs[j]->chained) state[j]++;   // nothing left to launch
+            } else if (state[j] == 2) ZG_TRY(jobs[j]->phase_c());
             else {
                 ZG_TRY(jobs[j]->finish());
                 remaining--;

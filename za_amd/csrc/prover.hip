@@ -7,6 +7,7 @@
 // final group arithmetic.  There is no CPU fallback: zg_init fails without a GPU.
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <memory>
 #include <cstdarg>
 #include <cstdlib>
@@ -217,6 +218,11 @@ extern "C" void zg_free(zg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ntt_tables_free(ctx);
     msm_scratch_free(ctx);
+    for (auto& p : ctx->prof_pending) {
+        if (p.e0) (void)hipEventDestroy(p.e0);
+        if (p.e1) (void)hipEventDestroy(p.e1);
+    }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx->prove_ws;
     ctx->prove_ws = nullptr;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -299,8 +305,8 @@ static int prof_drain(zg_ctx* ctx) {
             ctx->prof[p.id].bytes += p.bytes;
             ctx->prof[p.id].units += p.units;
         }
-        if (p.e0) (void)hipEventDestroy(p.e0);
-        if (p.e1) (void)hipEventDestroy(p.e1);
+        if (p.e0) ctx->prof_pool.push_back(p.e0);
+        if (p.e1) ctx->prof_pool.push_back(p.e1);
     }
     ctx->prof_pending.clear();
     return ZG_OK;
@@ -932,6 +938,25 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
 
 static void scalar_words(uint32_t out[8], const uint8_t le[32]) { memcpy(out, le, 32); }
 
+// k0*P0 + k1*P1 + k2*P2 with one shared doubling chain (Straus): the 7 non-empty subset sums are tabulated,
+// then 254 doublings + at most 254 additions instead of three separate double-and-add ladders.
+static G1XYZZ straus3(const G1XYZZ pts[3], const uint32_t* const k[3]) {
+    G1XYZZ tab[8];
+    tab[0] = G1XYZZ::inf();
+    for (int m = 1; m < 8; m++) {
+        const int low = m & -m, idx = low == 1 ? 0 : low == 2 ? 1 : 2;
+        tab[m] = tab[m ^ low].add(pts[idx]);
+    }
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int i = 255; i >= 0; i--) {
+        acc = acc.dbl();
+        const int m = (int)((k[0][i >> 5] >> (i & 31)) & 1) | (int)(((k[1][i >> 5] >> (i & 31)) & 1) << 1) |
+                      (int)(((k[2][i >> 5] >> (i & 31)) & 1) << 2);
+        if (m) acc = acc.add(tab[m]);
+    }
+    return acc;
+}
+
 extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world,
                                 const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
     if (!ctx || !p || !partials_all || world < 1 || !r_le || !s_le || !proof_out) return ZG_E_INVALID_ARG;
@@ -960,14 +985,17 @@ extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* 
     const G1XYZZ delta1 = G1XYZZ::from_affine(p->delta_g1), alpha = G1XYZZ::from_affine(p->alpha_g1),
                  beta1 = G1XYZZ::from_affine(p->beta_g1);
     const G2XYZZ delta2 = G2XYZZ::from_affine(p->delta_g2);
+    // B = beta2 + s*delta2 + sum b2: the one G2 multiplication (about 3 G1 ones) runs on a helper thread
+    G2Affine B;
+    std::thread tb([&] { B = delta2.mul(s).add_mixed(p->beta_g2).add(b2_ans).to_affine(); });
     // A = alpha + r*delta + sum a
     G1XYZZ g_a = delta1.mul(r).add_mixed(p->alpha_g1).add(a_ans);
-    // B = beta2 + s*delta2 + sum b2
-    G2XYZZ g_b = delta2.mul(s).add_mixed(p->beta_g2).add(b2_ans);
-    // C = rs*delta + s*alpha + r*beta1 + s*(sum a) + r*(sum b1) + sum h + sum l
-    G1XYZZ g_c = delta1.mul(rs).add(alpha.mul(s)).add(beta1.mul(r)).add(a_ans.mul(s)).add(b1_ans.mul(r)).add(h_acc).add(l_acc);
+    // C = s*(alpha + sum a) + r*(beta1 + sum b1) + rs*delta + sum h + sum l
+    const G1XYZZ pts[3] = {alpha.add(a_ans), beta1.add(b1_ans), delta1};
+    const uint32_t* const ks[3] = {s, r, rs};
+    G1XYZZ g_c = straus3(pts, ks).add(h_acc).add(l_acc);
     G1Affine A = g_a.to_affine(), C = g_c.to_affine();
-    G2Affine B = g_b.to_affine();
+    tb.join();
     if (A.is_inf() || B.is_inf() || C.is_inf())
         return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "a proof element is the identity (BadFormat(\"invalid point\") in za)");
     fq_to_be(proof_out, A.x); fq_to_be(proof_out + 32, A.y);
@@ -985,6 +1013,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "zg_prove needs an unsharded key (world = 1); use the phase API");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
+    if (ctx->prof_enabled && !ctx->prof_pending.empty()) ZG_TRY(prof_drain(ctx));   // recycle the last proof's events
     ZG_TRY(check_query_sizes(ctx, p, r));
     const size_t m = (size_t)1 << r->log_m;
     DevBuf& dh = prove_ws(ctx).h;
