@@ -37,7 +37,7 @@ static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, partial, lvl[2], dbuf[2], ones[2], bsum, meta, heavy;
+    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], dbuf[2], ones[2], bsum, meta, heavy;
     static constexpr size_t HOST_BYTES = 256 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
@@ -82,6 +82,12 @@ static MsmPlan plan_msm(size_t n_real, size_t n_ones) {
 // scalar fall into ONE set of 2^(c-1) buckets.  The bucket reduction is paid once instead of once per window,
 // which moves the optimum to a wider digit (c = 20 instead of 16 at n = 2^22: 13 instead of 16 mixed adds per
 // scalar).  Costs nwin x the key's HBM footprint -- the trade 288 GB of HBM3E is there for.
+// The last digit of a canonical scalar (< 2^254) has only t = 254 - c*(nwin-1) bits.  Folded into the shared
+// bucket set it piles n entries onto the lowest 2^t buckets, and with a small t one k_part_local workgroup sorts
+// all of them (measured: c = 19, t = 7 cost 1.26 ms of a 2^20 proof).  Large jobs only use plans with t >= 10.
+// (Spreading the short digit over the bucket range with a rescaled last table row was tried: it balances the sort
+// but mixes 360-point and 104-point buckets inside every wave of k_accumulate, +2 ms at 2^22.)
+static int fbw_top_bits(int c, int nwin) { return 254 - c * (nwin - 1); }
 static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
     MsmPlan p{};
     p.c = c;
@@ -107,6 +113,7 @@ bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_b
         if (nwin > MAXWIN) continue;
         if ((double)n_table * nwin >= 2.0e9) continue;                 // value = w * n + i must fit 31 bits
         if ((double)n_table * nwin * (double)elem_bytes > (double)max_bytes) continue;
+        if (n_real >= (1u << 17) && fbw_top_bits(c, nwin) < 10) continue;   // small jobs: the imbalance is harmless
         double cost = (double)n_real * nwin + 4.8 * (double)(1u << (c - 1)) + 3000.0 * ((c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
         if (cost < best_cost) {
             best_cost = cost;
@@ -453,17 +460,80 @@ __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict_
     for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
 }
 
+// Items sorted by their number of points (counting sort, longest first): a wave of k_accumulate then holds 64
+// items of (nearly) the same length.  Bucket loads of a dense job are Poisson(~104): in bucket order the longest of
+// 64 lanes is ~1.23x the mean and every lane waits for it.
+static constexpr uint32_t ITEM_CLASSES = 513;   // item sizes 0 .. 512
+__device__ __forceinline__ uint32_t item_size(uint32_t t, const uint32_t* __restrict__ item_key,
+                                              const uint32_t* __restrict__ item_off, const uint32_t* __restrict__ offsets,
+                                              uint32_t T, uint32_t ones_key) {
+    const uint32_t key = item_key[t];
+    const uint32_t Tk = key == ones_key ? T_ONES : T;
+    const uint32_t start = offsets[key] + (t - item_off[key]) * Tk;
+    const uint32_t left = offsets[key + 1] - start;
+    return left < Tk ? left : Tk;
+}
+__global__ void __launch_bounds__(256) k_item_hist(const uint32_t* __restrict__ item_key, const uint32_t* __restrict__ item_off,
+                                                   const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t T,
+                                                   uint32_t ones_key, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[ITEM_CLASSES];
+    for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint32_t total = item_off[nkeys];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
+        atomicAdd(&h[item_size(t, item_key, item_off, offsets, T, ones_key)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+// cursor[s] = number of items longer than s (longest first)
+__global__ void __launch_bounds__(64) k_item_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor) {
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int sz = (int)ITEM_CLASSES - 1; sz >= 0; sz--) {
+            cursor[sz] = run;
+            run += hist[sz];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict__ item_key, const uint32_t* __restrict__ item_off,
+                                                      const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t T,
+                                                      uint32_t ones_key, uint32_t* __restrict__ cursor,
+                                                      uint32_t* __restrict__ perm) {
+    __shared__ uint32_t h[ITEM_CLASSES], base[ITEM_CLASSES];
+    const uint32_t total = item_off[nkeys];
+    // grid-stride in whole-block chunks so that every thread of a block sees the same number of rounds
+    for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < total; t0 += gridDim.x * blockDim.x) {
+        for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        const uint32_t t = t0 + threadIdx.x;
+        uint32_t sz = 0, rank = 0;
+        if (t < total) {
+            sz = item_size(t, item_key, item_off, offsets, T, ones_key);
+            rank = atomicAdd(&h[sz], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
+            if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+        __syncthreads();
+        if (t < total) perm[base[sz] + rank] = t;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ stage 1
 template <class F>
 __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict__ bases,
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ item_off,
-                                                    const uint32_t* __restrict__ item_key, uint32_t nkeys,
+                                                    const uint32_t* __restrict__ item_key,
+                                                    const uint32_t* __restrict__ perm, uint32_t nkeys,
                                                     uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
     using L = typename LazyOf<F>::L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
+    if (perm) t = perm[t];              // items in order of decreasing length
     uint32_t key = item_key[t];
     uint32_t Tk = key == ones_key ? T_ONES : T;
     uint32_t seg = t - item_off[key];
@@ -770,6 +840,18 @@ struct MsmJob : MsmJobBase {
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
                                               ones_hi - ones_lo, st));
+            // order the items by length
+            ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
+            ZG_HIP(ctx, S.ihist.reserve(2 * ITEM_CLASSES * 4));
+            uint32_t* hist = S.ihist.as<uint32_t>();
+            ZG_HIP(ctx, hipMemsetAsync(hist, 0, ITEM_CLASSES * 4, st));
+            const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
+            hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                               S.offsets.as<uint32_t>(), nkeys, P.T, ones_key, hist);
+            hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(64), 0, st, hist, hist + ITEM_CLASSES);
+            hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
+                               S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, P.T, ones_key,
+                               hist + ITEM_CLASSES, S.perm.as<uint32_t>());
         }
         {
             ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
@@ -778,7 +860,8 @@ struct MsmJob : MsmJobBase {
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
                                fbw_table ? fbw_table : d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.item_key.as<uint32_t>(), nkeys, P.T, ones_key, S.partial.as<XYZZ<F>>());
+                               S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, P.T, ones_key,
+                               S.partial.as<XYZZ<F>>());
         }
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
