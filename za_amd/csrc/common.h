@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,7 @@ struct Ctx {
     struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes, units; };
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per scope cost 0.3 ms per proof)
+    std::mutex prof_mu;                  // the MSM jobs of a proof run on their own host threads
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
@@ -48,6 +50,7 @@ struct ProfScope {
     ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr, uint64_t units = 0)
         : c(ctx), st(stream ? stream : ctx->stream) {
         if (!ctx->prof_enabled) return;
+        std::lock_guard<std::mutex> lock(ctx->prof_mu);
         Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes, units};
         for (hipEvent_t* e : {&p.e0, &p.e1}) {
             if (!ctx->prof_pool.empty()) {
@@ -61,7 +64,15 @@ struct ProfScope {
         ctx->prof_pending.push_back(p);
         idx = (int)ctx->prof_pending.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_pending[idx].e1, st); }
+    ~ProfScope() {
+        if (idx < 0) return;
+        hipEvent_t e1;
+        {
+            std::lock_guard<std::mutex> lock(c->prof_mu);
+            e1 = c->prof_pending[idx].e1;
+        }
+        (void)hipEventRecord(e1, st);
+    }
 };
 
 #define ZG_HIP(ctx, expr)                                                                      \

@@ -21,6 +21,8 @@
 namespace zg {
 
 int fail(Ctx* ctx, int code, const char* fmt, ...) {
+    static std::mutex mu;   // the MSM jobs of a proof report from their own threads
+    std::lock_guard<std::mutex> lock(mu);
     if (ctx) {
         char buf[512];
         va_list ap;
