@@ -203,11 +203,14 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
     __syncthreads();
     const int sh = contiguous ? 0 : j;  // position of the butterfly bits inside the local index
     const uint32_t half = tile_elems >> 1;
-    for (int it = 0; it < k; it++) {
-        const int q = DIT ? it : k - 1 - it;
+    // DIF: reduce the sums every 2nd stage (and after the last one); `it` counts stages in execution order
+    auto reduces = [&](int it) { return (it & 1) != 0 || it == k - 1; };
+    int it = 0;
+    if (k & 1) {   // an odd stage count: one radix-2 stage first, radix-4 pairs after it
+        const int q = DIT ? 0 : k - 1;
         const int s = s_lo + q;          // global stage: butterfly span 2^s
         const int bit = sh + q;
-        const bool red = (it & 1) != 0 || it == k - 1;   // DIF: reduce the sums every 2nd stage
+        const bool red = reduces(0);
         for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
             uint32_t i0 = ((b >> bit) << (bit + 1)) | (b & ((1u << bit) - 1u));
             uint32_t i1 = i0 | (1u << bit);
@@ -223,6 +226,53 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, const F
                 FrD sm = u + v;                      // <= 4.02 (after a reducing stage) or 8.04
                 lds_put(i1, FrD::sub<5>(u, v) * w);  // v <= 4.02
                 lds_put(i0, red ? sm.reduce() : sm);
+            }
+        }
+        __syncthreads();
+        it = 1;
+    }
+    // Two stages per LDS round trip: a thread owns the four elements that differ in local bits (bit, bit + 1) and
+    // runs the two radix-2 stages on them in registers -- the same arithmetic, element by element, as two separate
+    // stages (so the lazy bounds above still hold), with half the LDS traffic and barriers and 3 twiddle loads
+    // instead of 4: both low-stage butterflies share a twiddle, the two high-stage ones differ by omega^(m/4).
+    const uint32_t quarter = tile_elems >> 2;
+    for (; it < k; it += 2) {
+        const int qlo = DIT ? it : k - 2 - it;
+        const int s = s_lo + qlo;        // low stage: span 2^s; high stage: span 2^(s+1)
+        const int bit = sh + qlo;
+        for (uint32_t g = threadIdx.x; g < quarter; g += blockDim.x) {
+            const uint32_t i00 = ((g >> bit) << (bit + 2)) | (g & ((1u << bit) - 1u));
+            const uint32_t i01 = i00 | (1u << bit), i10 = i00 | (2u << bit), i11 = i01 | i10;
+            const size_t e00 = gidx(i00);
+            const size_t lowbits = e00 & (((size_t)1 << s) - 1);
+            const size_t t1 = lowbits << (log_m - 1 - s);          // low stage, both butterflies
+            const size_t t2 = lowbits << (log_m - 2 - s);          // high stage, butterfly (00, 10)
+            const size_t t3 = t2 + ((size_t)1 << (log_m - 2));     // high stage, butterfly (01, 11)
+            FrD x0 = lds_get(i00), x1 = lds_get(i01), x2 = lds_get(i10), x3 = lds_get(i11);
+            if (DIT) {
+                const FrD w1 = FrD::load_canon(&tw[t1]);
+                FrD ta = x1 * w1, tb = x3 * w1;
+                FrD a0 = x0 + ta, a1 = FrD::sub<2>(x0, ta), a2 = x2 + tb, a3 = FrD::sub<2>(x2, tb);
+                FrD tc = a2 * FrD::load_canon(&tw[t2]), td = a3 * FrD::load_canon(&tw[t3]);
+                lds_put(i00, a0 + tc);
+                lds_put(i10, FrD::sub<2>(a0, tc));
+                lds_put(i01, a1 + td);
+                lds_put(i11, FrD::sub<2>(a1, td));
+            } else {
+                const bool red_hi = reduces(it), red_lo = reduces(it + 1);
+                FrD b0 = x0 + x2, b1 = x1 + x3;
+                FrD b2 = FrD::sub<5>(x0, x2) * FrD::load_canon(&tw[t2]);
+                FrD b3 = FrD::sub<5>(x1, x3) * FrD::load_canon(&tw[t3]);
+                if (red_hi) {
+                    b0 = b0.reduce();
+                    b1 = b1.reduce();
+                }
+                const FrD w1 = FrD::load_canon(&tw[t1]);
+                FrD y00 = b0 + b1, y10 = b2 + b3;
+                lds_put(i01, FrD::sub<5>(b0, b1) * w1);
+                lds_put(i11, FrD::sub<5>(b2, b3) * w1);
+                lds_put(i00, red_lo ? y00.reduce() : y00);
+                lds_put(i10, red_lo ? y10.reduce() : y10);
             }
         }
         __syncthreads();
