@@ -142,8 +142,7 @@ def main():
             P = synth.params_shard(ctx, full, rank, world)
             full.close()
     d_w = ctx.upload(sr.witness)
-    if world == 1:
-        P.prepare(r1, d_w)     # fixed-base window tables: once per key, not per proof
+    P.prepare(r1, d_w)         # fixed-base window tables (of this rank's shard): once per key, not per proof
     n_constraints = sr.n_constraints
     nnz = list(sr.nnz)
     n_aux = sr.n_aux
