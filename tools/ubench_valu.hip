@@ -36,6 +36,12 @@ __global__ void __launch_bounds__(256) bench(uint64_t* out, int iters, uint32_t 
                 if (OP == 13) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(b[i]) : "v"(c[i]) : "vcc");
                 if (OP == 14) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(dx));
                 if (OP == 15) asm volatile("v_mad_i32_i24 %0, %0, %1, %0" : "+v"(b[i]) : "v"(c[i]));
+                if (OP == 16) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(a[i]));
+                if (OP == 17) asm volatile("v_and_b32 %0, %0, %1" : "+v"(b[i]) : "v"(c[i]));
+                if (OP == 18) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(b[i]) : "v"(c[i]));
+                if (OP == 19) asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(b[i]));
+                if (OP == 20) asm volatile("v_ashrrev_i64 %0, 29, %0" : "+v"(a[i]));
+                if (OP == 21) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]) : "vcc");
             }
         }
     }
@@ -75,6 +81,13 @@ int main() {
     run<4>("v_add_co+v_addc_co (pair)", d_out);
     run<13>("v_add_co_u32", d_out);
     run<5>("v_mov_b32", d_out);
+    run<16>("v_lshrrev_b64", d_out);
+    run<20>("v_ashrrev_i64", d_out);
+    run<17>("v_and_b32", d_out);
+    run<18>("v_alignbit_b32", d_out);
+    run<19>("v_lshrrev_b32", d_out);
+    run<21>("v_mad_i64_i32", d_out);
+    run<8>("v_fma_f64", d_out);
     run<6>("v_mad_u32_u24", d_out);
     run<15>("v_mad_i32_i24", d_out);
     run<7>("v_mul_hi_u32_u24", d_out);
