@@ -307,12 +307,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const uint32_t* __
 }
 
 // single block: in-place exclusive scan of both block-sum arrays
-__global__ void __launch_bounds__(1024) k_scan_bsums(uint32_t* bsum, uint32_t nb) {
+// (256 threads: a 1024-thread workgroup needs a CU with 16 free wave slots and waited up to 3 ms behind the
+// long-running accumulation waves of the other jobs)
+__global__ void __launch_bounds__(256) k_scan_bsums(uint32_t* bsum, uint32_t nb) {
     __shared__ uint32_t lds[16];
     for (int arr = 0; arr < 2; arr++) {
         uint32_t* a = bsum + (size_t)arr * nb;
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < nb; base += 1024) {
+        for (uint32_t base = 0; base < nb; base += blockDim.x) {
             uint32_t idx = base + threadIdx.x;
             uint32_t v = idx < nb ? a[idx] : 0;
             uint32_t tot;
@@ -367,10 +369,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_xscan_reduce(const uint32_t* _
     block_excl_scan(sc, lds, tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(1024) k_xscan_bsums(uint32_t* bsum, uint32_t nb) {
+__global__ void __launch_bounds__(256) k_xscan_bsums(uint32_t* bsum, uint32_t nb) {
     __shared__ uint32_t lds[16];
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nb; base += 1024) {
+    for (uint32_t base = 0; base < nb; base += blockDim.x) {
         uint32_t idx = base + threadIdx.x;
         uint32_t val = idx < nb ? bsum[idx] : 0;
         uint32_t tot;
@@ -789,7 +791,7 @@ struct MsmJob : MsmJobBase {
             ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>((size_t)nbx, (size_t)2 * nbk) * 4));
             hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
                                S.bsum.as<uint32_t>());
-            hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nbx);
+            hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
             hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
                                S.bsum.as<uint32_t>());
         }
@@ -804,7 +806,7 @@ struct MsmJob : MsmJobBase {
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
         hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
                            S.bsum.as<uint32_t>(), nb);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, S.bsum.as<uint32_t>(), nb);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
         hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
                            S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                            (uint32_t*)nullptr);
