@@ -459,3 +459,78 @@ def test_two_contexts_prove_concurrently_with_one_resident_key(ctx):
     ctx.free(d_w)
     assert all(bytes(p) == bytes(want) for p in got[0] + got[1]) and len(got[0]) == len(got[1]) == 4
     sr.close()
+
+
+def test_r1cs_small_value_path_edge_coefficients(ctx):
+    """The prove path's evaluator sums terms with a +-2^s coefficient (s < 64) on a 0/1 witness value as integers.
+    A bit-packing circuit exercises every shift, both signs, the 2^64 and r - 2^64 coefficients that must take the
+    generic path, rows mixing both kinds, a row whose fast terms sum to a negative number, and a long generic row
+    (> 64 terms: the in-row reduction).  Key from the GPU set-up, proof against the C oracle."""
+    R_ = bn.R
+    rng = np.random.default_rng(99)
+    nbits = 66
+    bits = [int(b) for b in rng.integers(0, 2, nbits)]
+    bits[0] = 1
+    w = [1, 0]                      # ONE, public: packed value
+    var_bit = []
+    for b in bits:
+        w.append(b); var_bit.append(len(w) - 1)
+    cons = []
+
+    def newvar(v):
+        w.append(v % R_); return len(w) - 1
+    # bit constraints b*(b-1) = 0  ->  b * b = b
+    for v in var_bit:
+        cons.append(([(v, 1)], [(v, 1)], [(v, 1)]))
+    # packed = sum 2^s b_s for s < 66 (s = 64, 65 are generic coefficients)
+    packed = sum(b << s for s, b in enumerate(bits))
+    p_var = newvar(packed)
+    cons.append(([(v, 1 << s) for s, v in enumerate(var_bit)], [(0, 1)], [(p_var, 1)]))
+    # negative powers: neg = -sum 2^s b_s (s < 64) - 2^64 b_64
+    neg = -sum(b << s for s, b in enumerate(bits[:65]))
+    n_var = newvar(neg)
+    cons.append(([(v, (R_ - (1 << s)) % R_) for s, v in enumerate(var_bit[:65])], [(0, 1)], [(n_var, 1)]))
+    # mixed signs with a negative total on the fast path plus one generic term
+    tot = bits[1] - (bits[2] << 63) - (bits[3] << 5) + 7 * packed
+    m_var = newvar(tot)
+    cons.append(([(var_bit[1], 1), (var_bit[2], R_ - (1 << 63)), (var_bit[3], R_ - 32), (p_var, 7)], [(0, 1)], [(m_var, 1)]))
+    # a long generic row: 100 random coefficients on non-bit variables
+    big = [newvar(int(rng.integers(2, 1 << 62)) * int(rng.integers(2, 1 << 62))) for _ in range(100)]
+    coefs = [int(rng.integers(3, 1 << 62)) * 3 + 1 for _ in range(100)]
+    l_var = newvar(sum(c * w[v] for c, v in zip(coefs, big)))
+    cons.append(([(v, c) for c, v in zip(coefs, big)], [(0, 1)], [(l_var, 1)]))
+    # the public output, then padding up to a 2^9 domain so the tiled evaluator is used
+    w[1] = packed
+    cons.append(([(p_var, 1)], [(0, 1)], [(1, 1)]))
+    k = 2
+    while len(cons) + 2 < 512:
+        cons.append(([(k, 1)], [(0, 1)], [(k, 1)]))
+        k = 2 + (k - 1) % (len(w) - 2)
+    r1 = g.R1CS(2, len(w) - 2, cons)
+    assert r1.is_satisfied(w)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    assert R.log_m == 9
+    P, pbytes = ctx.setup(R, 0x21, 0x32, 0x43, 0x54, 0x65)
+    wb = co.witness_bytes(w)
+    got = ctx.prove(P, R, wb, 77, 88)
+    assert co.prove(download_params(ctx, P), csr, wb, 77, 88, threads=4) == got
+    import za_amd
+    assert za_amd.verify(pbytes, got, [packed]) is True
+
+
+def test_table_budget_falls_back_to_the_plain_schedule(ctx, monkeypatch):
+    """ZA_AMD_FBW_MAX_GB too small for any table: same proof through the per-window schedule."""
+    from za_amd import synth
+    lg = 12
+    sr = synth.SynthR1CS(lg, 2, 0.0, 5)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P1 = synth.synth_params(ctx, *sizes, 17)
+    a = ctx.prove(P1, R, sr.witness, 3, 4)
+    monkeypatch.setenv("ZA_AMD_FBW_MAX_GB", "0.00001")
+    P2 = synth.synth_params(ctx, *sizes, 17)
+    b = ctx.prove(P2, R, sr.witness, 3, 4)
+    assert a == b
+    sr.close()
