@@ -32,14 +32,17 @@ struct Ctx {
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
     struct ProveWs* prove_ws = nullptr;
     // reusable MSM scratch (one per concurrent job) and side streams, see msm.hip
-    struct MsmScratch* msm_scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int MSM_SLOTS = 8;   // 5 queries + up to 3 extra parts of the h job
+    struct MsmScratch* msm_scratch[MSM_SLOTS] = {nullptr};
+    hipStream_t side[MSM_SLOTS] = {nullptr};
     hipEvent_t side_ev = nullptr;
+    hipEvent_t part_ev[2 * (MSM_SLOTS - 4)] = {nullptr};   // (sorted, accumulated) per part of the h job
     hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip)
     bool side_ready = false;
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
+int live_contexts();   // zg_ctx handles currently alive in this process (prover.hip)
 
 // kernel classes timed by the profiling facility
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,

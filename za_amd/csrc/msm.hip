@@ -698,6 +698,12 @@ struct MsmJobBase {
     hipStream_t st = nullptr;
     bool done = false;
     bool chained = false;   // phase_b also queued phase_c's work (dense jobs)
+    // a job split into parts (the h multiexp): part k sorts after part k-1 has sorted and accumulates after part
+    // k-1 has accumulated, so its memory-bound sort overlaps the previous part's ALU-bound accumulation and the
+    // previous part's latency-bound reduction overlaps its own accumulation
+    MsmJobBase* dep = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr;
+    bool launched = false;   // phase_b has run (its events are recorded)
 };
 
 template <class F>
@@ -751,13 +757,20 @@ struct MsmJob : MsmJobBase {
     }
 
     int phase_b() override {
-        if (done) return ZG_OK;
+        if (done) {
+            launched = true;
+            return ZG_OK;
+        }
         const uint32_t* cls = reinterpret_cast<const uint32_t*>(S.host);
         const size_t n_zero = cls[0], n_ones = cls[1], n_real = n - n_zero - n_ones;
         if (n_real == 0 && n_ones == 0) {  // all scalars zero
             done = true;
+            launched = true;
+            if (ev_sorted) ZG_HIP(ctx, hipEventRecord(ev_sorted, st));
+            if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
             return ZG_OK;
         }
+        if (dep && dep->ev_sorted) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_sorted, 0));
         P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : plan_msm(n_real, n_ones);
         ones_key = P.nkeys;  // one extra bucket after the kw * B regular ones
         nkeys = P.nkeys + 1;
@@ -814,6 +827,8 @@ struct MsmJob : MsmJobBase {
                            S.meta.as<uint32_t>());
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
+        if (ev_sorted) ZG_HIP(ctx, hipEventRecord(ev_sorted, st));
+        launched = true;
         if (dense) {   // no ones bucket and a known bound on the item count: queue the rest without the read-back
             items_bound = (uint32_t)std::min<size_t>(max_entries / P.T + nkeys, 0xffffffffu);
             chained = true;
@@ -856,6 +871,7 @@ struct MsmJob : MsmJobBase {
                                hist + ITEM_CLASSES, S.perm.as<uint32_t>());
         }
         {
+            if (dep && dep->ev_acc) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_acc, 0));
             ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
                          chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
             acc_prof = ps.idx;
@@ -864,6 +880,7 @@ struct MsmJob : MsmJobBase {
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, P.T, ones_key,
                                S.partial.as<XYZZ<F>>());
+            if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
@@ -1018,7 +1035,7 @@ struct MsmJob : MsmJobBase {
 // (One host thread per job with blocking waits was measured: 0.6 ms slower per 2^22 proof -- the runtime's launch
 // path serialises the threads, the waits wake late, and the witness accumulations then crowd the first NTT passes.)
 static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
-    int state[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
+    int state[16] = {0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
     int remaining = njobs;
     while (remaining > 0) {
         bool progressed = false;
@@ -1035,6 +1052,7 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
                 continue;
             }
             if (state[j] == 3 && launches_pending) continue;
+            if (state[j] == 1 && jobs[j]->dep && !jobs[j]->dep->launched) continue;   // parts launch in order
             hipError_t q = hipStreamQuery(jobs[j]->st);
             if (q == hipErrorNotReady) continue;
             if (q != hipSuccess) return fail(ctx, ZG_E_HIP, "stream query failed: %s", hipGetErrorString(q));
@@ -1078,34 +1096,72 @@ int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const u
 // priority: their big-register G2 / tree kernels would otherwise starve behind the h accumulation.
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
                hipEvent_t ev_h) {
+    constexpr int NS = Ctx::MSM_SLOTS;
     if (!ctx->side_ready) {
         int lo_prio = 0, hi_prio = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
-        for (int k = 0; k < 5; k++)
-            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, k == 0 ? lo_prio : hi_prio));
+        for (int k = 0; k < NS; k++)
+            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking,
+                                                    k == 0 || k >= 5 ? lo_prio : hi_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+        for (int k = 0; k < 2 * (NS - 4); k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
         ctx->side_ready = true;
     }
+    // The h job is split into parts over consecutive base ranges (see MsmJobBase::dep): part 0 on side[0], the
+    // others on side[5..].  Two parts take 0.33 ms off a 2^22 proof (three: +0.1 ms); when several contexts share the
+    // GPU their proofs already fill each other's sort and reduction phases and the split costs 0.37 ms, so it is
+    // only used by a lone context.  ZA_AMD_H_PARTS overrides the count (1 = one job).
+    int parts = 1;
+    if (g1[0].dense && g1[0].n >= ((size_t)1 << 20) && live_contexts() == 1) parts = 2;
+    if (const char* e = getenv("ZA_AMD_H_PARTS")) parts = atoi(e);
+    if (parts < 1) parts = 1;
+    if (parts > NS - 4) parts = NS - 4;
+    if (g1[0].n < (size_t)parts * 4096) parts = 1;
     ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
-    for (int k = 0; k < 5; k++) {
-        hipEvent_t ev = k == 0 ? ev_h : ev_witness;
+    for (int k = 0; k < NS; k++) {
+        if (k >= 5 && k - 4 >= parts) continue;
+        hipEvent_t ev = (k == 0 || k >= 5) ? ev_h : ev_witness;
         ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
     }
     MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
-    MsmJob<Fq> j0(ctx, scratch_slot(ctx, 0), ctx->side[0], (const G1Affine*)g1[0].bases, g1[0].scalars, g1[0].index, g1[0].n, &out1[0]);
-    j0.dense = g1[0].dense;
     MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
     MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
     MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
-    // the G2 job has the longest chain: first; h (gated on the NTT) last
+    // h parts
+    G1XYZZ hout[NS - 4];
+    std::unique_ptr<MsmJob<Fq>> hp[NS - 4];
     {
-        MsmJob<Fq>* gj[4] = {&j0, &j1, &j3, &j4};
-        for (int k = 0; k < 4; k++)
-            if (g1[k].fbw_table) {
-                gj[k]->fbw_table = (const G1Affine*)g1[k].fbw_table;
-                gj[k]->fbw_c = g1[k].fbw_c;
-                gj[k]->fbw_nwin = g1[k].fbw_nwin;
-                gj[k]->fbw_stride = g1[k].fbw_stride;
+        const size_t n = g1[0].n, chunk = (n + parts - 1) / parts;
+        for (int k = 0; k < parts; k++) {
+            const size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
+            const int slot = k == 0 ? 0 : 4 + k;
+            const uint32_t* sc = g1[0].scalars ? g1[0].scalars + 8 * lo : nullptr;
+            const uint32_t* ix = g1[0].index ? g1[0].index + lo : nullptr;
+            if (ix) sc = g1[0].scalars;   // scalars are addressed through the index
+            hp[k].reset(new MsmJob<Fq>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const G1Affine*)g1[0].bases + lo, sc, ix,
+                                       hi - lo, &hout[k]));
+            hp[k]->dense = g1[0].dense;
+            if (g1[0].fbw_table) {
+                hp[k]->fbw_table = (const G1Affine*)g1[0].fbw_table + lo;   // row w of the part starts at w * stride + lo
+                hp[k]->fbw_c = g1[0].fbw_c;
+                hp[k]->fbw_nwin = g1[0].fbw_nwin;
+                hp[k]->fbw_stride = g1[0].fbw_stride;
+            }
+            if (parts > 1) {
+                hp[k]->ev_sorted = ctx->part_ev[2 * k];
+                hp[k]->ev_acc = ctx->part_ev[2 * k + 1];
+                if (k > 0) hp[k]->dep = hp[k - 1].get();
+            }
+        }
+    }
+    {
+        MsmJob<Fq>* gj[3] = {&j1, &j3, &j4};
+        for (int k = 0; k < 3; k++)
+            if (g1[k + 1].fbw_table) {
+                gj[k]->fbw_table = (const G1Affine*)g1[k + 1].fbw_table;
+                gj[k]->fbw_c = g1[k + 1].fbw_c;
+                gj[k]->fbw_nwin = g1[k + 1].fbw_nwin;
+                gj[k]->fbw_stride = g1[k + 1].fbw_stride;
             }
         if (g2.fbw_table) {
             j2.fbw_table = (const G2Affine*)g2.fbw_table;
@@ -1114,8 +1170,14 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
             j2.fbw_stride = g2.fbw_stride;
         }
     }
-    MsmJobBase* jobs[5] = {&j2, &j1, &j3, &j4, &j0};
-    return run_jobs(ctx, jobs, 5);
+    // the G2 job has the longest chain: first; h (gated on the NTT) last, its parts in order
+    MsmJobBase* jobs[4 + NS - 4] = {&j2, &j1, &j3, &j4};
+    for (int k = 0; k < parts; k++) jobs[4 + k] = hp[k].get();
+    ZG_TRY(run_jobs(ctx, jobs, 4 + parts));
+    G1XYZZ h = hout[0];
+    for (int k = 1; k < parts; k++) h = h.add(hout[k]);
+    out1[0] = h;
+    return ZG_OK;
 }
 
 // table[w * stride + i] = 2^(c*w) * bases[i], affine, w = 0 .. nwin-1 (row 0 is a copy of the bases)
@@ -1170,7 +1232,7 @@ int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_i
 }
 
 void msm_scratch_free(Ctx* ctx) {
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < Ctx::MSM_SLOTS; k++) {
         if (ctx->msm_scratch[k]) {
             if (ctx->msm_scratch[k]->host) (void)hipHostFree(ctx->msm_scratch[k]->host);
             delete ctx->msm_scratch[k];
@@ -1178,7 +1240,8 @@ void msm_scratch_free(Ctx* ctx) {
         }
     }
     if (ctx->side_ready) {
-        for (int k = 0; k < 5; k++) (void)hipStreamDestroy(ctx->side[k]);
+        for (int k = 0; k < Ctx::MSM_SLOTS; k++) (void)hipStreamDestroy(ctx->side[k]);
+        for (int k = 0; k < 2 * (Ctx::MSM_SLOTS - 4); k++) (void)hipEventDestroy(ctx->part_ev[k]);
         (void)hipEventDestroy(ctx->side_ev);
         ctx->side_ready = false;
     }

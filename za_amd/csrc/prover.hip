@@ -6,6 +6,7 @@
 // Everything heavy runs in HIP kernels; the host only sequences launches and does the O(1)
 // final group arithmetic.  There is no CPU fallback: zg_init fails without a GPU.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <memory>
@@ -33,6 +34,9 @@ int fail(Ctx* ctx, int code, const char* fmt, ...) {
     }
     return code;
 }
+
+static std::atomic<int> g_live_ctx{0};
+int live_contexts() { return g_live_ctx.load(); }
 
 static double now_ms() {
     using namespace std::chrono;
@@ -211,6 +215,7 @@ extern "C" int zg_init(int device, zg_ctx** out) {
         return ZG_E_HIP;
     }
     c->stream = c->own_stream;
+    g_live_ctx.fetch_add(1);
     *out = c;
     return ZG_OK;
 }
@@ -228,6 +233,7 @@ extern "C" void zg_free(zg_ctx* ctx) {
     delete ctx->prove_ws;
     ctx->prove_ws = nullptr;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    g_live_ctx.fetch_sub(1);
     delete ctx;
 }
 extern "C" const char* zg_strerror(int code) {
