@@ -534,3 +534,24 @@ def test_table_budget_falls_back_to_the_plain_schedule(ctx, monkeypatch):
     b = ctx.prove(P2, R, sr.witness, 3, 4)
     assert a == b
     sr.close()
+
+
+@pytest.mark.parametrize("parts", ["2", "3", "4"])
+def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts):
+    """The h multiexp split into dependent parts over consecutive base ranges (ZA_AMD_H_PARTS) against the single
+    job, with and without the window table."""
+    from za_amd import synth
+    lg = 15
+    sr = synth.SynthR1CS(lg, 2, 0.9, 808)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P = synth.synth_params(ctx, *sizes, 23)
+    monkeypatch.setenv("ZA_AMD_H_PARTS", "1")
+    want = ctx.prove(P, R, sr.witness, 21, 22)
+    monkeypatch.setenv("ZA_AMD_H_PARTS", parts)
+    assert ctx.prove(P, R, sr.witness, 21, 22) == want
+    monkeypatch.setenv("ZA_AMD_FBW", "0")
+    P2 = synth.synth_params(ctx, *sizes, 23)
+    assert ctx.prove(P2, R, sr.witness, 21, 22) == want
+    sr.close()
