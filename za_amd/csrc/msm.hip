@@ -4,7 +4,7 @@
 // prover/src/groth16/prover.rs:173).  Bellman runs one CPU thread per c-bit window with 2^c-1
 // Jacobian buckets, skips exponent 0 and adds exponent-1 bases straight into the accumulator; the
 // result is a group element, so any bucket schedule gives the same point.
-// GPU schedule (all kernels on ctx->stream):
+// GPU schedule (one job = one stream; the h job of a proof runs as two dependent parts, see msm_batch5):
 //   0. k_classify   counts scalars equal to 0, equal to 1, and the rest; the window size c is planned
 //                   from the number of "real" scalars (a 97%-bit witness needs far fewer buckets)
 //   1. k_part<0/1>, k_part_local   signed c-bit digits of every scalar, sorted by bucket with a two-level LDS
@@ -13,6 +13,7 @@
 //                   scalar share ONE bucket set and the position selects the table row.
 //   2. scans        exclusive prefix sums: bucket offsets and "item" offsets (an item = up to T points
 //                   of one bucket, so work per thread is bounded for any scalar distribution)
+//   3. k_item_*     items ordered by length (counting sort, longest first): the 64 lanes of a wave run equal loops
 //   4. k_accumulate one thread per item: gather affine bases (dwordx4 loads), XYZZ mixed adds   [dominant]
 //   5. k_bits_level / k_rowsum   bucket reduction by bit planes: per window S = sum of buckets and
 //                   T_j = sum of the buckets with index bit j set; plain sums only, four adds per thread and level
