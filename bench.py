@@ -269,6 +269,8 @@ def main():
             "phases_ms_last_step": phases,
             "kernel_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "setup_s": t_setup,
+            "key_tables": {name: {"kind": ("none", "window", "subset-sum")[P.table_info(k)[0]],
+                                  "gb": P.table_info(k)[1] / 1e9} for k, name in enumerate(("h", "l", "a", "b_g1", "b_g2"))},
             "proof_sha": __import__("hashlib").sha256(bytes(proof)).hexdigest()[:16] if proof is not None else None,
         }
         if msm_line:

@@ -219,6 +219,11 @@ int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
  * ZA_AMD_FBW_MAX_GB caps them (default 60% of the free HBM); without room the plain per-window schedule is used.
  * Results are identical either way. */
 int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness);
+/* Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) currently has: kind 0 none, 1 window table (dense
+ * assignment), 2 subset-sum table (sums over groups of four positions, for an assignment that is at least 90 % zeros
+ * and ones: a group of four 0/1 scalars costs one mixed add instead of one per 1; 3.75x the query's footprint), and
+ * its size in bytes. */
+int zg_params_table_info(const zg_params* params, int which, int* kind, uint64_t* bytes);
 
 /* ---- verify (host CPU) ---------------------------------------------------------
  * zg_verify replaces bellman_ce::groth16::{prepare_verifying_key, verify_proof} (prover/src/groth16/prover.rs:191-200,

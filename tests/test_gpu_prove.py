@@ -412,13 +412,15 @@ def test_fixed_base_window_table_gives_the_same_proof_as_the_plain_schedule(ctx,
     per-window schedule (ZA_AMD_FBW=0) must agree byte for byte; both against the C oracle."""
     from za_amd import synth
     lg = 13
-    sr = synth.SynthR1CS(lg, 2, 0.5, 77)
+    sr = synth.SynthR1CS(lg, 2, 0.0, 77)      # a dense witness: every query qualifies for a window table
     R = sr.load(ctx)
     m = 1 << lg
     sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
     P_tab = synth.synth_params(ctx, *sizes, 31)
     d_w = ctx.upload(sr.witness)
     P_tab.prepare(R, d_w)          # h, l, a, b_g1 and b_g2 tables, sized from this witness
+    kinds = [P_tab.table_info(k)[0] for k in range(5)]
+    assert kinds == [1, 1, 1, 1, 1], kinds
     with_table = ctx.prove_dev(P_tab, R, d_w, 5, 6)
     ctx.free(d_w)
     monkeypatch.setenv("ZA_AMD_FBW", "0")
@@ -555,3 +557,43 @@ def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts):
     P2 = synth.synth_params(ctx, *sizes, 23)
     assert ctx.prove(P2, R, sr.witness, 21, 22) == want
     sr.close()
+
+
+def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch):
+    """An all-0/1 witness takes the subset-sum ("quad") tables for l and a.  Rows (u - v + w) * 1 = w give the a and l
+    queries pairs of opposite points in neighbouring positions (their subset sum is the identity), rows
+    (x + y) * 1 = z pairs of equal points; proof against the C oracle, the plain schedule, and the pairing check."""
+    import za_amd
+    rng = np.random.default_rng(7)
+    w = [1, 1]                       # ONE, one public input (a constant 1)
+    cons = []
+    for _ in range(260):
+        b = int(rng.integers(0, 2)); c = int(rng.integers(0, 2))
+        u = len(w); w.append(b)
+        v = len(w); w.append(b)
+        x = len(w); w.append(c)
+        cons.append(([(u, 1), (v, bn.R - 1), (x, 1)], [(0, 1)], [(x, 1)]))       # opposite points for u, v
+        p, q = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        while p + q == 2:
+            p, q = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        y = len(w); w.append(p)
+        z = len(w); w.append(q)
+        s_ = len(w); w.append(p + q)                                                # 0 or 1
+        cons.append(([(y, 1), (z, 1)], [(0, 1)], [(s_, 1)]))                        # equal points for y, z
+    cons.append(([(1, 1)], [(0, 1)], [(1, 1)]))
+    r1 = g.R1CS(2, len(w) - 2, cons)
+    assert r1.is_satisfied(w) and r1.num_aux >= 1024
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, pbytes = ctx.setup(R, 0x91, 0x82, 0x73, 0x64, 0x55)
+    wb = co.witness_bytes(w)
+    d_w = ctx.upload(np.frombuffer(wb, dtype=np.uint8))
+    P.prepare(R, d_w)
+    assert [P.table_info(k)[0] for k in (1, 2)] == [2, 2]        # subset-sum tables for l and a
+    got = ctx.prove_dev(P, R, d_w, 1234, 5678)
+    assert co.prove(download_params(ctx, P), csr, wb, 1234, 5678, threads=4) == got
+    assert za_amd.verify(pbytes, got, [1]) is True
+    monkeypatch.setenv("ZA_AMD_FBW", "0")
+    P2, _ = ctx.setup(R, 0x91, 0x82, 0x73, 0x64, 0x55)
+    assert ctx.prove_dev(P2, R, d_w, 1234, 5678) == got
+    ctx.free(d_w)

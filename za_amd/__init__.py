@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
-    "zg_params_prepare",
+    "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
@@ -368,6 +368,12 @@ class Params:
         """Build the fixed-base window tables now (otherwise the first prove with this key does it); without a
         device witness only the h query's table."""
         self.ctx._check(self.ctx.lib.zg_params_prepare(self.ctx.h, self.h, r1cs.h, C.c_void_p(d_witness)))
+
+    def table_info(self, which):
+        """(kind, bytes): kind 0 none, 1 window table, 2 subset-sum table."""
+        k, b = C.c_int(), C.c_uint64()
+        self.ctx._check(self.ctx.lib.zg_params_table_info(self.h, C.c_int(which), C.byref(k), C.byref(b)))
+        return k.value, b.value
 
     def close(self):
         if self.h:

@@ -136,7 +136,12 @@ struct MsmDesc {
     const void* fbw_table = nullptr;
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
+    // optional subset-sum table for a mostly-0/1 assignment: [n bases][15 sums per 4 positions]
+    const void* quad_table = nullptr;
 };
+int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
+int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);
+size_t msm_quad_entries(size_t n);
 bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out);
 int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table);
 int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table);

@@ -31,6 +31,7 @@ struct zg_params {
     struct Fbw {
         zg::DevBuf buf;
         int c = 0, nwin = 0;
+        int kind = 0;    // 0 = window table, 1 = subset-sum ("quad") table
         uint64_t n = 0;
         int state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit / does not pay
     };

@@ -214,9 +214,9 @@ __device__ __forceinline__ bool scalar_is_one(const Scalar256& s) {
 // MODE 1: tile_tab holds the exclusive scan of that table; pairs are written to A[pos] = {val, low bits}
 template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
-                                              size_t n, int c, int nwin, int kw, uint32_t vstride, int hb, int lb,
-                                              uint32_t ntiles, uint32_t* __restrict__ tile_tab, uint2* __restrict__ A,
-                                              uint32_t* __restrict__ sorted) {
+                                              size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
+                                              int lb, uint32_t ntiles, uint32_t* __restrict__ tile_tab,
+                                              uint2* __restrict__ A, uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_bins[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;  // last bin: scalars == 1
     const uint32_t wsel = kw == 1 ? 0u : ~0u;            // folded windows (fbw table): the window goes into the value
@@ -228,10 +228,28 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
     const uint32_t lomask = (1u << lb) - 1u;
     for (uint32_t k = threadIdx.x; k < (uint32_t)PART_TP; k += blockDim.x) {
         const size_t i = base + k;
-        if (i >= n) break;
-        Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
-        if (scalar_is_zero(s)) continue;
-        if (scalar_is_one(s)) {
+        const bool live = i < n;
+        Scalar256 s;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s.w[q] = 0;
+        if (live) s = load_scalar(scalars, index ? (size_t)index[i] : i);
+        const bool one = live && scalar_is_one(s), zero = !live || scalar_is_zero(s);
+        if (quad_n) {
+            // Subset-sum table (msm_quad_build): the four lanes of an aligned group of positions whose scalars are
+            // all 0 or 1 emit ONE entry, the table's sum over the positions holding a 1.
+            const uint64_t mo = __ballot(one), mr = __ballot(!one && !zero);
+            const uint32_t qb = lane_id() & ~3u;
+            const uint32_t q_ones = (uint32_t)(mo >> qb) & 15u, q_real = (uint32_t)(mr >> qb) & 15u;
+            if (q_real == 0) {
+                if (one && (lane_id() & 3u) == (uint32_t)__builtin_ctz(q_ones)) {
+                    uint32_t pos = atomicAdd(&lds_bins[nbins - 1], 1u);
+                    if (MODE == 1) sorted[pos] = quad_n + 15u * (uint32_t)(i >> 2) + q_ones - 1u;
+                }
+                continue;
+            }
+        }
+        if (zero) continue;
+        if (one) {
             uint32_t pos = atomicAdd(&lds_bins[nbins - 1], 1u);
             if (MODE == 1) sorted[pos] = (uint32_t)i;   // the ones bin is one bucket and the last bin: final order
             continue;
@@ -717,6 +735,7 @@ struct MsmJob : MsmJobBase {
     size_t n;
     XYZZ<F>* out;
     bool dense = false;   // plan from n directly, no k_classify round trip
+    const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
     const Affine<F>* fbw_table = nullptr;   // fixed-base window table: [fbw_nwin][fbw_stride] affine points
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
@@ -797,8 +816,9 @@ struct MsmJob : MsmJobBase {
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
+        const uint32_t quad_n = quad_table && !fbw_table ? (uint32_t)n : 0u;
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
+                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -810,7 +830,7 @@ struct MsmJob : MsmJobBase {
                                S.bsum.as<uint32_t>());
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
+                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
@@ -877,7 +897,7 @@ struct MsmJob : MsmJobBase {
                          chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
             acc_prof = ps.idx;
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
-                               fbw_table ? fbw_table : d_bases,
+                               fbw_table ? fbw_table : quad_table ? quad_table : d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, P.T, ones_key,
                                S.partial.as<XYZZ<F>>());
@@ -1157,6 +1177,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     }
     {
         MsmJob<Fq>* gj[3] = {&j1, &j3, &j4};
+        for (int k = 0; k < 3; k++) gj[k]->quad_table = (const G1Affine*)g1[k + 1].quad_table;
+        j2.quad_table = (const G2Affine*)g2.quad_table;
         for (int k = 0; k < 3; k++)
             if (g1[k + 1].fbw_table) {
                 gj[k]->fbw_table = (const G1Affine*)g1[k + 1].fbw_table;
@@ -1213,6 +1235,39 @@ int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride,
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
+
+// Subset-sum ("quad") table for a query whose assignment is mostly 0 / 1: out[15 * g + m - 1] = sum of
+// bases[4g + j] over the bits j of m (m = 1 .. 15), affine.  A group of four 0/1 scalars then costs one mixed add
+// (15/16 on average) instead of one per 1 (2 on average).  3.75x the query's footprint.
+template <class F>
+__global__ void __launch_bounds__(256) k_quad_build(const Affine<F>* __restrict__ bases, size_t n, Affine<F>* __restrict__ out) {
+    using L = typename LazyOf<F>::L;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t groups = (n + 3) / 4;
+    if (t >= groups * 15) return;
+    const size_t g = t / 15;
+    const uint32_t m = (uint32_t)(t - g * 15) + 1u;
+    XYZZd<L> acc = XYZZd<L>::inf();
+    for (int j = 0; j < 4; j++) {
+        const size_t i = 4 * g + j;
+        if (!((m >> j) & 1u) || i >= n) continue;
+        acc = acc.add_mixed(AffD<L>::load(&bases[i]));
+    }
+    acc.to_affine_mem(&out[t]);
+}
+template <class F>
+static int quad_build(Ctx* ctx, const Affine<F>* d_bases, size_t n, Affine<F>* d_buf) {
+    if (n == 0) return ZG_OK;
+    ZG_HIP(ctx, hipMemcpyAsync(d_buf, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t threads = (n + 3) / 4 * 15;
+    hipLaunchKernelGGL((k_quad_build<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n,
+                       d_buf + n);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf) { return quad_build<Fq>(ctx, d_bases, n, d_buf); }
+int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf) { return quad_build<Fq2>(ctx, d_bases, n, d_buf); }
+size_t msm_quad_entries(size_t n) { return n + (n + 3) / 4 * 15; }
 
 // blocking: how many of the n scalars (through the index indirection) are 0 / 1
 int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,

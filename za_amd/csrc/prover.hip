@@ -839,14 +839,31 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
             ZG_TRY(msm_classify_counts(ctx, use[k].scalars, use[k].index, n, &zeros, &ones));
             n_real = n - zeros - ones;
         }
-        // a mostly-0/1 assignment leaves few digits to save, and gathering them from an nwin-times larger table
-        // costs more than that (measured at 2^22: b_g2 accumulation 1.5 -> 2.1 ms with 3% real scalars)
-        if (n_real < 64 || n_real * 2 < n) continue;
         size_t free_b = 0, total_b = 0;
         ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
         size_t budget = (size_t)((double)free_b * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
+        if (k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
+            // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
+            const size_t entries = msm_quad_entries(n);
+            if (entries * elem > budget || entries >= (1ull << 31) || t.buf.alloc(entries * elem) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;
+            }
+            if (k == 4)
+                ZG_TRY(msm_quad_build_g2(ctx, (const G2Affine*)use[k].bases, n, t.buf.as<G2Affine>()));
+            else
+                ZG_TRY(msm_quad_build_g1(ctx, (const G1Affine*)use[k].bases, n, t.buf.as<G1Affine>()));
+            ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            t.kind = 1;
+            t.n = n;
+            t.state = 1;
+            continue;
+        }
+        // few real scalars leave few digits to save, and gathering them from an nwin-times larger table costs more
+        // than that (measured at 2^22: b_g2 accumulation 1.5 -> 2.1 ms with 3% real scalars)
+        if (n_real < 64 || n_real * 2 < n) continue;
         int c = 0, nwin = 0;
         if (!msm_fbw_plan(n_real, n, budget, elem, &c, &nwin)) continue;
         if (t.buf.alloc((size_t)nwin * n * elem) != hipSuccess) {
@@ -860,6 +877,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         t.c = c;
         t.nwin = nwin;
+        t.kind = 0;
         t.n = n;
         t.state = 1;
     }
@@ -899,6 +917,15 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
     return ZG_OK;
 }
 
+extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) {
+    if (!p || which < 0 || which > 4 || !kind || !bytes) return ZG_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    const auto& t = p->fbw[which];
+    *kind = t.state == 1 ? (t.kind == 1 ? 2 : 1) : 0;
+    *bytes = t.state == 1 ? t.buf.bytes : 0;
+    return ZG_OK;
+}
+
 extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness) {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -925,7 +952,9 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
         const auto& t = p->fbw[k];
-        if (use[k].n && t.state == 1 && t.n == use[k].n) {
+        if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
+            d.quad_table = t.buf.p;
+        } else if (use[k].n && t.state == 1 && t.n == use[k].n) {
             d.fbw_table = t.buf.p;
             d.fbw_c = t.c;
             d.fbw_nwin = t.nwin;
