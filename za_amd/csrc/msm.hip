@@ -98,7 +98,6 @@ static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
     p.nkeys = p.B;
     size_t mean = (n * (size_t)nwin + p.B - 1) / p.B;
     size_t T = 2 * mean;
-    if (const char* e = getenv("ZG_X_FBW_T")) T = atoi(e);   // EXPERIMENT
     if (T < 16) T = 16;
     if (T > 512) T = 512;
     p.T = (uint32_t)T;
