@@ -35,7 +35,7 @@ namespace zg {
 
 static constexpr int MAXWIN = 128;
 static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
-static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket
+static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (upper limit; see item_sizes)
 
 struct MsmScratch {
     DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], dbuf[2], ones[2], bsum, meta, heavy;
@@ -296,9 +296,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
     return wave_off + x - v;
 }
 
-// items of bucket idx: the ones bucket (idx == nkeys - 1) uses T_ONES points per item
+// The kernels take both item sizes in one word: points per item of a regular bucket | points per item of the ones
+// bucket << 16 (item_sizes() on the host).
 __device__ __forceinline__ uint32_t items_of(uint32_t cnt, uint32_t T, uint32_t idx, uint32_t nkeys) {
-    const uint32_t t = idx + 1 == nkeys ? T_ONES : T;
+    const uint32_t t = idx + 1 == nkeys ? T >> 16 : T & 0xffffu;
     return (cnt + t - 1) / t;
 }
 
@@ -488,7 +489,7 @@ __device__ __forceinline__ uint32_t item_size(uint32_t t, const uint32_t* __rest
                                               const uint32_t* __restrict__ item_off, const uint32_t* __restrict__ offsets,
                                               uint32_t T, uint32_t ones_key) {
     const uint32_t key = item_key[t];
-    const uint32_t Tk = key == ones_key ? T_ONES : T;
+    const uint32_t Tk = key == ones_key ? T >> 16 : T & 0xffffu;
     const uint32_t start = offsets[key] + (t - item_off[key]) * Tk;
     const uint32_t left = offsets[key + 1] - start;
     return left < Tk ? left : Tk;
@@ -555,7 +556,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
     if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
     if (perm) t = perm[t];              // items in order of decreasing length
     uint32_t key = item_key[t];
-    uint32_t Tk = key == ones_key ? T_ONES : T;
+    uint32_t Tk = key == ones_key ? T >> 16 : T & 0xffffu;
     uint32_t seg = t - item_off[key];
     uint32_t start = offsets[key] + seg * Tk;
     uint32_t end = offsets[key + 1];
@@ -742,6 +743,7 @@ struct MsmJob : MsmJobBase {
     int acc_prof = -1;
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
+    uint32_t t_ones = T_ONES, t_pack = 0;   // item sizes (regular | ones << 16) as the kernels take them
     int grid = 1;
     const XYZZ<F>* ones_ptr = nullptr;
     int red_nlev = 0, red_f[16], red_bitbase[16];   // bit-plane reduction levels (bits folded per level)
@@ -791,6 +793,19 @@ struct MsmJob : MsmJobBase {
         }
         if (dep && dep->ev_sorted) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_sorted, 0));
         P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : plan_msm(n_real, n_ones);
+        {   // Small jobs are latency bound: a thread runs its item's mixed adds one after the other (64 G2 adds are
+            // 1.1 ms whatever n is).  Below ~64K items the items are shortened -- down to half the mean bucket load, so
+            // that only buckets above twice the mean need the heavy-bucket fold -- and the GPU gets more, shorter threads.
+            const size_t entries = n_real * (size_t)P.nwin, target = 65536;
+            if (entries / P.T < target) {
+                size_t t2 = std::max<size_t>(8, entries / target);
+                t2 = std::max<size_t>(t2, (entries / P.nkeys + 1) / 2);
+                if (t2 < P.T) P.T = (uint32_t)t2;
+            }
+            t_ones = T_ONES;
+            if (n_ones / T_ONES < target / 2) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, n_ones / (target / 2)));
+            t_pack = P.T | (t_ones << 16);
+        }
         ones_key = P.nkeys;  // one extra bucket after the kw * B regular ones
         nkeys = P.nkeys + 1;
         // bucket bits split into high (level-1 bins) and low (level-2, in LDS) parts
@@ -837,10 +852,10 @@ struct MsmJob : MsmJobBase {
                            S.sorted.as<uint32_t>());
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
+        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
                            S.bsum.as<uint32_t>(), nb);
         hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, P.T,
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
                            S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                            (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
@@ -884,10 +899,10 @@ struct MsmJob : MsmJobBase {
             ZG_HIP(ctx, hipMemsetAsync(hist, 0, ITEM_CLASSES * 4, st));
             const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
             hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.offsets.as<uint32_t>(), nkeys, P.T, ones_key, hist);
+                               S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist);
             hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(64), 0, st, hist, hist + ITEM_CLASSES);
             hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
-                               S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, P.T, ones_key,
+                               S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key,
                                hist + ITEM_CLASSES, S.perm.as<uint32_t>());
         }
         {
@@ -898,7 +913,7 @@ struct MsmJob : MsmJobBase {
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
                                fbw_table ? fbw_table : quad_table ? quad_table : d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, P.T, ones_key,
+                               S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, t_pack, ones_key,
                                S.partial.as<XYZZ<F>>());
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
