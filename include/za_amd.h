@@ -252,7 +252,9 @@ int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline
  * line.  id: 0 msm_accumulate_g1, 1 msm_accumulate_g2, 2 msm_digit_sort, 3 msm_bucket_reduce,
- * 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval.  alg_bytes = algorithmic HBM bytes of the timed launches. */
+ * 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval.  alg_bytes = algorithmic HBM bytes of the timed launches.
+ * zg_profile_enable: 0 off, 1 = classes 0 and 1 only (the dominant kernels: about five event pairs per proof),
+ * 2 = every class (about a hundred event pairs per proof, which cost 0.5 ms of a proof's wall time). */
 #define ZG_PROFILE_KERNELS 7
 int zg_profile_enable(zg_ctx* ctx, int on);
 int zg_profile_reset(zg_ctx* ctx);

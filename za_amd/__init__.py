@@ -301,8 +301,10 @@ class Context:
                                               _ptr(out)))
         return out.tobytes()
 
-    def profile_enable(self, on=True):
-        self._check(self.lib.zg_profile_enable(self.h, C.c_int(int(on))))
+    def profile_enable(self, level=2):
+        """0 off, 1 = accumulation kernels only, 2 (or True) = every kernel class."""
+        level = 2 if level is True else int(level)
+        self._check(self.lib.zg_profile_enable(self.h, C.c_int(level)))
 
     def profile_reset(self):
         self._check(self.lib.zg_profile_reset(self.h))

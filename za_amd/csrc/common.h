@@ -21,7 +21,7 @@ struct Ctx {
     std::string last_error;
     double timings[6] = {0, 0, 0, 0, 0, 0};
     // optional per-kernel timing with HIP events on `stream` (zg_profile_*)
-    bool prof_enabled = false;
+    int prof_enabled = 0;   // 0 off, 1 = the accumulation kernels only (about 5 scopes per proof), 2 = every class
     struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes, units; };
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per scope cost 0.3 ms per proof)
@@ -52,7 +52,7 @@ struct ProfScope {
     hipStream_t st;
     ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr, uint64_t units = 0)
         : c(ctx), st(stream ? stream : ctx->stream) {
-        if (!ctx->prof_enabled) return;
+        if (ctx->prof_enabled < (id == PROF_MSM_ACC_G1 || id == PROF_MSM_ACC_G2 ? 1 : 2)) return;
         std::lock_guard<std::mutex> lock(ctx->prof_mu);
         Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes, units};
         for (hipEvent_t* e : {&p.e0, &p.e1}) {

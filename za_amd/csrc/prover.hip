@@ -300,7 +300,7 @@ extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) {
 // ------------------------------------------------------------------------------------------------ profiling
 extern "C" int zg_profile_enable(zg_ctx* ctx, int on) {
     if (!ctx) return ZG_E_INVALID_ARG;
-    ctx->prof_enabled = on != 0;
+    ctx->prof_enabled = on < 0 ? 0 : on > 2 ? 2 : on;
     return ZG_OK;
 }
 static int prof_drain(zg_ctx* ctx) {
