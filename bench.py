@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--provers", type=int, default=2,
+    ap.add_argument("--provers", type=int, default=3,
                     help="extra line: throughput with this many concurrent provers on the GPU (1 = skip); the headline "
                          "value is always one proof at a time")
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
