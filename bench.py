@@ -200,7 +200,7 @@ def main():
         # second prover's NTT phase fills the low-occupancy sort / reduction tails of the first one's h multiexp
         import threading
         ctxs = [ctx] + [za_amd.Context(local_rank) for _ in range(args.provers - 1)]
-        per = max(2, (2 * args.steps) // args.provers)
+        per = max(4, args.steps)
         outs = [None] * args.provers
 
         def work(i, k):
