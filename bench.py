@@ -263,6 +263,16 @@ def main():
             roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "achieved": mads / (acc_ms * 1e-3),
                                      "peak": 467.5e9 * 64, "frac": mads / (acc_ms * 1e-3) / (467.5e9 * 64),
                                      "mixed_adds_per_launch": acc_units / acc_n}
+            # all VALU instructions, not only the multiplications' mads: instructions per mixed add from the
+            # SQ_INSTS_VALU pass (profiles/r01_pmc_valu_instructions.json) against the same measured issue rate
+            vpath = os.path.join(ROOT, "profiles", "r01_pmc_valu_instructions.json")
+            if os.path.exists(vpath):
+                try:
+                    ipm = json.load(open(vpath))["k_accumulate_g1_valu_instructions_per_wave_mixed_add"]
+                    roof["alu_secondary"]["valu_instructions_per_mixed_add"] = ipm
+                    roof["alu_secondary"]["issue_frac"] = acc_units * ipm / (acc_ms * 1e-3) / (467.5e9 * 64)
+                except Exception:
+                    pass
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
