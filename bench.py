@@ -37,6 +37,9 @@ def parse():
                     help="extra line: throughput with this many concurrent provers on the GPU (1 = skip); the headline "
                          "value is always one proof at a time")
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "poseidon"],
+                    help="synthetic = config-4-shaped random R1CS (the headline); poseidon = circomlib Poseidon(t=6) hash "
+                         "chain padded to 2^log_m (BASELINE config 3: use --log-m 20), generated in Python (~15 s at 2^20)")
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
     ap.add_argument("--cpu-log-m", type=int, default=22, help="size of the bounded CPU-baseline sample (2^22 = the GPU workload itself, ~10 s of CPU)")
@@ -126,8 +129,27 @@ def main():
 
     # ---- workload (untimed set-up): R1CS + witness + proving key resident in HBM
     t_setup = time.time()
-    sr = synth.SynthR1CS(args.log_m, 2, args.bit_fraction, args.seed)
-    r1 = sr.load(ctx)
+    if args.workload == "poseidon":
+        from za_amd import workloads
+
+        class _W:      # the fields of synth.SynthR1CS the rest of the script uses
+            pass
+        sr = _W()
+        sr.n_inputs, sr.n_aux, cons, wit, hashes = workloads.poseidon_chain(args.log_m)
+        sr.n_constraints = len(cons)
+        rp, cl, cf = workloads.csr_arrays(cons)
+        sr.nnz = [len(c) for c in cl]
+        sr.witness = workloads.witness_bytes(wit)
+        sr.close = lambda: None
+        r1 = ctx.r1cs_load(sr.n_inputs, sr.n_aux, sr.n_constraints, rp, cl, cf)
+        n_perm = len(hashes)
+        del cons, wit, rp, cl, cf
+        if args.synthetic_key or world > 1:
+            print("--workload poseidon runs on one GPU with a key from zg_setup", file=sys.stderr)
+            sys.exit(2)
+    else:
+        sr = synth.SynthR1CS(args.log_m, 2, args.bit_fraction, args.seed)
+        r1 = sr.load(ctx)
     m = 1 << args.log_m
     n_a = sr.n_inputs + r1.a_aux_total
     n_b = r1.b_input_total + r1.b_aux_total
@@ -278,7 +300,10 @@ def main():
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 Montgomery (256-bit modular integer)", "data": "synthetic",
-            "config": {"workload": "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
+            "config": {"workload": ("Poseidon(t=6, RF=8, RP=57, circomlib parameters) hash chain of %d permutations, config 3 "
+                                    "shape, padded to n_constraints + n_inputs = 2^%d, proving key from zg_setup"
+                                    % (n_perm, args.log_m)) if args.workload == "poseidon" else
+                                   "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
                                    "seed 0x%x), n_constraints + n_inputs = 2^%d, %s"
                                    % (100 * args.bit_fraction, args.seed, args.log_m,
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
@@ -297,7 +322,7 @@ def main():
             line["g1_msm"] = msm_line
         if conc_line:
             line["concurrent_provers"] = conc_line
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "synthetic":
             try:
                 line["cpu_baseline"] = cpu_baseline(ctx, args)
             except Exception as e:  # the bench line must still come out
