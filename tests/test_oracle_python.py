@@ -129,3 +129,20 @@ def test_poseidon_chain_generator_is_pinned_by_the_reference_known_answers():
     assert r1.is_satisfied(w)
     bad = list(w); bad[1] = (bad[1] + 1) % ci.R
     assert not r1.is_satisfied(bad)
+
+
+def test_workload_csr_arrays_match_the_oracle_layout():
+    """za_amd.workloads (bench.py's circuit generator) hands zg_r1cs_load the same CSR arrays and witness bytes as the
+    oracle's own conversion of the same constraint list."""
+    import numpy as np
+    from oracle import circuits as ci, coracle as co
+    from za_amd import workloads as wl
+    n_inputs, n_aux, cons, w, hs = wl.poseidon_chain(11, n_perm=1)
+    r1, w2, hs2 = ci.poseidon_chain_r1cs(11, n_perm=1)
+    assert (w, hs) == (w2, hs2) and r1.is_satisfied(w)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    rp, cl, cf = wl.csr_arrays(cons)
+    for k in range(3):
+        assert np.array_equal(rp[k], csr.row_ptr[k]) and np.array_equal(cl[k], csr.col[k]) and np.array_equal(cf[k], csr.coeff[k])
+    assert wl.witness_bytes(w) == co.witness_bytes(w)
+    assert wl.R == ci.R
