@@ -122,6 +122,10 @@ void zg_r1cs_free(zg_r1cs* r);
 /* n_inputs, n_aux, n_constraints, log_m, a_aux_density_total, b_input_density_total,
  * b_aux_density_total */
 int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]);
+/* Constraints::satisfies_with_signals (prover/src/groth16/prover.rs:155, compiler/src/types/constraint.rs:29-67), on the
+ * GPU: *first_bad = index of the first constraint with <A,w><B,w> != <C,w>, or UINT64_MAX if all hold.  witness32 is a
+ * host pointer (canonical LE, as for zg_prove). */
+int zg_r1cs_check(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint64_t* first_bad);
 /* Evaluate a = A*w, b = B*w, c = C*w on the GPU (n_constraints + n_inputs rows each, Montgomery LE). */
 int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint8_t* a_out,
                  uint8_t* b_out, uint8_t* c_out);
@@ -142,6 +146,10 @@ int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const uint8_t* h, s
                         const uint8_t* b_g1, size_t n_b_g1, const uint8_t* b_g2, size_t n_b_g2,
                         int rank, int world, zg_params** out);
 void zg_params_free(zg_params* p);
+/* Parameters::write (prover/src/groth16/format.rs:250) of a resident key that carries its verifying key (one loaded by
+ * zg_params_load / zg_pk_load or made by zg_setup*; world = 1).  *written always receives the size; ZG_E_BUFFER_TOO_SMALL
+ * if cap is insufficient (or out is NULL). */
+int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, size_t cap, size_t* written);
 /* Skip za's proving-key container header (u32be-len AST blob, constraints, ignore_signals;
  * prover/src/groth16/format.rs:223-247) and return the offset of the bellman Parameters body. */
 int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
@@ -237,6 +245,28 @@ int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t proof[256], 
 /* vk JSON exactly as JsonVerifyingKey::to_json emits it (prover/src/groth16/format.rs:130-167): fields alpha_g1,
  * beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2, ic, input_names; names = n_names NUL-terminated strings back to back. */
 int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out, size_t cap);
+
+/* The readers: JsonVerifyingKey::{from_json, to_bellman} (prover/src/groth16/format.rs:169-194) and
+ * JsonProofAndInput::json_to_bellman (format.rs:101-121).  Coordinates are strings holding a decimal or a 0x-prefixed
+ * hexadecimal number (str_to_fq -> FS::parse, format.rs:33-36, compiler/src/algebra/fs.rs:43-55) below q, points must lie
+ * on their curve (try_from_coordinates; G2 also in the order-r subgroup); public inputs are what Fr::from_str accepts
+ * (canonical decimal below r) -- anything else is ZG_E_BAD_FORMAT with a Rust-Debug-shaped message in
+ * zg_last_error_thread() (`BadFormat("bad format")`, `Json("missing field `ic`")`, ...).  Every struct field must be
+ * present (serde), unknown fields are ignored.
+ * zg_vk_from_json writes bellman VerifyingKey::write bytes (the form zg_verify / zg_vk_json / zg_verifier_solidity
+ * take); *written always receives the size needed.  zg_proof_from_json writes the 256-byte proof and n canonical-LE
+ * public inputs (ZG_E_BUFFER_TOO_SMALL if cap_inputs < 32 n; *n_public is set either way).  No GPU, no ctx. */
+int zg_vk_from_json(const char* json, uint8_t* vk_out, size_t cap, size_t* written);
+int zg_proof_from_json(const char* json, uint8_t proof_out[256], uint8_t* public_inputs32, size_t cap_inputs,
+                       size_t* n_public);
+/* generate_solidity (prover/src/groth16/ethereum.rs:216-261): the verifier contract `za setup` writes by default
+ * (cli/src/main.rs:33), G2 coordinates printed c1 first (ethereum.rs:28-31,231-236), numbers as FqRepr prints them.
+ * names: the public input names, n_names NUL-terminated strings back to back (`// input = [...]` and the length of
+ * verifyTx's input array).  *written = bytes needed including the NUL. */
+int zg_verifier_solidity(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out,
+                         size_t cap, size_t* written);
+/* Message of the last failing call made by THIS thread (ctx-less entry points have no zg_last_error). Never NULL. */
+const char* zg_last_error_thread(void);
 
 /* ---- formats ---------------------------------------------------------------------------------
  * proof.json exactly as JsonProofAndInput::write emits it (prover/src/groth16/format.rs:80-128):

@@ -49,3 +49,44 @@ def poseidon_chain_r1cs(log_m, n_perm=None):
     """(R1CS, witness, [hash values]) of za_amd.workloads.poseidon_chain."""
     n_inputs, n_aux, cons, w, hashes = poseidon_chain(log_m, n_perm)
     return R1CS(n_inputs, n_aux, cons), w, hashes
+
+
+# ----------------------------------------------------------------------------- R1CS with a prescribed H polynomial
+def prescribed_h_r1cs(log_m, h):
+    """(R1CS, witness) whose quotient polynomial H has exactly the coefficients `h` (m - 1 values, m = 2^log_m).
+
+    One public input (ONE) and m - 1 rows u_i * v_i = t_i over fresh aux variables, so bellman's domain is exactly m
+    (it appends the row a = ONE, b = c = 0).  With A(x) = x^(m-1)/omega (a_i = omega^(-i-1), and a_(m-1) = 1 as the
+    appended row needs) and B(x) = sum_k beta_k x^k one gets A*B = (1/omega) sum_k beta_k x^(m-1+k), i.e.
+    H = (1/omega) sum_(k>=1) beta_k x^(k-1): beta_(j+1) = omega h_j, and beta_0 makes B vanish at omega^(m-1).
+    Lets a test put 0, 1, r - 1 ... into the dense h multiexp, which random circuits never do."""
+    from .groth16 import Domain
+    from .bn254 import inv
+    m = 1 << log_m
+    assert len(h) == m - 1 and log_m >= 1
+    d = Domain(log_m)
+    w_ = d.omega
+    beta = [0] + [hj * w_ % R for hj in h]
+    winv = d.omegainv
+    acc, p = 0, winv
+    for k in range(1, m):
+        acc = (acc + beta[k] * p) % R
+        p = p * winv % R
+    beta[0] = (-acc) % R
+    b = list(beta)
+    d.fft(b)                      # b[i] = B(omega^i)
+    assert b[m - 1] == 0
+    a = []
+    p = winv                      # a_i = omega^(-i-1)
+    for _ in range(m):
+        a.append(p)
+        p = p * winv % R
+    assert a[m - 1] == 1
+    w = [1]
+    cons = []
+    for i in range(m - 1):
+        u = len(w)
+        w += [a[i], b[i], a[i] * b[i] % R]
+        cons.append(([(u, 1)], [(u + 1, 1)], [(u + 2, 1)]))
+    r1 = R1CS(1, len(w) - 1, cons)
+    return r1, w

@@ -600,3 +600,127 @@ def proof_bytes(proof):
     A, B, C = proof
     return (fq_be(A[0].v) + fq_be(A[1].v) + fq_be(B[0].c0) + fq_be(B[0].c1) + fq_be(B[1].c0)
             + fq_be(B[1].c1) + fq_be(C[0].v) + fq_be(C[1].v))
+
+
+# ----------------------------------------------------------------------------- vk JSON, JSON readers, Solidity export
+def fs_parse(s):
+    """FS::parse (compiler/src/algebra/fs.rs:43-55): `0x` + hex digits, else decimal digits; not reduced."""
+    if s.startswith("0x"):
+        body, base, what = s[2:], 16, "hexadecimal"
+    else:
+        body, base, what = s, 10, "decimal"
+    digits = "0123456789abcdefABCDEF" if base == 16 else "0123456789"
+    if not body or any(ch not in digits for ch in body):
+        raise ValueError('Algebra(InvalidFormat("%s is not %s"))' % (s, what))
+    return int(body, base)
+
+
+def _str_to_fq(s):
+    """str_to_fq (format.rs:33-36); Fq::from_str only exists below q (the reference unwrap()s)."""
+    v = fs_parse(s)
+    if v >= Q:
+        raise ValueError('BadFormat("%s is not a field element")' % s)
+    return v
+
+
+def _g1_from_j(j):
+    if not isinstance(j, list) or len(j) != 2 or not all(isinstance(x, str) for x in j):
+        raise ValueError("Json")
+    P = (Fq(_str_to_fq(j[0])), Fq(_str_to_fq(j[1])))
+    if not is_on_curve(P, G1_B):
+        raise ValueError('BadFormat("bad coordinates")')
+    return P
+
+
+def _g2_from_j(j):
+    if not (isinstance(j, list) and len(j) == 2 and all(isinstance(x, list) and len(x) == 2 for x in j)):
+        raise ValueError("Json")
+    P = (Fq2(_str_to_fq(j[0][0]), _str_to_fq(j[0][1])), Fq2(_str_to_fq(j[1][0]), _str_to_fq(j[1][1])))
+    if not is_on_curve(P, G2_B):
+        raise ValueError('BadFormat("bad coordinates")')
+    return P
+
+
+def _g1_j(P):
+    if P is None:
+        raise ValueError('BadFormat("invalid point")')
+    return [fq_repr_str(P[0].v), fq_repr_str(P[1].v)]
+
+
+def _g2_j(P):
+    if P is None:
+        raise ValueError('BadFormat("invalid point")')
+    return [[fq_repr_str(P[0].c0), fq_repr_str(P[0].c1)], [fq_repr_str(P[1].c0), fq_repr_str(P[1].c1)]]
+
+
+def vk_json(vk, input_names=()):
+    """JsonVerifyingKey::from_bellman(..).with_input_names(..).to_json() (format.rs:130-167,191-193): serde emits the
+    fields in declaration order alpha_g1, beta_g1, beta_g2, delta_g1, delta_g2, gamma_g2, ic, input_names."""
+    obj = {"alpha_g1": _g1_j(vk.alpha_g1), "beta_g1": _g1_j(vk.beta_g1), "beta_g2": _g2_j(vk.beta_g2),
+           "delta_g1": _g1_j(vk.delta_g1), "delta_g2": _g2_j(vk.delta_g2), "gamma_g2": _g2_j(vk.gamma_g2),
+           "ic": [_g1_j(p) for p in vk.ic], "input_names": list(input_names)}
+    return json.dumps(obj, separators=(",", ":"), ensure_ascii=False)
+
+
+def vk_from_json(text):
+    """JsonVerifyingKey::from_json + to_bellman (format.rs:169-194)."""
+    j = json.loads(text)
+    for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "gamma_g2", "ic", "input_names"):
+        if k not in j:
+            raise ValueError("Json(missing field `%s`)" % k)
+    return VerifyingKey(_g1_from_j(j["alpha_g1"]), _g1_from_j(j["beta_g1"]), _g2_from_j(j["beta_g2"]),
+                        _g2_from_j(j["gamma_g2"]), _g1_from_j(j["delta_g1"]), _g2_from_j(j["delta_g2"]),
+                        [_g1_from_j(p) for p in j["ic"]])
+
+
+def vk_bytes(vk):
+    """bellman VerifyingKey::write = the prefix of Parameters::write."""
+    return b"".join([g1_uncompressed(vk.alpha_g1), g1_uncompressed(vk.beta_g1), g2_uncompressed(vk.beta_g2),
+                     g2_uncompressed(vk.gamma_g2), g1_uncompressed(vk.delta_g1), g2_uncompressed(vk.delta_g2),
+                     struct.pack(">I", len(vk.ic))] + [g1_uncompressed(x) for x in vk.ic])
+
+
+def proof_from_json(text):
+    """JsonProofAndInput::json_to_bellman (format.rs:101-121): coordinates through FS::parse (decimal or 0x hex),
+    public inputs through Fr::from_str (canonical decimal below r only) -> BadFormat("bad format")."""
+    j = json.loads(text)
+    for k in ("a", "b", "c", "public_inputs"):
+        if k not in j:
+            raise ValueError("Json(missing field `%s`)" % k)
+    proof = (_g1_from_j(j["a"]), _g2_from_j(j["b"]), _g1_from_j(j["c"]))
+    pub = []
+    for s in j["public_inputs"]:
+        ok = isinstance(s, str) and s != "" and all(ch in "0123456789" for ch in s) and (s == "0" or s[0] != "0")
+        if not ok or int(s) >= R:
+            raise ValueError('BadFormat("bad format")')
+        pub.append(int(s))
+    return proof, pub
+
+
+def rust_debug_vec_str(names):
+    """format!("{:?}", Vec<String>) for the printable-ASCII names circuits have."""
+    def one(s):
+        return '"' + s.replace("\\", "\\\\").replace('"', '\\"') + '"'
+    return "[" + ", ".join(one(s) for s in names) + "]"
+
+
+def solidity_verifier(template, vk, input_names):
+    """generate_solidity (prover/src/groth16/ethereum.rs:216-261) applied to `template` (the CONTRACT_TEMPLATE text,
+    ethereum.rs:8-214 -- the caller supplies it; this module does not carry it).  G2 coordinates are printed c1
+    first (:231-236)."""
+    def s1(P):
+        return "%s,%s" % (fq_repr_str(P[0].v), fq_repr_str(P[1].v))
+
+    def s2(P):
+        return "[%s,%s],[%s,%s]" % (fq_repr_str(P[0].c1), fq_repr_str(P[0].c0), fq_repr_str(P[1].c1), fq_repr_str(P[1].c0))
+    c = template
+    c = c.replace("<%vk_a%>", s1(vk.alpha_g1))
+    c = c.replace("<%vk_b%>", s2(vk.beta_g2))
+    c = c.replace("<%vk_gamma%>", s2(vk.gamma_g2))
+    c = c.replace("<%vk_delta%>", s2(vk.delta_g2))
+    c = c.replace("<%vk_inputs_length%>", "%d" % len(input_names))
+    c = c.replace("<%vk_inputs%>", rust_debug_vec_str(input_names))
+    c = c.replace("<%vk_gammaABC_length%>", "%d" % len(vk.ic))
+    c = c.replace("<%vk_gammaABC_pts%>", "\n".join("vk.gammaABC[%d] = Pairing.G1Point(%s);" % (i, s1(x))
+                                                     for i, x in enumerate(vk.ic)))
+    return c

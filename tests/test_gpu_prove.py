@@ -597,3 +597,55 @@ def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch):
     P2, _ = ctx.setup(R, 0x91, 0x82, 0x73, 0x64, 0x55)
     assert ctx.prove_dev(P2, R, d_w, 1234, 5678) == got
     ctx.free(d_w)
+
+
+def test_h_coefficient_equal_to_one_single_constraint(ctx):
+    """The dense (h) multiexp must not lose a scalar equal to 1 (round-1 defect: k_part sent it to the ones bin, which
+    a dense job never reduces).  x * (2 ONE) = 2x with x = 3 has H = [1]: m = 2, one h base."""
+    import za_amd
+    r1 = g.R1CS(1, 1, [([(1, 1)], [(0, 2)], [(1, 2)])])
+    w = [1, 3]
+    assert g.h_coefficients(r1, w) == [1]
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    td = (0x15, 0x26, 0x37, 0x48, 0x59)
+    P, pbytes = ctx.setup(R, *td)
+    params, _ = g.generate_parameters(r1, *td)
+    assert pbytes == g.params_write(params)
+    exp = g.create_proof(r1, params, w, 21, 34)
+    got = ctx.prove(P, R, co.witness_bytes(w), 21, 34)
+    assert got == g.proof_bytes(exp)
+    assert za_amd.verify(pbytes, got, []) is True
+
+
+@pytest.mark.parametrize("lg,fbw,parts", [(5, None, None), (12, None, None), (12, "0", None), (13, None, "2"), (13, "0", "3")])
+def test_dense_h_job_with_zero_one_and_extreme_coefficients(ctx, monkeypatch, lg, fbw, parts):
+    """H prescribed coefficient by coefficient (oracle/circuits.py::prescribed_h_r1cs): runs of 0 and 1, r - 1, 2,
+    2^253-ish and random values, through the window-table schedule, the plain per-window schedule and the h job in
+    parts -- proof bytes against the C oracle with the same (GPU-made) key."""
+    import random
+    import za_amd
+    from oracle.circuits import prescribed_h_r1cs
+    if fbw is not None:
+        monkeypatch.setenv("ZA_AMD_FBW", fbw)
+    if parts is not None:
+        monkeypatch.setenv("ZA_AMD_H_PARTS", parts)
+    rng = random.Random(1000 + lg)
+    m = 1 << lg
+    pool = [0, 1, 1, 1, 2, bn.R - 1, bn.R - 2, (1 << 253) + 1, 1 << 20, (1 << 20) - 1]
+    h = [rng.choice(pool) if rng.random() < 0.7 else rng.randrange(bn.R) for _ in range(m - 1)]
+    h[0] = 1
+    h[-1] = 1
+    for k in range(8, min(40, m - 1)):
+        h[k] = 1 if k < 24 else 0          # a run of ones and a run of zeros inside one sort tile
+    r1, w = prescribed_h_r1cs(lg, h)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    wb = co.witness_bytes(w)
+    a, b, c, *_ = co.r1cs_eval(csr, wb, threads=4)
+    hb = co.h_coeffs(a, b, c, m, lg, threads=4)
+    assert [int.from_bytes(bytes(hb[32 * i:32 * i + 32]), "little") for i in range(m - 1)] == h
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, pbytes = ctx.setup(R, 0x1A, 0x2B, 0x3C, 0x4D, 0x5E)
+    got = ctx.prove(P, R, wb, 0x777, 0x999)
+    assert co.prove(download_params(ctx, P), csr, wb, 0x777, 0x999, threads=8) == got
+    assert za_amd.verify(pbytes, got, []) is True

@@ -37,12 +37,13 @@ ABI_SYMBOLS = [
     "zg_msm_g1", "zg_msm_g2", "zg_msm_g1_dev", "zg_msm_g2_dev",
     "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
-    "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_pk_params_offset",
+    "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
+    "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
 
@@ -73,6 +74,7 @@ def load_library():
         lib = C.CDLL(LIB_PATH)
         lib.zg_strerror.restype = C.c_char_p
         lib.zg_last_error.restype = C.c_char_p
+        lib.zg_last_error_thread.restype = C.c_char_p
         lib.zg_free.restype = None
         lib.zg_r1cs_free.restype = None
         lib.zg_params_free.restype = None
@@ -342,6 +344,13 @@ class R1CS:
         self.ctx._check(self.ctx.lib.zg_r1cs_eval(self.ctx.h, self.h, _ptr(w), _ptr(a), _ptr(b), _ptr(c)))
         return a, b, c
 
+    def check(self, witness):
+        """Index of the first unsatisfied constraint, or None (Constraints::satisfies_with_signals, prover.rs:155)."""
+        w = _u8(witness)
+        bad = C.c_uint64()
+        self.ctx._check(self.ctx.lib.zg_r1cs_check(self.ctx.h, self.h, _ptr(w), C.byref(bad)))
+        return None if bad.value == 0xFFFFFFFFFFFFFFFF else bad.value
+
     def close(self):
         if self.h:
             self.ctx.lib.zg_r1cs_free(self.h)
@@ -415,6 +424,63 @@ def vk_json(vk_bytes, input_names=()):
                         C.c_size_t(cap))
     if rc:
         raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return buf.value.decode()
+
+
+def _thread_error(lib, rc):
+    return ZaAmdError(rc, "%s: %s" % (lib.zg_strerror(rc).decode(), lib.zg_last_error_thread().decode()))
+
+
+def vk_from_json(text):
+    """JsonVerifyingKey::from_json + to_bellman (format.rs:169-194) -> bellman VerifyingKey::write bytes."""
+    lib = load_library()
+    t = text.encode() if isinstance(text, str) else bytes(text)
+    need = C.c_size_t()
+    rc = lib.zg_vk_from_json(t, None, C.c_size_t(0), C.byref(need))
+    if rc != ZG_E_BUFFER_TOO_SMALL:
+        raise _thread_error(lib, rc)
+    out = np.zeros(need.value, dtype=np.uint8)
+    rc = lib.zg_vk_from_json(t, _ptr(out), C.c_size_t(out.size), C.byref(need))
+    if rc:
+        raise _thread_error(lib, rc)
+    return out.tobytes()
+
+
+def proof_from_json(text):
+    """JsonProofAndInput::json_to_bellman (format.rs:101-121) -> (256 proof bytes, [public inputs as ints])."""
+    lib = load_library()
+    t = text.encode() if isinstance(text, str) else bytes(text)
+    proof = np.zeros(256, dtype=np.uint8)
+    n = C.c_size_t()
+    cap = 32 * 64
+    while True:
+        pub = np.zeros(cap, dtype=np.uint8)
+        rc = lib.zg_proof_from_json(t, _ptr(proof), _ptr(pub), C.c_size_t(cap), C.byref(n))
+        if rc == ZG_E_BUFFER_TOO_SMALL and 32 * n.value > cap:
+            cap = 32 * n.value
+            continue
+        if rc:
+            raise _thread_error(lib, rc)
+        break
+    vals = [int.from_bytes(pub[32 * i:32 * i + 32].tobytes(), "little") for i in range(n.value)]
+    return proof.tobytes(), vals
+
+
+def verifier_solidity(vk_bytes, input_names=()):
+    """generate_solidity (ethereum.rs:216-261): the contract `za setup` writes for verifier type "solidity"."""
+    lib = load_library()
+    v = _u8(vk_bytes)
+    names = b"".join(n.encode() + b"\0" for n in input_names)
+    need = C.c_size_t()
+    rc = lib.zg_verifier_solidity(_ptr(v), C.c_size_t(v.size), names if input_names else None, C.c_size_t(len(input_names)),
+                                  None, C.c_size_t(0), C.byref(need))
+    if rc != ZG_E_BUFFER_TOO_SMALL:
+        raise _thread_error(lib, rc)
+    buf = C.create_string_buffer(need.value)
+    rc = lib.zg_verifier_solidity(_ptr(v), C.c_size_t(v.size), names if input_names else None, C.c_size_t(len(input_names)),
+                                  buf, C.c_size_t(need.value), C.byref(need))
+    if rc:
+        raise _thread_error(lib, rc)
     return buf.value.decode()
 
 

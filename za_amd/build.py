@@ -8,8 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libza_amd.so")
-SOURCES = ["msm.hip", "ntt.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip"]
-HEADERS = ["fp.h", "fd.h", "ec.h", "ecd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
+LIB_ZA2C = os.path.join(HERE, "libza2c.so")     # the outer drop-in boundary: za's C binding symbols (csrc/za2c.cpp)
+DRIVER = os.path.join(HERE, "za-gpu")           # `za setup|prove` shaped command-line driver (csrc/za_gpu_main.cpp)
+SOURCES = ["msm.hip", "ntt.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip", "outer.hip"]
+HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc"]
 
@@ -60,6 +62,21 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # libza2c.so (verbose / setup / prove / verify over the C ABI) and the za-gpu driver: plain host C++
+    za2c_src = os.path.join(CSRC, "za2c.cpp")
+    if force or jobs or _stale(LIB_ZA2C, [za2c_src, LIB, os.path.join(HERE, "..", "include", "za_amd.h")]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_ZA2C, za2c_src, "-L" + HERE, "-lza_amd",
+               "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("libza2c build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    main_src = os.path.join(CSRC, "za_gpu_main.cpp")
+    if force or _stale(DRIVER, [main_src, LIB_ZA2C]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", DRIVER, main_src, "-L" + HERE, "-lza2c", "-lza_amd",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + HERE]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("za-gpu build failed:\n%s\n%s" % (r.stdout, r.stderr))
     return LIB
 
 

@@ -37,11 +37,16 @@ struct Ctx {
     hipStream_t side[MSM_SLOTS] = {nullptr};
     hipEvent_t side_ev = nullptr;
     hipEvent_t part_ev[2 * (MSM_SLOTS - 4)] = {nullptr};   // (sorted, accumulated) per part of the h job
-    hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip)
+    hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip): borrowed pointers
+    hipEvent_t gate_w = nullptr, gate_h = nullptr;     // the ctx's own gate events (created lazily, destroyed by zg_free)
+    bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
+// Every extern "C" entry point is a function-try-block ending in `return on_exception(ctx)`: no C++ exception
+// (std::bad_alloc from a container sized by untrusted input, ...) crosses the C boundary.
+int on_exception(Ctx* ctx);
 int live_contexts();   // zg_ctx handles currently alive in this process (prover.hip)
 
 // kernel classes timed by the profiling facility

@@ -19,6 +19,10 @@ struct ParsedParams {
 int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed);
 // Parameters::write -- reference call site prover/src/groth16/format.rs:250.
 void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out);
+// VerifyingKey::read / write: the prefix of the Parameters body up to and including ic (alpha_g1, beta_g1, beta_g2,
+// gamma_g2, delta_g1, delta_g2, u32be |ic|, ic); points are curve- and subgroup-checked.
+int parse_bellman_vk(Ctx* ctx, const uint8_t* buf, size_t len, ParsedParams* out);
+void write_bellman_vk(const ParsedParams& p, std::vector<uint8_t>* out);
 // za proving-key container header (format.rs:223-247): returns offset of the Parameters body.
 int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
 // proof.json (format.rs:80-128)
@@ -40,6 +44,8 @@ int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal
                             size_t len, uint8_t* witness_out);
 
 Fq2 g2_coeff_b();                       // 3/(9+u), Montgomery
+bool g2_in_subgroup(const G2Affine& p); // [r]P == identity (the twist has a large cofactor; G1's is 1)
+bool scalar_is_canonical(const uint32_t v[8]);   // v < r
 void fq_to_be(uint8_t out[32], const Fq& mont);
 bool fq_from_be(const uint8_t in[32], Fq* mont);  // false if >= q
 

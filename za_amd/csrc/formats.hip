@@ -14,6 +14,18 @@ Fq2 g2_coeff_b() {
     return three * xi.inv();
 }
 
+bool g2_in_subgroup(const G2Affine& p) {
+    if (p.is_inf()) return true;
+    return G2XYZZ::from_affine(p).mul(FrParams::MOD).is_inf();
+}
+bool scalar_is_canonical(const uint32_t v[8]) {
+    for (int i = 7; i >= 0; i--) {
+        if (v[i] < FrParams::MOD[i]) return true;
+        if (v[i] > FrParams::MOD[i]) return false;
+    }
+    return false;
+}
+
 void fq_to_be(uint8_t out[32], const Fq& mont) {
     Fq c = mont.from_mont();
     for (int i = 0; i < 32; i++) out[i] = (uint8_t)(c.l[(31 - i) >> 2] >> (8 * ((31 - i) & 3)));
@@ -35,7 +47,7 @@ bool fq_from_be(const uint8_t in[32], Fq* mont) {
 
 namespace {
 
-enum PointStatus { PT_OK = 0, PT_COMPRESSED, PT_BAD_INFINITY, PT_NOT_IN_FIELD, PT_NOT_ON_CURVE };
+enum PointStatus { PT_OK = 0, PT_COMPRESSED, PT_BAD_INFINITY, PT_NOT_IN_FIELD, PT_NOT_ON_CURVE, PT_NOT_IN_SUBGROUP };
 
 // pairing_ce bn256 G1Uncompressed: x || y big-endian; byte0 bit7 = compression flag (must be clear),
 // bit6 = identity (then everything else must be zero).
@@ -69,6 +81,9 @@ PointStatus read_g2(const uint8_t* b, bool checked, const Fq2& coeff_b, G2Affine
         !fq_from_be(b + 96, &p.y.c0))
         return PT_NOT_IN_FIELD;
     if (checked && !on_curve(p, coeff_b)) return PT_NOT_ON_CURVE;
+    // into_affine() of a G2Uncompressed also checks the subgroup (one multiplication by r per point, as bellman's
+    // checked Parameters::read pays); G1 needs none (cofactor 1)
+    if (checked && !g2_in_subgroup(p)) return PT_NOT_IN_SUBGROUP;
     *out = p;
     return PT_OK;
 }
@@ -79,6 +94,7 @@ const char* status_str(PointStatus s) {
         case PT_BAD_INFINITY: return "unexpected information in infinity encoding";
         case PT_NOT_IN_FIELD: return "coordinate is not in the field";
         case PT_NOT_ON_CURVE: return "point is not on the curve";
+        case PT_NOT_IN_SUBGROUP: return "point is not in the correct subgroup";
         default: return "ok";
     }
 }
@@ -218,11 +234,24 @@ static void put_u32be(std::vector<uint8_t>* o, uint32_t v) {
     o->push_back((uint8_t)(v >> 8)); o->push_back((uint8_t)v);
 }
 
-void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out) {
+void write_bellman_vk(const ParsedParams& p, std::vector<uint8_t>* out) {
     put_g1(out, p.alpha_g1); put_g1(out, p.beta_g1); put_g2(out, p.beta_g2); put_g2(out, p.gamma_g2);
     put_g1(out, p.delta_g1); put_g2(out, p.delta_g2);
     put_u32be(out, (uint32_t)p.ic.size());
     for (auto& x : p.ic) put_g1(out, x);
+}
+int parse_bellman_vk(Ctx* ctx, const uint8_t* buf, size_t len, ParsedParams* out) {
+    // reuse the Parameters parser on a buffer that ends after ic by appending five empty queries
+    const size_t need = 64 + 64 + 128 + 128 + 64 + 128 + 4;
+    if (len < need) return fail(ctx, ZG_E_IO, "verifying key: unexpected end");
+    const uint32_t n = ((uint32_t)buf[need - 4] << 24) | ((uint32_t)buf[need - 3] << 16) | ((uint32_t)buf[need - 2] << 8) | buf[need - 1];
+    if ((size_t)n > (len - need) / 64) return fail(ctx, ZG_E_IO, "verifying key: ic exceeds the buffer");
+    std::vector<uint8_t> tmp(buf, buf + need + (size_t)n * 64);
+    tmp.resize(tmp.size() + 20, 0);   // h, l, a, b_g1, b_g2 with zero entries
+    return parse_bellman_params(ctx, tmp.data(), tmp.size(), true, out, nullptr);
+}
+void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out) {
+    write_bellman_vk(p, out);
     for (const std::vector<G1Affine>* v : {&p.h, &p.l, &p.a, &p.b_g1}) {
         put_u32be(out, (uint32_t)v->size());
         for (auto& x : *v) put_g1(out, x);
@@ -339,6 +368,8 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated AST blob");
     uint32_t nc;
     if (!rd.u32be(&nc)) return fail(ctx, ZG_E_IO, "pk: truncated constraint count");
+    // a constraint takes at least its u32 length prefix + three u64 term counts: bound the allocation by the buffer
+    if ((size_t)nc > (len - rd.pos) / 28) return fail(ctx, ZG_E_IO, "pk: %u constraints do not fit the container", nc);
     struct Term { uint64_t sig; Fr coeff; };
     std::vector<std::vector<Term>> lcs[3];
     for (int k = 0; k < 3; k++) lcs[k].resize(nc);
@@ -363,6 +394,7 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     }
     uint32_t ni;
     if (!rd.u32be(&ni)) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
+    if ((size_t)ni > (len - rd.pos) / 4) return fail(ctx, ZG_E_IO, "pk: %u ignored signals do not fit the container", ni);
     std::vector<uint32_t> ignore(ni);
     for (uint32_t i = 0; i < ni; i++)
         if (!rd.u32be(&ignore[i])) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");

@@ -1,6 +1,7 @@
 // Opaque handle layouts behind include/za_amd.h (shared by prover.hip and synth.hip).
 #pragma once
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -22,6 +23,10 @@ struct zg_r1cs {
 struct zg_params {
     zg::G1Affine alpha_g1, beta_g1, delta_g1;
     zg::G2Affine beta_g2, delta_g2;
+    // the rest of the verifying key (kept when the key came from Parameters::read or from zg_setup; empty for keys built
+    // from raw arrays): zg_params_write needs it
+    zg::G2Affine gamma_g2 = zg::G2Affine::inf();
+    std::vector<zg::G1Affine> ic;
     struct Query {
         zg::DevBuf buf;
         uint64_t total = 0, lo = 0, hi = 0;

@@ -215,7 +215,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
                                               size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
                                               int lb, uint32_t ntiles, uint32_t* __restrict__ tile_tab,
-                                              uint2* __restrict__ A, uint32_t* __restrict__ sorted) {
+                                              uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin) {
     extern __shared__ uint32_t lds_bins[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;  // last bin: scalars == 1
     const uint32_t wsel = kw == 1 ? 0u : ~0u;            // folded windows (fbw table): the window goes into the value
@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
 #pragma unroll
         for (int q = 0; q < 8; q++) s.w[q] = 0;
         if (live) s = load_scalar(scalars, index ? (size_t)index[i] : i);
-        const bool one = live && scalar_is_one(s), zero = !live || scalar_is_zero(s);
+        // use_ones_bin == 0 (dense jobs, which queue the accumulation without reading the ones bucket's size back):
+        // a scalar equal to 1 takes the digit path like any other value (digit 1 of window 0)
+        const bool one = use_ones_bin && live && scalar_is_one(s), zero = !live || scalar_is_zero(s);
         if (quad_n) {
             // Subset-sum table (msm_quad_build): the four lanes of an aligned group of positions whose scalars are
             // all 0 or 1 emit ONE entry, the table's sum over the positions holding a 1.
@@ -832,9 +834,10 @@ struct MsmJob : MsmJobBase {
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
-        const uint32_t quad_n = quad_table && !fbw_table ? (uint32_t)n : 0u;
+        const uint32_t quad_n = quad_table && !fbw_table && !dense ? (uint32_t)n : 0u;
+        const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
+                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -846,7 +849,8 @@ struct MsmJob : MsmJobBase {
                                S.bsum.as<uint32_t>());
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>());
+                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
+                           use_ones_bin);
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),

@@ -166,18 +166,9 @@ struct Vk {
 
 }  // namespace
 
-// bellman VerifyingKey::read == the prefix of Parameters::write (format.rs:250): alpha_g1, beta_g1, beta_g2,
-// gamma_g2, delta_g1, delta_g2, u32be |ic|, ic
 static int parse_vk(Ctx* ctx, const uint8_t* buf, size_t len, Vk* vk) {
-    // reuse the Parameters parser on a buffer that ends after ic by appending five empty queries
-    size_t need = 64 + 64 + 128 + 128 + 64 + 128 + 4;
-    if (len < need) return fail(ctx, ZG_E_IO, "verifying key: unexpected end");
-    uint32_t n = ((uint32_t)buf[need - 4] << 24) | ((uint32_t)buf[need - 3] << 16) | ((uint32_t)buf[need - 2] << 8) | buf[need - 1];
-    if ((size_t)n * 64 > len - need) return fail(ctx, ZG_E_IO, "verifying key: ic exceeds the buffer");
-    std::vector<uint8_t> tmp(buf, buf + need + (size_t)n * 64);
-    tmp.resize(tmp.size() + 20, 0);   // h, l, a, b_g1, b_g2 with zero entries
     ParsedParams pp;
-    ZG_TRY(parse_bellman_params(ctx, tmp.data(), tmp.size(), true, &pp, nullptr));
+    ZG_TRY(parse_bellman_vk(ctx, buf, len, &pp));
     vk->alpha_g1 = pp.alpha_g1; vk->beta_g1 = pp.beta_g1; vk->delta_g1 = pp.delta_g1;
     vk->beta_g2 = pp.beta_g2; vk->gamma_g2 = pp.gamma_g2; vk->delta_g2 = pp.delta_g2;
     vk->ic = pp.ic;
@@ -210,7 +201,7 @@ using namespace zg;
 
 // proof: 256 bytes (A.x A.y B.x.c0 B.x.c1 B.y.c0 B.y.c1 C.x C.y canonical big-endian)
 extern "C" int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t proof[256], const uint8_t* public_inputs32,
-                         size_t n_public, int* ok) {
+                         size_t n_public, int* ok) try {
     if (!vk_bytes || !proof || !ok || (n_public && !public_inputs32)) return ZG_E_INVALID_ARG;
     *ok = 0;
     Ctx tmp;
@@ -225,10 +216,14 @@ extern "C" int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t p
         return ZG_E_BAD_FORMAT;
     if (!on_curve(A, Fq::from_u64(3)) || !on_curve(C, Fq::from_u64(3)) || !on_curve(B, g2_coeff_b()))
         return ZG_E_BAD_FORMAT;   // try_from_coordinates fails: "bad coordinates" (format.rs:41-44)
+    // G1 has cofactor 1; a B outside the order-r subgroup of the twist is not a group element bellman can hold
+    if (!g2_in_subgroup(B)) return ZG_E_BAD_FORMAT;
     G1XYZZ acc = G1XYZZ::from_affine(vk.ic[0]);
     for (size_t i = 0; i < n_public; i++) {
         uint32_t k[8];
         memcpy(k, public_inputs32 + 32 * i, 32);
+        // Fr::from_str rejects values >= r ("bad format", format.rs:112-116): x and x + r would verify alike
+        if (!scalar_is_canonical(k)) return ZG_E_BAD_FORMAT;
         acc = acc.add(G1XYZZ::from_affine(vk.ic[i + 1]).mul(k));
     }
     Fq12 f = miller_loop(B, A);
@@ -237,11 +232,13 @@ extern "C" int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t p
     f = f * miller_loop(vk.delta_g2, C.neg());
     *ok = f.pow(FINAL_EXP, 44) == Fq12::one() ? 1 : 0;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 // vk JSON as JsonVerifyingKey serialises it (prover/src/groth16/format.rs:130-167): alpha_g1, beta_g1, beta_g2,
 // delta_g1, delta_g2, gamma_g2, ic, input_names.  names: n_names NUL-terminated strings back to back (may be NULL).
-extern "C" int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out, size_t cap) {
+extern "C" int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* names, size_t n_names, char* out, size_t cap) try {
     if (!vk_bytes || !out) return ZG_E_INVALID_ARG;
     Ctx tmp;
     Vk vk;
@@ -274,4 +271,6 @@ extern "C" int zg_vk_json(const uint8_t* vk_bytes, size_t vk_len, const char* na
     if (j.size() >= cap) return ZG_E_BUFFER_TOO_SMALL;
     memcpy(out, j.c_str(), j.size() + 1);
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }

@@ -21,18 +21,33 @@
 
 namespace zg {
 
+// ctx-less entry points (zg_verify, the JSON readers, ...) report through a per-thread message (zg_last_error_thread)
+static thread_local std::string t_last_error;
 int fail(Ctx* ctx, int code, const char* fmt, ...) {
     static std::mutex mu;   // the MSM jobs of a proof report from their own threads
-    std::lock_guard<std::mutex> lock(mu);
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_last_error = buf;
     if (ctx) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof(buf), fmt, ap);
-        va_end(ap);
+        std::lock_guard<std::mutex> lock(mu);
         ctx->last_error = buf;
     }
     return code;
+}
+
+int on_exception(Ctx* ctx) {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, ZG_E_IO, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(ctx, ZG_E_IO, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(ctx, ZG_E_IO, "unexpected exception");
+    }
 }
 
 static std::atomic<int> g_live_ctx{0};
@@ -111,6 +126,17 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, uint64
     const uint64_t row = first_row + i;
     const uint64_t dst = rev_bits ? (uint64_t)(__brev((uint32_t)row) >> (32 - rev_bits)) : row;
     FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a[dst]);
+}
+
+// first row with a*b != c (mod r): atomicMin over the row index
+__global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
+                                                    uint64_t n_rows, unsigned long long* __restrict__ first_bad) {
+    uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const FrD ab = FrD::load_red(&a[row]) * FrD::load_red(&b[row]);   // a*b in M261 needs one factor out of Montgomery form:
+    // a = x*R, b = y*R  ->  a*b = x*y*R (Montgomery product); c = z*R: compare directly
+    const FrD d = FrD::sub<3>(ab, FrD::load_red(&c[row]));
+    if (!d.is_zero_mod_p()) atomicMin(first_bad, (unsigned long long)row);
 }
 
 struct ProveWs {
@@ -197,7 +223,7 @@ int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d
 using namespace zg;
 
 // ------------------------------------------------------------------------------------------------ ctx
-extern "C" int zg_init(int device, zg_ctx** out) {
+extern "C" int zg_init(int device, zg_ctx** out) try {
     if (!out) return ZG_E_INVALID_ARG;
     *out = nullptr;
     // five MSM streams + the main stream want their own hardware queues (ROCm's default is 4 per
@@ -218,6 +244,8 @@ extern "C" int zg_init(int device, zg_ctx** out) {
     g_live_ctx.fetch_add(1);
     *out = c;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 extern "C" void zg_free(zg_ctx* ctx) {
     if (!ctx) return;
@@ -230,6 +258,8 @@ extern "C" void zg_free(zg_ctx* ctx) {
         if (p.e1) (void)hipEventDestroy(p.e1);
     }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->gate_w) (void)hipEventDestroy(ctx->gate_w);
+    if (ctx->gate_h) (void)hipEventDestroy(ctx->gate_h);
     delete ctx->prove_ws;
     ctx->prove_ws = nullptr;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -257,51 +287,68 @@ extern "C" const char* zg_strerror(int code) {
     }
 }
 extern "C" const char* zg_last_error(const zg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
-extern "C" int zg_set_stream(zg_ctx* ctx, void* hip_stream) {
+extern "C" const char* zg_last_error_thread(void) { return t_last_error.c_str(); }
+extern "C" int zg_set_stream(zg_ctx* ctx, void* hip_stream) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_sync(zg_ctx* ctx) {
+extern "C" int zg_sync(zg_ctx* ctx) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_dev_alloc(zg_ctx* ctx, size_t bytes, void** d_ptr) {
+extern "C" int zg_dev_alloc(zg_ctx* ctx, size_t bytes, void** d_ptr) try {
     if (!ctx || !d_ptr) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_dev_free(zg_ctx* ctx, void* d_ptr) {
+extern "C" int zg_dev_free(zg_ctx* ctx, void* d_ptr) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZG_HIP(ctx, hipFree(d_ptr));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_h2d(zg_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+extern "C" int zg_h2d(zg_ctx* ctx, void* d_dst, const void* src, size_t bytes) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+extern "C" int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) {
+extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) try {
     if (!ctx || !ms) return ZG_E_INVALID_ARG;
     for (int i = 0; i < 6; i++) ms[i] = ctx->timings[i];
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ profiling
-extern "C" int zg_profile_enable(zg_ctx* ctx, int on) {
+extern "C" int zg_profile_enable(zg_ctx* ctx, int on) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ctx->prof_enabled = on < 0 ? 0 : on > 2 ? 2 : on;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 static int prof_drain(zg_ctx* ctx) {
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -319,25 +366,31 @@ static int prof_drain(zg_ctx* ctx) {
     ctx->prof_pending.clear();
     return ZG_OK;
 }
-extern "C" int zg_profile_reset(zg_ctx* ctx) {
+extern "C" int zg_profile_reset(zg_ctx* ctx) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_TRY(prof_drain(ctx));
     for (auto& s : ctx->prof) s = zg::Ctx::ProfStat();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
+extern "C" int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes) try {
     if (!ctx || id < 0 || id >= PROF_COUNT || !ms || !launches || !alg_bytes) return ZG_E_INVALID_ARG;
     ZG_TRY(prof_drain(ctx));
     *ms = ctx->prof[id].ms;
     *launches = ctx->prof[id].launches;
     *alg_bytes = ctx->prof[id].bytes;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) {
+extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) try {
     if (!ctx || id < 0 || id >= PROF_COUNT || !units) return ZG_E_INVALID_ARG;
     ZG_TRY(prof_drain(ctx));
     *units = ctx->prof[id].units;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" const char* zg_profile_name(int id) {
     static const char* names[] = {"msm_accumulate_g1", "msm_accumulate_g2", "msm_digit_sort", "msm_bucket_reduce",
@@ -410,15 +463,19 @@ static int msm_host(zg_ctx* ctx, const uint8_t* bases, size_t n_bases, const uin
     return ZG_OK;
 }
 extern "C" int zg_msm_g1(zg_ctx* ctx, const uint8_t* bases64, size_t n_bases, const uint8_t* scalars32,
-                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[96]) {
+                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[96]) try {
     return msm_host<Fq>(ctx, bases64, n_bases, scalars32, density_bits, n_scalars, out_jac);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" int zg_msm_g2(zg_ctx* ctx, const uint8_t* bases128, size_t n_bases, const uint8_t* scalars32,
-                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[192]) {
+                         const uint64_t* density_bits, size_t n_scalars, uint8_t out_jac[192]) try {
     return msm_host<Fq2>(ctx, bases128, n_bases, scalars32, density_bits, n_scalars, out_jac);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars, const uint32_t* d_scalar_index,
-                             size_t n, uint8_t out_jac[96]) {
+                             size_t n, uint8_t out_jac[96]) try {
     if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     G1XYZZ r;
@@ -429,9 +486,11 @@ extern "C" int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_sca
     ZG_TRY(msm_g1(ctx, tmp.as<G1Affine>(), (const uint32_t*)d_scalars, d_scalar_index, n, &r));
     jac_bytes(out_jac, r);
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars, const uint32_t* d_scalar_index,
-                             size_t n, uint8_t out_jac[192]) {
+                             size_t n, uint8_t out_jac[192]) try {
     if (!ctx || !out_jac) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     G2XYZZ r;
@@ -442,15 +501,19 @@ extern "C" int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_sca
     ZG_TRY(msm_g2(ctx, tmp.as<G2Affine>(), (const uint32_t*)d_scalars, d_scalar_index, n, &r));
     jac_bytes(out_jac, r);
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------ NTT / H API
-extern "C" int zg_ntt_fr_dev(zg_ctx* ctx, void* d_inout, uint32_t log_m, int inverse, int coset) {
+extern "C" int zg_ntt_fr_dev(zg_ctx* ctx, void* d_inout, uint32_t log_m, int inverse, int coset) try {
     if (!ctx || !d_inout) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     return ntt_fr_dev(ctx, (Fr*)d_inout, log_m, inverse != 0, coset != 0);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_ntt_fr(zg_ctx* ctx, uint8_t* inout, uint32_t log_m, int inverse, int coset) {
+extern "C" int zg_ntt_fr(zg_ctx* ctx, uint8_t* inout, uint32_t log_m, int inverse, int coset) try {
     if (!ctx || !inout) return ZG_E_INVALID_ARG;
     if (log_m >= 28) return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u >= 2^28", log_m);
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -462,9 +525,11 @@ extern "C" int zg_ntt_fr(zg_ctx* ctx, uint8_t* inout, uint32_t log_m, int invers
     ZG_HIP(ctx, hipMemcpyAsync(inout, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, size_t n_rows,
-                            uint32_t log_m, uint8_t* h_out) {
+                            uint32_t log_m, uint8_t* h_out) try {
     if (!ctx || !a || !b || !c || !h_out) return ZG_E_INVALID_ARG;
     if (log_m >= 28) return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "domain 2^%u >= 2^28", log_m);
     const size_t m = (size_t)1 << log_m;
@@ -486,12 +551,14 @@ extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, con
     if (m > 1) ZG_HIP(ctx, hipMemcpyAsync(h_out, dh.p, (m - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------ R1CS
 extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
                             const uint64_t* const row_ptr[3], const uint32_t* const col[3],
-                            const uint8_t* const coeff[3], zg_r1cs** out) {
+                            const uint8_t* const coeff[3], zg_r1cs** out) try {
     if (!ctx || !out || !row_ptr || !col || !coeff || n_inputs == 0) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -559,10 +626,12 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
     ZG_HIP(ctx, hipGetLastError());
     *out = r.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 // za proving key -> (R1CS, Parameters) in one call
 extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checked, int rank, int world, zg_r1cs** r1cs_out,
-                          zg_params** params_out) {
+                          zg_params** params_out) try {
     if (!ctx || !pk || !r1cs_out || !params_out) return ZG_E_INVALID_ARG;
     *r1cs_out = nullptr;
     *params_out = nullptr;
@@ -590,21 +659,27 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     *r1cs_out = r;
     *params_out = p;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" int zg_witness_from_binwitness(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* binwitness, size_t len,
-                                          uint8_t* witness32_out, size_t cap) {
+                                          uint8_t* witness32_out, size_t cap) try {
     if (!ctx || !r || !binwitness || !witness32_out) return ZG_E_INVALID_ARG;
     if (r->var_of_signal.empty()) return fail(ctx, ZG_E_INVALID_ARG, "this R1CS was not loaded from a za proving key");
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     if (cap < nv * 32) return ZG_E_BUFFER_TOO_SMALL;
     return witness_from_binwitness(ctx, r->var_of_signal, (uint32_t)nv, binwitness, len, witness32_out);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" void zg_r1cs_free(zg_r1cs* r) { delete r; }
-extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) {
+extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) try {
     if (!r || !info) return ZG_E_INVALID_ARG;
     info[0] = r->n_inputs; info[1] = r->n_aux; info[2] = r->n_constraints; info[3] = r->log_m;
     info[4] = r->a_aux_total; info[5] = r->b_in_total; info[6] = r->b_aux_total;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 // d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
@@ -647,8 +722,38 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
     return ZG_OK;
 }
 
+extern "C" int zg_r1cs_check(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint64_t* first_bad) try {
+    if (!ctx || !r || !first_bad) return ZG_E_INVALID_ARG;
+    if (!witness32) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    *first_bad = UINT64_MAX;
+    if (r->n_constraints == 0) return ZG_OK;
+    const size_t m = (size_t)1 << r->log_m, nv = (size_t)r->n_inputs + r->n_aux;
+    DevBuf dw, d[3], flag;
+    ZG_HIP(ctx, dw.alloc(nv * 32));
+    ZG_HIP(ctx, flag.alloc(8));
+    ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(ctx, hipMemsetAsync(flag.p, 0xff, 8, ctx->stream));
+    Fr* abc[3];
+    for (int k = 0; k < 3; k++) {
+        ZG_HIP(ctx, d[k].alloc(m * 32));
+        abc[k] = d[k].as<Fr>();
+    }
+    ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc, /*bitrev=*/false));
+    hipLaunchKernelGGL(k_r1cs_check, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, ctx->stream, abc[0],
+                       abc[1], abc[2], r->n_constraints, flag.as<unsigned long long>());
+    ZG_HIP(ctx, hipGetLastError());
+    unsigned long long h = 0;
+    ZG_HIP(ctx, hipMemcpyAsync(&h, flag.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *first_bad = (uint64_t)h;
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+
 extern "C" int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint8_t* a_out, uint8_t* b_out,
-                            uint8_t* c_out) {
+                            uint8_t* c_out) try {
     if (!ctx || !r || !a_out || !b_out || !c_out) return ZG_E_INVALID_ARG;
     if (!witness32) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -668,6 +773,8 @@ extern "C" int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witnes
         ZG_HIP(ctx, hipMemcpyAsync(outs[k], d[k].p, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------ params
@@ -694,7 +801,7 @@ static int params_upload(zg_ctx* ctx, zg_params* p, int which, const void* host,
 
 extern "C" int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const uint8_t* h, size_t n_h, const uint8_t* l,
                                    size_t n_l, const uint8_t* a, size_t n_a, const uint8_t* b_g1, size_t n_b_g1,
-                                   const uint8_t* b_g2, size_t n_b_g2, int rank, int world, zg_params** out) {
+                                   const uint8_t* b_g2, size_t n_b_g2, int rank, int world, zg_params** out) try {
     if (!ctx || !vk5 || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -714,10 +821,12 @@ extern "C" int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const ui
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = p.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank, int world,
-                              zg_params** out, size_t* consumed) {
+                              zg_params** out, size_t* consumed) try {
     if (!ctx || !bellman_params || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -728,6 +837,8 @@ extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t
     p->world = world;
     p->alpha_g1 = pp.alpha_g1; p->beta_g1 = pp.beta_g1; p->delta_g1 = pp.delta_g1;
     p->beta_g2 = pp.beta_g2; p->delta_g2 = pp.delta_g2;
+    p->gamma_g2 = pp.gamma_g2;
+    p->ic = pp.ic;
     ZG_TRY(params_upload(ctx, p.get(), 0, pp.h.data(), pp.h.size(), 64));
     ZG_TRY(params_upload(ctx, p.get(), 1, pp.l.data(), pp.l.size(), 64));
     ZG_TRY(params_upload(ctx, p.get(), 2, pp.a.data(), pp.a.size(), 64));
@@ -736,22 +847,30 @@ extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = p.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 extern "C" void zg_params_free(zg_params* p) { delete p; }
-extern "C" int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi) {
+extern "C" int zg_params_shard_range(const zg_params* p, int which, uint64_t* lo, uint64_t* hi) try {
     if (!p || which < 0 || which > 4 || !lo || !hi) return ZG_E_INVALID_ARG;
     *lo = p->q[which].lo;
     *hi = p->q[which].hi;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
-extern "C" int zg_params_query_total(const zg_params* p, int which, uint64_t* total) {
+extern "C" int zg_params_query_total(const zg_params* p, int which, uint64_t* total) try {
     if (!p || which < 0 || which > 4 || !total) return ZG_E_INVALID_ARG;
     *total = p->q[which].total;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
-extern "C" int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) {
+extern "C" int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) try {
     if (!pk || !offset) return ZG_E_INVALID_ARG;
     return pk_params_offset(pk, len, offset);
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ prove
@@ -771,6 +890,14 @@ static int check_query_sizes(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) 
     return ZG_OK;
 }
 
+// The two events that gate the multiexps of an overlapped proof (witness ready / H ready) belong to the ctx: they
+// are created on the ctx's device and destroyed with it (zg_free).
+static int gate_events(zg_ctx* ctx) {
+    if (!ctx->gate_w) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_w, hipEventDisableTiming));
+    if (!ctx->gate_h) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_h, hipEventDisableTiming));
+    return ZG_OK;
+}
+
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
 static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
     const size_t m = (size_t)1 << r->log_m;
@@ -783,7 +910,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
-extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
     if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -793,18 +920,30 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
     ctx->timings[1] = 0;
     ctx->timings[2] = now_ms() - t0;   // R1CS evaluation + H
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
-                                     const void* d_h_shard, uint8_t partials[ZG_PARTIALS_BYTES]) {
+                                     const void* d_h_shard, uint8_t partials[ZG_PARTIALS_BYTES]) try {
     return zg_prove_partials_ex(ctx, p, r, d_witness, d_h_shard, 0x1f, partials);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
-extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
     if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
+    // "witness ready" is recorded BEFORE the H pipeline is queued: a following zg_prove_partials_ex with the witness
+    // mask gates its multiexps on this event instead of on everything queued so far, so rank 0's l / a / b jobs run
+    // beside its NTT passes (as they do inside zg_prove_dev) rather than after them.
+    ZG_TRY(gate_events(ctx));
+    ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
+    ctx->witness_gate_armed = true;
     return prove_h_enqueue(ctx, r, d_witness, d_h_out);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // Fixed-base window tables for this rank's part of each query, built once per key: every proof with the key
@@ -917,26 +1056,30 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
     return ZG_OK;
 }
 
-extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) {
+extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) try {
     if (!p || which < 0 || which > 4 || !kind || !bytes) return ZG_E_INVALID_ARG;
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     const auto& t = p->fbw[which];
     *kind = t.state == 1 ? (t.kind == 1 ? 2 : 1) : 0;
     *bytes = t.state == 1 ? t.buf.bytes : 0;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
-extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness) {
+extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness) try {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_TRY(check_query_sizes(ctx, p, r));
     QueryUse use[5];
     ZG_TRY(query_uses(ctx, p, r, d_witness, nullptr, 0x1f, use));
     return ensure_tables(ctx, p, use, 0x1f);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
-                                    const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) {
+                                    const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -962,7 +1105,10 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
         }
         if (k < 4) d1[k] = d; else d2 = d;
     }
-    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ctx->ev_witness, ctx->ev_h));
+    hipEvent_t ev_wit = ctx->ev_witness;
+    if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
+    ctx->witness_gate_armed = false;
+    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
@@ -971,9 +1117,12 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     jac_bytes(partials + 384, b2_acc);
     ctx->timings[3] = now_ms() - t0;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 static void scalar_words(uint32_t out[8], const uint8_t le[32]) { memcpy(out, le, 32); }
+
 
 // k0*P0 + k1*P1 + k2*P2 with one shared doubling chain (Straus): the 7 non-empty subset sums are tabulated,
 // then 254 doublings + at most 254 additions instead of three separate double-and-add ladders.
@@ -995,7 +1144,7 @@ static G1XYZZ straus3(const G1XYZZ pts[3], const uint32_t* const k[3]) {
 }
 
 extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world,
-                                const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+                                const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
     if (!ctx || !p || !partials_all || world < 1 || !r_le || !s_le || !proof_out) return ZG_E_INVALID_ARG;
     double t0 = now_ms();
     G1XYZZ h_acc = G1XYZZ::inf(), l_acc = G1XYZZ::inf(), a_ans = G1XYZZ::inf(), b1_ans = G1XYZZ::inf();
@@ -1012,6 +1161,8 @@ extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* 
     uint32_t r[8], s[8], rs[8];
     scalar_words(r, r_le);
     scalar_words(s, s_le);
+    if (!scalar_is_canonical(r) || !scalar_is_canonical(s))
+        return fail(ctx, ZG_E_BAD_FORMAT, "r and s must be canonical scalars (< the group order)");
     {
         Fr fr_r, fr_s;
         memcpy(&fr_r, r, 32);
@@ -1041,10 +1192,12 @@ extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* 
     fq_to_be(proof_out + 192, C.x); fq_to_be(proof_out + 224, C.y);
     ctx->timings[4] = now_ms() - t0;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
-                            const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+                            const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
     if (!ctx || !p || !r || !proof_out || !r_le || !s_le) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "zg_prove needs an unsharded key (world = 1); use the phase API");
@@ -1057,28 +1210,27 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ZG_HIP(ctx, dh.reserve(m * 32));
     // The witness MSMs do not depend on H: gate them on "now", queue the NTT pipeline, gate the h MSM
     // on its completion, and let the job scheduler overlap everything.
-    static thread_local hipEvent_t ev_w = nullptr, ev_h = nullptr;
-    if (!ev_w) {
-        ZG_HIP(ctx, hipEventCreateWithFlags(&ev_w, hipEventDisableTiming));
-        ZG_HIP(ctx, hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
-    }
-    ZG_HIP(ctx, hipEventRecord(ev_w, ctx->stream));
+    ZG_TRY(gate_events(ctx));
+    ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p));
-    ZG_HIP(ctx, hipEventRecord(ev_h, ctx->stream));
-    ctx->ev_witness = ev_w;
-    ctx->ev_h = ev_h;
+    ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
+    ctx->ev_witness = ctx->gate_w;
+    ctx->ev_h = ctx->gate_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
     int rc_p = zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials);
     ctx->ev_witness = ctx->ev_h = nullptr;
+    ctx->witness_gate_armed = false;
     ZG_TRY(rc_p);
     ctx->timings[1] = ctx->timings[2] = 0;   // overlapped with the MSMs: see zg_profile_* for kernel times
     ZG_TRY(zg_prove_combine(ctx, p, partials, 1, r_le, s_le, proof_out));
     ctx->timings[5] = now_ms() - t0;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
-                        const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) {
+                        const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
     if (!witness32) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1093,30 +1245,40 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     ctx->timings[0] = t1 - t0;
     ctx->timings[5] = now_ms() - t0;
     return rc;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_prove_random(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
-                               uint8_t proof_out[256]) {
+                               uint8_t proof_out[256]) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     std::random_device rd;
     uint8_t rs[2][32];
     for (int k = 0; k < 2; k++) {
-        // uniform below 2^253 < r: ample for blinding, always canonical
-        for (int i = 0; i < 32; i += 4) {
-            uint32_t v = rd();
-            memcpy(rs[k] + i, &v, 4);
+        // uniform in [0, r) as Fr::rand: 254 random bits, rejected while >= r (r ~ 0.756 * 2^254)
+        for (;;) {
+            uint32_t v[8];
+            for (int i = 0; i < 8; i++) v[i] = rd();
+            v[7] &= 0x3fffffffu;
+            if (scalar_is_canonical(v)) {
+                memcpy(rs[k], v, 32);
+                break;
+            }
         }
-        rs[k][31] &= 0x1f;
     }
     return zg_prove(ctx, p, r, witness32, rs[0], rs[1], proof_out);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, char* out,
-                             size_t cap) {
+                             size_t cap) try {
     if (!proof || !out || (n_public && !public_inputs32)) return ZG_E_INVALID_ARG;
     std::string j;
     proof_json(proof, public_inputs32, n_public, &j);
     if (j.size() >= cap) return ZG_E_BUFFER_TOO_SMALL;
     memcpy(out, j.c_str(), j.size() + 1);
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }

@@ -127,8 +127,49 @@ struct Csc {
 
 }  // namespace
 
+// Parameters::write (format.rs:250) of a resident, unsharded key: vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
+// delta_g2, ic), then h, l, a, b_g1, b_g2 fetched from HBM and taken out of the device's M261 form
+static int params_write_bytes(zg_ctx* ctx, const zg_params* p, std::vector<uint8_t>* bytes) {
+    if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "Parameters::write needs an unsharded key (world = 1)");
+    if (p->ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "this key was built without gamma_g2 / ic");
+    ParsedParams pp;
+    pp.alpha_g1 = p->alpha_g1; pp.beta_g1 = p->beta_g1; pp.beta_g2 = p->beta_g2;
+    pp.gamma_g2 = p->gamma_g2;
+    pp.delta_g1 = p->delta_g1; pp.delta_g2 = p->delta_g2;
+    pp.ic = p->ic;
+    auto fetch1 = [&](const zg_params::Query& q, std::vector<G1Affine>& v) -> hipError_t {
+        v.resize(q.total);
+        if (!q.total) return hipSuccess;
+        hipError_t e = hipMemcpy(v.data(), q.buf.p, (size_t)q.total * 64, hipMemcpyDeviceToHost);
+        for (auto& x : v) x = m261_to_host(x);
+        return e;
+    };
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZG_HIP(ctx, fetch1(p->q[0], pp.h));
+    ZG_HIP(ctx, fetch1(p->q[1], pp.l));
+    ZG_HIP(ctx, fetch1(p->q[2], pp.a));
+    ZG_HIP(ctx, fetch1(p->q[3], pp.b_g1));
+    pp.b_g2.resize(p->q[4].total);
+    if (p->q[4].total) ZG_HIP(ctx, hipMemcpy(pp.b_g2.data(), p->q[4].buf.p, (size_t)p->q[4].total * 128, hipMemcpyDeviceToHost));
+    for (auto& x : pp.b_g2) x = m261_to_host(x);
+    write_bellman_params(pp, bytes);
+    return ZG_OK;
+}
+extern "C" int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, size_t cap, size_t* written) try {
+    if (!ctx || !p || !written) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint8_t> bytes;
+    ZG_TRY(params_write_bytes(ctx, p, &bytes));
+    *written = bytes.size();
+    if (!out || cap < bytes.size()) return ZG_E_BUFFER_TOO_SMALL;
+    memcpy(out, bytes.data(), bytes.size());
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+
 extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160], zg_params** out, uint8_t* params_out,
-                        size_t cap, size_t* written) {
+                        size_t cap, size_t* written) try {
     if (!ctx || !r || !toxic || !out) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -290,29 +331,13 @@ extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160],
     p->delta_g1 = G1x.mul(wd).to_affine();
     p->delta_g2 = G2x.mul(wd).to_affine();
 
+    p->gamma_g2 = G2x.mul(wg).to_affine();
+    p->ic.resize(ni);
+    if (ni) ZG_HIP(ctx, hipMemcpy(p->ic.data(), ext_pts.p, (size_t)ni * 64, hipMemcpyDeviceToHost));
+    for (auto& x : p->ic) x = m261_to_host(x);
     if (params_out || written) {
-        // Parameters::write: vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2, ic), h, l, a, b_g1, b_g2
-        ParsedParams pp;
-        pp.alpha_g1 = p->alpha_g1; pp.beta_g1 = p->beta_g1; pp.beta_g2 = p->beta_g2;
-        pp.gamma_g2 = G2x.mul(wg).to_affine();
-        pp.delta_g1 = p->delta_g1; pp.delta_g2 = p->delta_g2;
-        auto fetch1 = [&](const void* d, size_t n, std::vector<G1Affine>& v) -> hipError_t {
-            v.resize(n);
-            if (!n) return hipSuccess;
-            hipError_t e = hipMemcpy(v.data(), d, n * 64, hipMemcpyDeviceToHost);
-            for (auto& x : v) x = m261_to_host(x);
-            return e;
-        };
-        ZG_HIP(ctx, fetch1(ext_pts.p, ni, pp.ic));
-        ZG_HIP(ctx, fetch1(p->q[0].buf.p, n_h, pp.h));
-        ZG_HIP(ctx, fetch1(p->q[1].buf.p, na, pp.l));
-        ZG_HIP(ctx, fetch1(p->q[2].buf.p, keep_a.size(), pp.a));
-        ZG_HIP(ctx, fetch1(p->q[3].buf.p, keep_b.size(), pp.b_g1));
-        pp.b_g2.resize(keep_b.size());
-        if (!keep_b.empty()) ZG_HIP(ctx, hipMemcpy(pp.b_g2.data(), p->q[4].buf.p, keep_b.size() * 128, hipMemcpyDeviceToHost));
-        for (auto& x : pp.b_g2) x = m261_to_host(x);
         std::vector<uint8_t> bytes;
-        write_bellman_params(pp, &bytes);
+        ZG_TRY(params_write_bytes(ctx, p.get(), &bytes));
         if (written) *written = bytes.size();
         if (params_out) {
             if (bytes.size() > cap) return ZG_E_BUFFER_TOO_SMALL;
@@ -321,11 +346,13 @@ extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160],
     }
     *out = p.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // generate_random_parameters: the toxic waste from the OS entropy source
 extern "C" int zg_setup_random(zg_ctx* ctx, const zg_r1cs* r, zg_params** out, uint8_t* params_out, size_t cap,
-                               size_t* written) {
+                               size_t* written) try {
     std::random_device rd;
     uint8_t toxic[160];
     for (int i = 0; i < 160; i += 4) {
@@ -337,4 +364,6 @@ extern "C" int zg_setup_random(zg_ctx* ctx, const zg_r1cs* r, zg_params** out, u
         toxic[32 * k] |= 1;           // never zero
     }
     return zg_setup(ctx, r, toxic, out, params_out, cap, written);
+} catch (...) {
+    return zg::on_exception(ctx);
 }

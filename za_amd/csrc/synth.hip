@@ -57,7 +57,7 @@ void push_term(zg_synth* s, int k, uint32_t var, const Fr& coeff_mont) {
 }
 }  // namespace
 
-extern "C" int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_fraction, uint64_t seed, zg_synth** out) {
+extern "C" int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_fraction, uint64_t seed, zg_synth** out) try {
     if (!out || log_m >= 28 || n_inputs == 0 || ((uint64_t)1 << log_m) <= n_inputs) return ZG_E_INVALID_ARG;
     const uint64_t m = (uint64_t)1 << log_m;
     const uint64_t n = m - n_inputs;
@@ -135,13 +135,17 @@ extern "C" int zg_synth_r1cs_new(uint32_t log_m, uint32_t n_inputs, double bit_f
     }
     *out = s.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
-extern "C" int zg_synth_r1cs_info(const zg_synth* s, uint64_t info[6]) {
+extern "C" int zg_synth_r1cs_info(const zg_synth* s, uint64_t info[6]) try {
     if (!s || !info) return ZG_E_INVALID_ARG;
     info[0] = s->n_inputs; info[1] = s->n_aux; info[2] = s->n_constraints;
     for (int k = 0; k < 3; k++) info[3 + k] = s->col[k].size();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 extern "C" const void* zg_synth_ptr(const zg_synth* s, int which) {
     if (!s || which < 0 || which > 9) return nullptr;
@@ -220,19 +224,23 @@ static int synth_bases_g2_m261(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed
     return ZG_OK;
 }
 // public: bases in the ABI's 2^256 Montgomery form, like any caller-supplied device bases
-extern "C" int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+extern "C" int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) try {
     if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_TRY(synth_bases_g1_m261(ctx, d_out, n, seed));
     return convert_mont_dev(ctx, d_out, n * 2, 0, 1);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+extern "C" int zg_synth_bases_g2_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) try {
     if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_TRY(synth_bases_g2_m261(ctx, d_out, n, seed));
     return convert_mont_dev(ctx, d_out, n * 4, 0, 1);
+} catch (...) {
+    return zg::on_exception(ctx);
 }
-extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed) try {
     if (!ctx || (!d_out && n)) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) return ZG_OK;
@@ -240,10 +248,12 @@ extern "C" int zg_synth_scalars_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t
                        seed);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // A sharded view of a resident key: chunk `rank` of `world` of every query, copied into a new handle.
-extern "C" int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int world, zg_params** out) {
+extern "C" int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int world, zg_params** out) try {
     if (!ctx || !full || !out || world < 1 || rank < 0 || rank >= world || full->world != 1) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -267,10 +277,12 @@ extern "C" int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = p.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 extern "C" int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint64_t n_a, uint64_t n_b, uint64_t seed,
-                                   int rank, int world, zg_params** out) {
+                                   int rank, int world, zg_params** out) try {
     if (!ctx || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
     *out = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -306,11 +318,13 @@ extern "C" int zg_synth_params_dev(zg_ctx* ctx, uint64_t n_h, uint64_t n_l, uint
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = p.release();
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 
 // Copy a resident query shard (which = 0..4) or the five vk points (which = -1, 448 bytes in the
 // zg_params_from_mont order) back to the host -- lets tests and the CPU baseline see a synthetic key.
-extern "C" int zg_params_download(const zg_params* p, int which, void* out, size_t bytes) {
+extern "C" int zg_params_download(const zg_params* p, int which, void* out, size_t bytes) try {
     if (!p || !out || which < -1 || which > 4) return ZG_E_INVALID_ARG;
     if (which == -1) {
         if (bytes < 448) return ZG_E_BUFFER_TOO_SMALL;
@@ -336,6 +350,8 @@ extern "C" int zg_params_download(const zg_params* p, int which, void* out, size
         memcpy(f + i, &v, 32);
     }
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ self-test hooks
@@ -363,10 +379,12 @@ static void st_field_host(int op, const uint8_t* a, const uint8_t* b, uint8_t* o
     }
 }
 // which: 0 Fq, 1 Fr.  op: 0 mul 1 add 2 sub 3 inv 4 to_mont 5 from_mont 6 neg 7 sqr.  Montgomery LE operands.
-extern "C" int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+extern "C" int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) try {
     if (!a || !b || !out) return ZG_E_INVALID_ARG;
     if (which) st_field_host<Fr>(op, a, b, out, n); else st_field_host<Fq>(op, a, b, out, n);
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 // operands arrive in the ABI's 2^256 form; the op runs in the device field (fd.h) and converts back
 template <class P29>
@@ -389,7 +407,7 @@ __global__ void k_st_field(int op, const Fp<typename P29::Wide>* a, const Fp<typ
     z.m261_to_m256().canonical().store(&out[i]);
 }
 extern "C" int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out,
-                                     size_t n) {
+                                     size_t n) try {
     if (!ctx || !a || !b || !out) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf da, db, dout;
@@ -407,9 +425,11 @@ extern "C" int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8
     ZG_HIP(ctx, hipMemcpyAsync(out, dout.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
 }
 // out = k * p (+ q if q != NULL) with the product's HOST curve code; group 1 = G1 (64 B points), 2 = G2 (128 B)
-extern "C" int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out) {
+extern "C" int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out) try {
     if (!p || !k32 || !out) return ZG_E_INVALID_ARG;
     uint32_t k[8];
     memcpy(k, k32, 32);
@@ -429,10 +449,12 @@ extern "C" int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t
         memcpy(out, &o, 128);
     }
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 // Parse and validate a bellman Parameters body without a GPU.  counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, consumed.
 // err (nullable) receives the parser's message.
-extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap) {
+extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap) try {
     if (!buf || !counts) return ZG_E_INVALID_ARG;
     zg_ctx tmp;
     ParsedParams pp;
@@ -450,4 +472,6 @@ extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, ui
     write_bellman_params(pp, &again);
     if (again.size() != used || memcmp(again.data(), buf, used) != 0) return ZG_E_BAD_FORMAT;
     return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
