@@ -88,6 +88,27 @@ int zg_msm_g1_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars,
 int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars,
                   const uint32_t* d_scalar_index, size_t n, uint8_t out_jac[192]);
 
+/* Resident bases: bellman's multiexp takes its bases as a shared `Arc<Vec<G::Affine>>` that outlives the call
+ * (SourceBuilder); the analogue here is a handle that keeps n affine bases in HBM (converted to the device form once)
+ * and, if table_budget_gb > 0 and it pays, a fixed-base window table 2^(c w) P_i over them (see zg_params_prepare).
+ * zg_msm_resident takes host scalars (n <= the handle's n, canonical LE; pinned memory from zg_host_alloc gives PCIe
+ * speed) and overlaps their chunked upload with the multiexp, which is BASELINE.json's "G1 MSM points/s" measurement:
+ * bases resident, scalars uploaded.  zg_msm_resident_dev takes scalars already in HBM.  dense_hint != 0 promises that
+ * essentially no scalar is 0 or 1 (uniform scalars: skips a classification pass); results are exact either way.
+ * info: n, table bytes, c, digits per scalar. */
+typedef struct zg_msm_bases zg_msm_bases;
+int zg_msm_bases_g1(zg_ctx* ctx, const uint8_t* bases64, size_t n, double table_budget_gb, zg_msm_bases** out);
+int zg_msm_bases_g1_dev(zg_ctx* ctx, const void* d_bases, size_t n, double table_budget_gb, zg_msm_bases** out);
+int zg_msm_bases_g2(zg_ctx* ctx, const uint8_t* bases128, size_t n, double table_budget_gb, zg_msm_bases** out);
+void zg_msm_bases_free(zg_msm_bases* b);
+int zg_msm_bases_info(const zg_msm_bases* b, uint64_t info[4]);
+int zg_msm_resident(zg_ctx* ctx, zg_msm_bases* b, const uint8_t* scalars32, size_t n, int dense_hint, uint8_t* out_jac);
+int zg_msm_resident_dev(zg_ctx* ctx, const zg_msm_bases* b, const void* d_scalars, size_t n, int dense_hint,
+                        uint8_t* out_jac);
+/* Pinned (page-locked) host memory for witnesses and scalars handed to zg_prove / zg_msm_resident. */
+int zg_host_alloc(zg_ctx* ctx, size_t bytes, void** out);
+int zg_host_free(zg_ctx* ctx, void* p);
+
 /* ---- Fr number-theoretic transform ---------------------------------------------------------
  * Replaces bellman_ce::domain::EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} (inside
  * create_proof).  m = 2^log_m Montgomery-LE elements, natural order in and out, in place.
@@ -150,6 +171,8 @@ void zg_params_free(zg_params* p);
  * zg_params_load / zg_pk_load or made by zg_setup*; world = 1).  *written always receives the size; ZG_E_BUFFER_TOO_SMALL
  * if cap is insufficient (or out is NULL). */
 int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, size_t cap, size_t* written);
+/* Only the verifying key (bellman VerifyingKey::write; host data, no GPU traffic): what zg_verify / zg_vk_json take. */
+int zg_params_write_vk(const zg_params* p, uint8_t* out, size_t cap, size_t* written);
 /* Skip za's proving-key container header (u32be-len AST blob, constraints, ignore_signals;
  * prover/src/groth16/format.rs:223-247) and return the offset of the bellman Parameters body. */
 int zg_pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
@@ -276,8 +299,8 @@ const char* zg_last_error_thread(void);
 int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public,
                   char* out, size_t cap);
 
-/* ---- timing of the last zg_prove* call on this ctx (milliseconds, GPU events + host clock):
- * [0] witness upload, [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
+/* ---- timing of the last zg_prove* call on this ctx (milliseconds, host clock):
+ * [0] witness bytes uploaded by zg_prove (the copy itself is part of [5]), [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline

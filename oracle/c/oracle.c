@@ -115,38 +115,74 @@ static void g2_aff_store(uint8_t* b, const g2_aff* p) {
 /* ------------------------------------------------------------------ multiexp */
 static unsigned multiexp_c(size_t n) { return n < 32 ? 3u : (unsigned)ceil(log((double)n)); }
 
+/* A multiexp is prepared (bases loaded, window sums allocated), its windows run as independent tasks, and the
+ * window sums are folded high to low.  create_proof submits ALL its multiexps to one Worker pool before waiting for
+ * any of them (bellman's futures), so mx_run_all() puts the windows of every prepared multiexp into one task list, in
+ * submission order. */
 #define DEFINE_MULTIEXP(GP, STRIDE)                                                              \
-    typedef struct { const GP##_aff* bases; const uint8_t* density; const uint64_t* exps; size_t n; \
-                     unsigned c; GP##_jac* win; } GP##_mx_ctx;                                   \
+    typedef struct { GP##_aff* bases; const uint8_t* density; const uint64_t* exps; size_t n;    \
+                     unsigned c; size_t nw; GP##_jac* win; } GP##_mx_ctx;                        \
     static void GP##_mx_task(void* p, size_t w) {                                                \
         GP##_mx_ctx* x = (GP##_mx_ctx*)p;                                                        \
         GP##_multiexp_window(&x->win[w], x->bases, x->density, x->exps, x->n, (unsigned)w * x->c, x->c); \
     }                                                                                            \
-    static int GP##_multiexp(GP##_jac* out, const uint8_t* bases_b, size_t n_bases,              \
-                             const uint8_t* scalars, const uint8_t* density, size_t n, int threads) { \
+    static int GP##_mx_prepare(GP##_mx_ctx* x, const uint8_t* bases_b, size_t n_bases,           \
+                               const uint8_t* scalars, const uint8_t* density, size_t n) {       \
         size_t tot = 0;                                                                          \
+        memset(x, 0, sizeof(*x));                                                                \
         if (density) { for (size_t i = 0; i < n; i++) tot += density[i] != 0; } else tot = n;    \
         if (tot != n_bases) return ORC_E_QUERY_SIZE;                                             \
-        GP##_aff* bases = (GP##_aff*)malloc(sizeof(GP##_aff) * (n_bases ? n_bases : 1));         \
-        for (size_t i = 0; i < n_bases; i++) GP##_aff_load(&bases[i], bases_b + (size_t)STRIDE * i); \
-        unsigned c = multiexp_c(n);                                                              \
-        size_t nw = (254 + c - 1) / c;                                                           \
-        GP##_jac* win = (GP##_jac*)calloc(nw, sizeof(GP##_jac));                                 \
-        GP##_mx_ctx ctx = {bases, density, (const uint64_t*)scalars, n, c, win};                 \
-        parallel_for(nw, threads, GP##_mx_task, &ctx);                                           \
+        x->bases = (GP##_aff*)malloc(sizeof(GP##_aff) * (n_bases ? n_bases : 1));                \
+        for (size_t i = 0; i < n_bases; i++) GP##_aff_load(&x->bases[i], bases_b + (size_t)STRIDE * i); \
+        x->density = density; x->exps = (const uint64_t*)scalars; x->n = n;                      \
+        x->c = multiexp_c(n);                                                                    \
+        x->nw = (254 + x->c - 1) / x->c;                                                         \
+        x->win = (GP##_jac*)calloc(x->nw, sizeof(GP##_jac));                                     \
+        return ORC_OK;                                                                           \
+    }                                                                                            \
+    static void GP##_mx_finish(GP##_jac* out, GP##_mx_ctx* x) {                                  \
         GP##_jac total;                                                                          \
         GP##_jac_set_inf(&total);                                                                \
-        for (size_t w = nw; w-- > 0;) {                                                          \
-            for (unsigned k = 0; k < c; k++) GP##_jac_double(&total, &total);                    \
-            GP##_jac_add(&total, &total, &win[w]);                                               \
+        for (size_t w = x->nw; w-- > 0;) {                                                       \
+            for (unsigned k = 0; k < x->c; k++) GP##_jac_double(&total, &total);                 \
+            GP##_jac_add(&total, &total, &x->win[w]);                                            \
         }                                                                                        \
-        free(win);                                                                               \
-        free(bases);                                                                             \
+        free(x->win);                                                                            \
+        free(x->bases);                                                                          \
+        x->win = NULL; x->bases = NULL;                                                          \
         *out = total;                                                                            \
+    }                                                                                            \
+    static int GP##_multiexp(GP##_jac* out, const uint8_t* bases_b, size_t n_bases,              \
+                             const uint8_t* scalars, const uint8_t* density, size_t n, int threads) { \
+        GP##_mx_ctx x;                                                                           \
+        int rc = GP##_mx_prepare(&x, bases_b, n_bases, scalars, density, n);                     \
+        if (rc) return rc;                                                                       \
+        parallel_for(x.nw, threads, GP##_mx_task, &x);                                           \
+        GP##_mx_finish(out, &x);                                                                 \
         return ORC_OK;                                                                           \
     }
 DEFINE_MULTIEXP(g1, 64)
 DEFINE_MULTIEXP(g2, 128)
+
+typedef struct { task_fn fn; void* ctx; size_t w; } mx_any_task;
+static void mx_any_run(void* p, size_t i) {
+    mx_any_task* t = &((mx_any_task*)p)[i];
+    t->fn(t->ctx, t->w);
+}
+/* the windows of n1 G1 and n2 G2 prepared multiexps as ONE task list, in submission order */
+static void mx_run_all(g1_mx_ctx* j1, int n1, g2_mx_ctx* j2, int n2, int threads) {
+    size_t total = 0;
+    for (int k = 0; k < n1; k++) total += j1[k].nw;
+    for (int k = 0; k < n2; k++) total += j2[k].nw;
+    mx_any_task* t = (mx_any_task*)malloc(sizeof(mx_any_task) * (total ? total : 1));
+    size_t at = 0;
+    for (int k = 0; k < n1; k++)
+        for (size_t w = 0; w < j1[k].nw; w++) t[at++] = (mx_any_task){g1_mx_task, &j1[k], w};
+    for (int k = 0; k < n2; k++)
+        for (size_t w = 0; w < j2[k].nw; w++) t[at++] = (mx_any_task){g2_mx_task, &j2[k], w};
+    parallel_for(total, threads, mx_any_run, t);
+    free(t);
+}
 
 int orc_msm_g1(const uint8_t* bases, size_t n_bases, const uint8_t* scalars, const uint8_t* density,
                size_t n, int threads, uint8_t out[64]) {
@@ -168,6 +204,28 @@ int orc_msm_g2(const uint8_t* bases, size_t n_bases, const uint8_t* scalars, con
     g2_aff a;
     g2_jac_to_aff(&a, &r);
     g2_aff_store(out, &a);
+    return ORC_OK;
+}
+
+/* sum_i scalars[i] * k[i] as a 384-bit little-endian integer (not reduced): the discrete-log side of the
+ * "bases with known discrete logs" identities the full-size tests use (scalars: n x 32 B canonical LE, k: n x u64) */
+int orc_dot_u64(const uint8_t* scalars, const uint64_t* k, size_t n, uint8_t out48[48]) {
+    uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t* s = (const uint64_t*)(scalars + 32 * i);
+        unsigned __int128 carry = 0;
+        for (int j = 0; j < 4; j++) {
+            unsigned __int128 t = (unsigned __int128)s[j] * k[i] + acc[j] + carry;
+            acc[j] = (uint64_t)t;
+            carry = t >> 64;
+        }
+        for (int j = 4; j < 6 && carry; j++) {
+            unsigned __int128 t = (unsigned __int128)acc[j] + carry;
+            acc[j] = (uint64_t)t;
+            carry = t >> 64;
+        }
+    }
+    memcpy(out48, acc, 48);
     return ORC_OK;
 }
 
@@ -544,14 +602,30 @@ int orc_prove(const orc_params* pp, const orc_r1cs* r1, const uint8_t* witness, 
     const uint8_t* w_aux = witness + 32 * ni;
     g1_jac h_acc, l_acc, a_in, a_aux, b1_in, b1_aux;
     g2_jac b2_in, b2_aux;
-    rc |= g1_multiexp(&h_acc, pp->h, m - 1, h, NULL, m - 1, threads);
-    rc |= g1_multiexp(&l_acc, pp->l, na, w_aux, NULL, na, threads);
-    rc |= g1_multiexp(&a_in, pp->a, ni, w_in, NULL, ni, threads);
-    rc |= g1_multiexp(&a_aux, pp->a + 64 * ni, a_aux_tot, w_aux, a_aux_d, na, threads);
-    rc |= g1_multiexp(&b1_in, pp->b_g1, b_in_tot, w_in, b_in_d, ni, threads);
-    rc |= g1_multiexp(&b1_aux, pp->b_g1 + 64 * b_in_tot, b_aux_tot, w_aux, b_aux_d, na, threads);
-    rc |= g2_multiexp(&b2_in, pp->b_g2, b_in_tot, w_in, b_in_d, ni, threads);
-    rc |= g2_multiexp(&b2_aux, pp->b_g2 + 128 * b_in_tot, b_aux_tot, w_aux, b_aux_d, na, threads);
+    {   /* the eight multiexp calls of create_proof share one pool: h, l, a (inputs, aux), b_g1 (inputs, aux), b_g2 */
+        g1_mx_ctx j1[6];
+        g2_mx_ctx j2[2];
+        memset(j1, 0, sizeof j1); memset(j2, 0, sizeof j2);
+        rc |= g1_mx_prepare(&j1[0], pp->h, m - 1, h, NULL, m - 1);
+        rc |= g1_mx_prepare(&j1[1], pp->l, na, w_aux, NULL, na);
+        rc |= g1_mx_prepare(&j1[2], pp->a, ni, w_in, NULL, ni);
+        rc |= g1_mx_prepare(&j1[3], pp->a + 64 * ni, a_aux_tot, w_aux, a_aux_d, na);
+        rc |= g1_mx_prepare(&j1[4], pp->b_g1, b_in_tot, w_in, b_in_d, ni);
+        rc |= g1_mx_prepare(&j1[5], pp->b_g1 + 64 * b_in_tot, b_aux_tot, w_aux, b_aux_d, na);
+        rc |= g2_mx_prepare(&j2[0], pp->b_g2, b_in_tot, w_in, b_in_d, ni);
+        rc |= g2_mx_prepare(&j2[1], pp->b_g2 + 128 * b_in_tot, b_aux_tot, w_aux, b_aux_d, na);
+        if (!rc) mx_run_all(j1, 6, j2, 2, threads);
+        g1_jac* o1[6] = {&h_acc, &l_acc, &a_in, &a_aux, &b1_in, &b1_aux};
+        g2_jac* o2[2] = {&b2_in, &b2_aux};
+        for (int k = 0; k < 6; k++) {
+            if (!rc) g1_mx_finish(o1[k], &j1[k]);
+            else { free(j1[k].win); free(j1[k].bases); }
+        }
+        for (int k = 0; k < 2; k++) {
+            if (!rc) g2_mx_finish(o2[k], &j2[k]);
+            else { free(j2[k].win); free(j2[k].bases); }
+        }
+    }
     free(h); free(a_aux_d); free(b_aux_d); free(b_in_d);
     if (rc) return rc;
     clock_gettime(CLOCK_MONOTONIC, &t3);

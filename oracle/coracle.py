@@ -91,6 +91,18 @@ def msm_g2(bases, scalars, density=None, threads=1):
     return out.tobytes()
 
 
+def dot_u64(scalars, k64):
+    """sum_i scalars[i] * k64[i] as a Python int (scalars: n x 32 B canonical LE; k64: uint64 array)."""
+    sa, sp = _buf(scalars)
+    ka = np.ascontiguousarray(k64, dtype=np.uint64)
+    n = ka.size
+    assert sa.size >= 32 * n
+    out = np.zeros(48, dtype=np.uint8)
+    rc = lib().orc_dot_u64(sp, ka.ctypes.data_as(C.c_void_p), C.c_size_t(n), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return int.from_bytes(out.tobytes(), "little")
+
+
 def g1_mul(p, k):
     out = np.zeros(64, dtype=np.uint8)
     kp, pp = _buf(p)

@@ -1,0 +1,112 @@
+"""BASELINE.json's large configurations at full size on one MI355X (the 8-GPU forms shard these same jobs):
+config 4 (2^22, 97 %-bit witness) byte for byte against the C oracle, config 5's uniform-Fr shape at 2^24 against the
+discrete-log expectation, and the 2^26-point standalone G1 MSM."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as bn
+from oracle import coracle as co
+from oracle import groth16 as g
+from tests.util import download_params
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 8, 64)
+
+
+def test_config4_at_2p22_matches_the_c_oracle(ctx):
+    """The bench workload itself (SplitMix64 seed 0x5A, 97 % bits, key from the GPU trapdoor set-up): zg_prove from a
+    host witness equals the oracle's create_proof byte for byte; the public input verifies under the pairing."""
+    import za_amd
+    from za_amd import synth
+    lg = 22
+    sr = synth.SynthR1CS(lg, 2, 0.97, 0x5A)
+    R = sr.load(ctx)
+    P, _ = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)
+    r, s = 0x1234567, 0x7654321
+    got = ctx.prove(P, R, sr.witness, r, s)
+    kinds = [P.table_info(k)[0] for k in range(5)]
+    assert kinds[0] == 1 and kinds[1] == 2, kinds        # h: window table; l: subset-sum table (bit-heavy witness)
+    mp = download_params(ctx, P)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    assert co.prove(mp, csr, sr.witness, r, s, threads=THREADS) == got
+    # the same through the witness-resident entry point and a second call (cached tables / workspaces)
+    d_w = ctx.upload(sr.witness)
+    assert ctx.prove_dev(P, R, d_w, r, s) == got
+    assert ctx.prove(P, R, sr.witness, r, s) == got
+    ctx.free(d_w)
+    w1 = int.from_bytes(bytes(sr.witness[32:64]), "little")
+    assert za_amd.verify(P.write_vk(), got, [w1]) is True
+    assert za_amd.verify(P.write_vk(), got, [w1 ^ 1]) is False
+    P.close(); R.close(); sr.close()
+
+
+def test_config5_shape_uniform_witness_at_2p24_matches_discrete_log_expectation(ctx):
+    """Uniform-Fr coefficients and witness (config 5's shape, SplitMix64 seed 0x26) at 2^24: every query takes a
+    fixed-base window table (13 x the key), no 0/1 shortcuts anywhere.  With every base's discrete log known the
+    proof's three elements are k*G for scalars computed independently (R1CS evaluation and H from the C oracle)."""
+    from za_amd import synth
+    lg = 24
+    sr = synth.SynthR1CS(lg, 2, 0.0, 0x26)
+    R = sr.load(ctx)
+    m = 1 << lg
+    ni = sr.n_inputs
+    n_a, n_b = ni + R.a_aux_total, R.b_input_total + R.b_aux_total
+    seed = 26000
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, seed)
+    r, s = 0xABCDEF01, 0x10FEDCBA
+    got = ctx.prove(P, R, sr.witness, r, s)
+    assert [P.table_info(k)[0] for k in range(5)] == [1, 1, 1, 1, 1]
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    a, b, c, ad, bi, bd = co.r1cs_eval(csr, sr.witness, threads=THREADS)
+    h = co.h_coeffs(a, b, c, sr.n_constraints + ni, lg, threads=THREADS)
+    del a, b, c
+    w = np.frombuffer(bytes(sr.witness), dtype=np.uint8).reshape(-1, 32)
+    a_idx = np.concatenate([np.arange(ni), ni + np.nonzero(ad)[0]])
+    b_idx = np.concatenate([np.nonzero(bi)[0], ni + np.nonzero(bd)[0]])
+    assert len(a_idx) == n_a and len(b_idx) == n_b
+    sh = co.dot_u64(h, synth.splitmix64_array(seed + 1, m - 1)) % bn.R
+    sl = co.dot_u64(w[ni:], synth.splitmix64_array(seed + 2, sr.n_aux)) % bn.R
+    sa = co.dot_u64(np.ascontiguousarray(w[a_idx]), synth.splitmix64_array(seed + 3, n_a)) % bn.R
+    sb = co.dot_u64(np.ascontiguousarray(w[b_idx]), synth.splitmix64_array(seed + 4, n_b)) % bn.R
+    alpha, beta, delta = 3, 5, 7
+    eA = (alpha + sa + r * delta) % bn.R
+    eB = (beta + sb + s * delta) % bn.R
+    eC = (r * s * delta + s * alpha + r * beta + s * sa + r * sb + sh + sl) % bn.R
+    A = bn.g1_from_mont_bytes(co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eA))
+    B = bn.g2_from_mont_bytes(co.g2_mul(bn.g2_to_mont_bytes(bn.G2_GEN), eB))
+    Cc = bn.g1_from_mont_bytes(co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eC))
+    assert got == g.proof_bytes((A, B, Cc))
+    P.close(); R.close(); sr.close()
+
+
+def test_g1_msm_2p26_points_discrete_log_identity(ctx):
+    """Config 5's standalone multiexp: 2^26 G1 bases k_i G, uniform scalars.  sum s_i P_i = (sum s_i k_i) G through the
+    window table (resident scalars and host scalars uploaded in chunks) and through the plain per-window schedule."""
+    from za_amd import synth
+    n = 1 << 26
+    seed_b, seed_s = 2626, 99
+    d_b = synth.synth_bases_g1(ctx, n, seed_b)
+    d_s = synth.synth_scalars(ctx, n, seed_s)
+    sc = ctx.d2h(d_s, 32 * n)
+    e = co.dot_u64(sc, synth.splitmix64_array(seed_b, n)) % bn.R
+    want = co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), e)            # affine Montgomery bytes
+    H = ctx.msm_bases_g1_dev(d_b, n, table_budget_gb=120.0)
+    info = ctx.msm_bases_info(H)
+    assert info["n"] == n and info["table_bytes"] >= 10 * 64 * n, info
+    got = ctx.msm_resident_dev(H, d_s, n, dense_hint=True)
+    assert got[:64] == want and got[64:] == bn.le32(bn.mont(1, bn.Q))
+    # host scalars from a pinned buffer: four dependent parts gated on four upload chunks
+    pin = ctx.host_alloc(32 * n)
+    pin[:] = sc
+    assert ctx.msm_resident(H, pin, n, dense_hint=True)[:64] == want
+    # a prefix of the bases (n' < n: no table) with unhinted scalars
+    n2 = (1 << 20) + 12345
+    e2 = co.dot_u64(sc[:32 * n2], synth.splitmix64_array(seed_b, n2)) % bn.R
+    assert ctx.msm_resident(H, pin, n2, dense_hint=False)[:64] == co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), e2)
+    ctx.host_free(pin)
+    ctx.msm_bases_free(H)
+    # the per-call entry point (ABI-form bases converted on every call, per-window schedule)
+    assert ctx.msm_g1_dev(d_b, d_s, n)[:64] == want
+    ctx.free(d_b); ctx.free(d_s)

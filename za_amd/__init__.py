@@ -35,9 +35,11 @@ ABI_SYMBOLS = [
     "zg_init", "zg_free", "zg_strerror", "zg_last_error", "zg_set_stream", "zg_sync",
     "zg_dev_alloc", "zg_dev_free", "zg_h2d", "zg_d2h",
     "zg_msm_g1", "zg_msm_g2", "zg_msm_g1_dev", "zg_msm_g2_dev",
+    "zg_msm_bases_g1", "zg_msm_bases_g1_dev", "zg_msm_bases_g2", "zg_msm_bases_free", "zg_msm_bases_info",
+    "zg_msm_resident", "zg_msm_resident_dev", "zg_host_alloc", "zg_host_free",
     "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
-    "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_pk_params_offset",
+    "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random",
     "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
@@ -187,6 +189,56 @@ class Context:
         self._check(self.lib.zg_msm_g2_dev(self.h, C.c_void_p(d_bases), C.c_void_p(d_scalars),
                                            C.c_void_p(d_index), C.c_size_t(n), _ptr(out)))
         return out.tobytes()
+
+    # ---- resident bases
+    def msm_bases_g1_dev(self, d_bases, n, table_budget_gb=0.0):
+        h = C.c_void_p()
+        self._check(self.lib.zg_msm_bases_g1_dev(self.h, C.c_void_p(d_bases), C.c_size_t(n), C.c_double(table_budget_gb),
+                                                 C.byref(h)))
+        return h
+
+    def msm_bases(self, bases, g2=False, table_budget_gb=0.0):
+        b = _u8(bases)
+        h = C.c_void_p()
+        fn = self.lib.zg_msm_bases_g2 if g2 else self.lib.zg_msm_bases_g1
+        self._check(fn(self.h, _ptr(b), C.c_size_t(b.size // (128 if g2 else 64)), C.c_double(table_budget_gb), C.byref(h)))
+        return h
+
+    def msm_bases_info(self, handle):
+        info = (C.c_uint64 * 4)()
+        self._check(self.lib.zg_msm_bases_info(handle, info))
+        return dict(zip(("n", "table_bytes", "c", "nwin"), [int(x) for x in info]))
+
+    def msm_bases_free(self, handle):
+        self.lib.zg_msm_bases_free.restype = None
+        self.lib.zg_msm_bases_free(handle)
+
+    def msm_resident(self, handle, scalars, n, dense_hint=False, g2=False):
+        """scalars: host bytes / uint8 array, or an int host address (e.g. of a pinned buffer)."""
+        out = np.zeros(192 if g2 else 96, dtype=np.uint8)
+        ptr = C.c_void_p(scalars) if isinstance(scalars, int) else _ptr(_u8(scalars))
+        self._check(self.lib.zg_msm_resident(self.h, handle, ptr, C.c_size_t(n), C.c_int(int(dense_hint)), _ptr(out)))
+        return out.tobytes()
+
+    def msm_resident_dev(self, handle, d_scalars, n, dense_hint=False, g2=False):
+        out = np.zeros(192 if g2 else 96, dtype=np.uint8)
+        self._check(self.lib.zg_msm_resident_dev(self.h, handle, C.c_void_p(d_scalars), C.c_size_t(n),
+                                                 C.c_int(int(dense_hint)), _ptr(out)))
+        return out.tobytes()
+
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as a numpy uint8 view (free with host_free(arr))."""
+        p = C.c_void_p()
+        self._check(self.lib.zg_host_alloc(self.h, C.c_size_t(nbytes), C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.zg_host_free(self.h, C.c_void_p(p)))
 
     # ---- NTT / H
     def ntt(self, data, log_m, inverse=False, coset=False):
@@ -374,6 +426,26 @@ class Params:
     @property
     def total_h(self):
         return self.query_total(0)
+
+    def write(self):
+        """Parameters::write bytes of this resident key (needs a key that carries its verifying key)."""
+        need = C.c_size_t()
+        rc = self.ctx.lib.zg_params_write(self.ctx.h, self.h, None, C.c_size_t(0), C.byref(need))
+        if rc != ZG_E_BUFFER_TOO_SMALL:
+            self.ctx._check(rc)
+        out = np.zeros(need.value, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.zg_params_write(self.ctx.h, self.h, _ptr(out), C.c_size_t(out.size), C.byref(need)))
+        return out.tobytes()
+
+    def write_vk(self):
+        """VerifyingKey::write bytes (the prefix of write())."""
+        need = C.c_size_t()
+        rc = self.ctx.lib.zg_params_write_vk(self.h, None, C.c_size_t(0), C.byref(need))
+        if rc != ZG_E_BUFFER_TOO_SMALL:
+            self.ctx._check(rc)
+        out = np.zeros(need.value, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.zg_params_write_vk(self.h, _ptr(out), C.c_size_t(out.size), C.byref(need)))
+        return out.tobytes()
 
     def prepare(self, r1cs, d_witness=None):
         """Build the fixed-base window tables now (otherwise the first prove with this key does it); without a

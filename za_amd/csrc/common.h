@@ -143,6 +143,9 @@ struct MsmDesc {
     size_t fbw_stride = 0;
     // optional subset-sum table for a mostly-0/1 assignment: [n bases][15 sums per 4 positions]
     const void* quad_table = nullptr;
+    // optional, dense jobs run in parts: part k's stream waits for part_gate[k] (e.g. "scalar chunk k has arrived")
+    const hipEvent_t* part_gate = nullptr;
+    int parts = 0;   // 0 = the scheduler's choice
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);

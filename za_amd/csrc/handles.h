@@ -44,3 +44,22 @@ struct zg_params {
     mutable std::mutex fbw_mu;
 };
 
+
+// Resident multiexp bases (bellman's `Arc<Vec<G::Affine>>` source, kept in HBM in device form) with an optional
+// fixed-base window table; see zg_msm_bases_* in include/za_amd.h.
+struct zg_msm_bases {
+    int device = 0;
+    bool g2 = false;
+    uint64_t n = 0;
+    zg::DevBuf bases, table;
+    int c = 0, nwin = 0;
+    // staging for host scalars: device buffer + copy stream + one event per part
+    zg::DevBuf scalars;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t chunk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~zg_msm_bases() {
+        for (auto& e : chunk_ev)
+            if (e) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};

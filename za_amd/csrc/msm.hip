@@ -1162,6 +1162,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // only used by a lone context.  ZA_AMD_H_PARTS overrides the count (1 = one job).
     int parts = 1;
     if (g1[0].dense && g1[0].n >= ((size_t)1 << 20) && live_contexts() == 1) parts = 2;
+    if (g1[0].parts > 0) parts = g1[0].parts;
     if (const char* e = getenv("ZA_AMD_H_PARTS")) parts = atoi(e);
     if (parts < 1) parts = 1;
     if (parts > NS - 4) parts = NS - 4;
@@ -1196,6 +1197,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
                 hp[k]->fbw_nwin = g1[0].fbw_nwin;
                 hp[k]->fbw_stride = g1[0].fbw_stride;
             }
+            if (g1[0].part_gate && g1[0].part_gate[k]) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[slot], g1[0].part_gate[k], 0));
             if (parts > 1) {
                 hp[k]->ev_sorted = ctx->part_ev[2 * k];
                 hp[k]->ev_acc = ctx->part_ev[2 * k + 1];

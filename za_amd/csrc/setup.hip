@@ -168,6 +168,24 @@ extern "C" int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, si
     return zg::on_exception(ctx);
 }
 
+extern "C" int zg_params_write_vk(const zg_params* p, uint8_t* out, size_t cap, size_t* written) try {
+    if (!p || !written) return ZG_E_INVALID_ARG;
+    if (p->ic.empty()) return fail(nullptr, ZG_E_MALFORMED_VERIFYING_KEY, "this key was built without gamma_g2 / ic");
+    ParsedParams pp;
+    pp.alpha_g1 = p->alpha_g1; pp.beta_g1 = p->beta_g1; pp.beta_g2 = p->beta_g2;
+    pp.gamma_g2 = p->gamma_g2;
+    pp.delta_g1 = p->delta_g1; pp.delta_g2 = p->delta_g2;
+    pp.ic = p->ic;
+    std::vector<uint8_t> bytes;
+    write_bellman_vk(pp, &bytes);
+    *written = bytes.size();
+    if (!out || cap < bytes.size()) return ZG_E_BUFFER_TOO_SMALL;
+    memcpy(out, bytes.data(), bytes.size());
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
+
 extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160], zg_params** out, uint8_t* params_out,
                         size_t cap, size_t* written) try {
     if (!ctx || !r || !toxic || !out) return ZG_E_INVALID_ARG;
