@@ -3,13 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W [--log-m 22]
 
-A "step" is one create_proof (zg_prove_dev) of the synthetic 2^log_m R1CS of config 4
-(SHA256-Merkle-like witness: 97 % bits, SplitMix64 seed 0x5A) with R1CS, proving key and witness
-already resident in HBM; r, s are fixed.  N > 1 is launched by torch.distributed.run, one rank per
-GPU: the MSMs shard by base chunk, the NTT stays on rank 0 (za_amd/dist.py).  Rank 0 prints ONE JSON
-line.  `roofline` is for the dominant kernel (G1 bucket accumulation) from HIP-event timings taken
-inside the timed region; `cpu_baseline` times the oracle (a port of bellman's CPU algorithm) on a
-bounded sample of the same workload on this box's host cores.
+A "step" is one create_proof -- zg_prove: the witness comes from (pinned) HOST memory, its upload is part of the
+step, as SURVEY 8(d) defines the metric -- of the synthetic 2^log_m R1CS of config 4 (SHA256-Merkle-like witness:
+97 % bits, SplitMix64 seed 0x5A) with the R1CS and the proving key resident in HBM; r, s are fixed.  N > 1 is launched
+by torch.distributed.run, one rank per GPU: the MSMs shard by base chunk, the NTT stays on rank 0 (za_amd/dist.py).
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (G1 bucket accumulation) from HIP-event timings
+taken inside the timed region; `cpu_baseline` times the oracle (a port of bellman's CPU algorithm) on the same
+workload on this box's host cores.  Secondary keys: prove_dev_ms (witness already in HBM), g1_msm (the metric's second
+half: 2^26 resident G1 bases, scalars uploaded), dense_witness (same size, no 0/1 shortcuts), shard_model (the
+per-rank phases of an 8-way sharded proof measured on this one GPU), concurrent_provers.
 """
 import argparse
 import json
@@ -26,6 +28,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 467.5e9 * 64   # lane v_mad_u64_u32 / s, tools/ubench_valu.hip on this chip
+MADS_PER_MIXED_ADD = 8 * 162 + 2 * 126
 
 
 def parse():
@@ -47,7 +51,11 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages through host memory (debugging only)")
     ap.add_argument("--synthetic-key", action="store_true", help="skip the set-up; use bases with known discrete logs")
-    ap.add_argument("--no-msm", action="store_true", help="skip the standalone 2^log_m G1 MSM (uniform scalars) line")
+    ap.add_argument("--no-msm", action="store_true", help="skip the standalone G1 MSM line")
+    ap.add_argument("--msm-log-n", type=int, default=26, help="standalone G1 MSM: 2^n bases in total (sharded over the ranks)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-witness (bit fraction 0) line")
+    ap.add_argument("--shard-model", type=int, default=8,
+                    help="N = 1 only: also time the phases one rank of a proof sharded W ways would run (0 = skip)")
     return ap.parse_args()
 
 
@@ -78,22 +86,51 @@ def cpu_baseline(ctx, args):
     mp = co.MontParams(vk5[0:64].tobytes(), vk5[64:128].tobytes(), vk5[128:256].tobytes(), vk5[256:320].tobytes(),
                        vk5[320:448].tobytes(), *arrs)
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = os.cpu_count() or 1        # bellman's Worker: one thread per host core
     t0 = time.time()
     proof_cpu, tm = co.prove(mp, csr, sr.witness, 5, 7, threads=threads, timings=True)
     dt = time.time() - t0
-    d_w = ctx.upload(sr.witness)
-    proof_gpu = ctx.prove_dev(P, r1, d_w, 5, 7)
+    proof_gpu = ctx.prove(P, r1, sr.witness, 5, 7)
     ok = proof_cpu == proof_gpu
-    ctx.free(d_w)
     P.close(); r1.close()
     n = sr.n_constraints
     sr.close()
     return {"value": n / dt, "unit": "constraints/s", "cores": threads, "kind": "port",
-            "sample": "oracle/c create_proof (bellman-algorithm port, %d threads) on the same synthetic workload at "
-                      "2^%d constraints: %.2f s (r1cs %.2f, H %.2f, MSM %.2f); proof bytes equal to the GPU's: %s"
+            "sample": "oracle/c create_proof (bellman-algorithm port: c = ceil(ln n) windows, the 8 multiexps' windows "
+                      "in one %d-thread pool, radix-2 FFT) on the same synthetic workload at 2^%d constraints: "
+                      "%.2f s (r1cs %.2f, H %.2f, MSM %.2f); proof bytes equal to the GPU's: %s"
                       % (threads, lg, dt, tm[0], tm[1], tm[2], ok)}
+
+
+def acc_roofline(prof, traffic=None, ipm=None):
+    """roofline object for k_accumulate<Fq> from the level-1 HIP-event profile of a timed region."""
+    acc_ms, acc_n, acc_bytes, acc_units = prof["msm_accumulate_g1"]
+    if not acc_n:
+        return None
+    achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "launches": acc_n, "avg_launch_ms": acc_ms / acc_n, "algorithmic_bytes_per_launch": acc_bytes / acc_n}
+    # secondary, integer-issue ceiling (DESIGN.md section 4): the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
+    # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
+    mads = acc_units * MADS_PER_MIXED_ADD
+    roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "achieved": mads / (acc_ms * 1e-3), "peak": VALU_ISSUE_PEAK,
+                             "frac": mads / (acc_ms * 1e-3) / VALU_ISSUE_PEAK, "mixed_adds_per_launch": acc_units / acc_n}
+    if ipm:
+        roof["alu_secondary"]["valu_instructions_per_mixed_add"] = ipm
+        roof["alu_secondary"]["issue_frac"] = acc_units * ipm / (acc_ms * 1e-3) / VALU_ISSUE_PEAK
+    return roof
+
+
+def profile_json(name, key):
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)).get(key)
+            except Exception:
+                return None
+    return None
 
 
 def main():
@@ -127,7 +164,19 @@ def main():
     ctx = za_amd.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # ---- workload (untimed set-up): R1CS + witness + proving key resident in HBM
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- workload (untimed set-up): R1CS + proving key resident in HBM, witness in pinned host memory
     t_setup = time.time()
     if args.workload == "poseidon":
         from za_amd import workloads
@@ -153,6 +202,7 @@ def main():
     m = 1 << args.log_m
     n_a = sr.n_inputs + r1.a_aux_total
     n_b = r1.b_input_total + r1.b_aux_total
+    full_key = None
     if args.synthetic_key:
         # bases = k_i * G with known discrete logs (tests use this form); same sizes, same prover work
         P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 7000, rank=rank, world=world)
@@ -163,7 +213,12 @@ def main():
             full = P
             P = synth.params_shard(ctx, full, rank, world)
             full.close()
-    d_w = ctx.upload(sr.witness)
+        else:
+            full_key = P
+    w_host = ctx.host_alloc(len(sr.witness))     # pinned: the H2D copy inside every step runs at PCIe speed
+    w_host[:] = sr.witness if isinstance(sr.witness, np.ndarray) else np.frombuffer(sr.witness, dtype=np.uint8)
+    witness_bytes = int(w_host.size)
+    d_w = ctx.upload(w_host)
     P.prepare(r1, d_w)         # fixed-base window tables (of this rank's shard): once per key, not per proof
     n_constraints = sr.n_constraints
     nnz = list(sr.nnz)
@@ -172,20 +227,21 @@ def main():
     t_setup = time.time() - t_setup
     r_blind, s_blind = 0x1234567, 0x7654321
 
+    phase_acc = {}
     if world > 1:
         from za_amd.dist import GpuEngine, sharded_prove
         engine = GpuEngine(ctx, P, r1, d_w, world)
 
         def step():
-            return sharded_prove(engine, r_blind, s_blind)
+            ctx.h2d(d_w, w_host)       # every rank's copy of the witness arrives over its own PCIe link, inside the step
+            tm = {}
+            out = sharded_prove(engine, r_blind, s_blind, timings=tm)
+            for k, v in tm.items():
+                phase_acc[k] = phase_acc.get(k, 0.0) + v
+            return out
     else:
         def step():
-            return ctx.prove_dev(P, r1, d_w, r_blind, s_blind)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            return ctx.prove(P, r1, w_host, r_blind, s_blind)
 
     proof = None
     # level 1: HIP events around the accumulation kernels only (the roofline's kernel).  Timing every kernel class
@@ -194,6 +250,7 @@ def main():
     for _ in range(args.warmup):
         proof = step()
     ctx.profile_reset()
+    phase_acc.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -202,6 +259,33 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     phases = ctx.last_timings()
+    phase_ms = {k: v / max(args.steps, 1) for k, v in phase_acc.items()}
+    elapsed = max_over_ranks(elapsed)
+    dist_line = None
+    if world > 1:
+        # the north-star's multi-GPU target is MSM scaling: per-proof MSM phase = witness MSMs + h MSM, max over ranks
+        msm_phase = max_over_ranks(phase_ms.get("witness_msm", 0.0) + phase_ms.get("h_msm", 0.0))
+        h_msm = max_over_ranks(phase_ms.get("h_msm", 0.0))
+        dist_line = {"msm_phase_ms": msm_phase, "h_msm_ms": h_msm,
+                     "witness_msm_ms_rank0_beside_ntt": phase_ms.get("witness_msm"),
+                     "h_ntt_ms": phase_ms.get("h_total"), "scatter_ms": phase_ms.get("scatter"),
+                     "gather_ms": phase_ms.get("gather"), "combine_ms": phase_ms.get("combine"),
+                     "note": "host wall times per proof; h_ntt_ms = rank 0's R1CS evaluation + 7 NTTs from start to "
+                             "finish (its witness MSMs run beside them); msm_phase_ms = max over ranks of witness MSMs + "
+                             "h MSM of the rank's 1/%d shard" % world}
+
+    # secondary: the same proofs with the witness already in HBM (round 1's headline form)
+    barrier()
+    t1 = time.perf_counter()
+    n_dev = max(3, args.steps // 2)
+    if world == 1:
+        for _ in range(n_dev):
+            ctx.prove_dev(P, r1, d_w, r_blind, s_blind)
+        torch.cuda.synchronize()
+        prove_dev_ms = 1e3 * (time.perf_counter() - t1) / n_dev
+    else:
+        prove_dev_ms = None
+
     # per-class kernel times: a separate, untimed, fully instrumented pass
     ctx.profile_enable(2)
     ctx.profile_reset()
@@ -211,15 +295,12 @@ def main():
     barrier()
     prof_all = ctx.profile_get()
     ctx.profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     conc_line = None
     if args.provers > 1 and world == 1:
-        # throughput with several provers sharing the GPU (one zg_ctx + host thread each, same resident key): the
-        # second prover's NTT phase fills the low-occupancy sort / reduction tails of the first one's h multiexp
+        # throughput with several provers sharing the GPU (one zg_ctx + host thread each, same resident key, each
+        # uploading its witness from pinned memory): one prover's upload and NTT phase fill the other's sort /
+        # reduction tails
         import threading
         ctxs = [ctx] + [za_amd.Context(local_rank) for _ in range(args.provers - 1)]
         per = max(4, args.steps)
@@ -227,7 +308,7 @@ def main():
 
         def work(i, k):
             for _ in range(k):
-                outs[i] = ctxs[i].prove_dev(P, r1, d_w, r_blind, s_blind)
+                outs[i] = ctxs[i].prove(P, r1, w_host, r_blind, s_blind)
         for i in range(args.provers):
             work(i, 1)
         torch.cuda.synchronize()
@@ -240,61 +321,134 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
         conc_line = {"provers": args.provers, "proofs": per * args.provers, "ms_per_proof": 1e3 * el / (per * args.provers),
-                     "constraints_per_s": n_constraints * per * args.provers / el,
+                     "constraints_per_s": n_constraints * per * args.provers / el, "witness": "host (pinned), uploaded per proof",
                      "identical_proofs": all(bytes(o) == bytes(proof) for o in outs)}
         for c in ctxs[1:]:
             c.close()
 
-    msm_line = None
-    if not args.no_msm and world == 1:
-        # second half of BASELINE.json's metric: G1 MSM points/s, bases resident in HBM (ABI form), uniform scalars
-        d_b = synth.synth_bases_g1(ctx, m, 4242)
-        d_s = synth.synth_scalars(ctx, m, 99)
-        ctx.msm_g1_dev(d_b, d_s, m)
+    shard_line = None
+    if world == 1 and args.shard_model > 1 and full_key is not None and args.workload == "synthetic":
+        # What ONE rank of a W-way sharded proof does, measured here: the MSM phase over a 1/W shard of every query
+        # (with its own tables), and the unsharded R1CS evaluation + H pipeline that stays on rank 0.
+        W = args.shard_model
+        Pk = synth.params_shard(ctx, full_key, 0, W)
+        Pk.prepare(r1, d_w)
+        d_h = ctx.alloc(32 * (m + W))
+        ctx.prove_h_dev(r1, d_w, d_h)
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.prove_h_dev(r1, d_w, d_h)
+            t2 = time.perf_counter()
+            ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x1e)
+            t3 = time.perf_counter()
+            ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x01)
+            t4 = time.perf_counter()
+            ts.append((t2 - t1, t3 - t2, t4 - t3))
+        ts = np.array(ts[1:]) * 1e3
+        full_w = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ctx.prove_partials_dev(full_key, r1, d_w, d_h, 0x1e)
+            t2 = time.perf_counter()
+            ctx.prove_partials_dev(full_key, r1, d_w, d_h, 0x01)
+            full_w.append((t2 - t1, time.perf_counter() - t2))
+        full_w = np.array(full_w[1:]) * 1e3
+        shard_line = {"world": W, "h_ntt_ms": float(ts[:, 0].mean()), "witness_msm_ms": float(ts[:, 1].mean()),
+                      "h_msm_ms": float(ts[:, 2].mean()), "msm_phase_ms": float(ts[:, 1:].sum(axis=1).mean()),
+                      "unsharded_msm_phase_ms": float(full_w.sum(axis=1).mean()),
+                      "msm_scaling_model": float(full_w.sum(axis=1).mean() / ts[:, 1:].sum(axis=1).mean()),
+                      "note": "one GPU, phases run one after the other (no overlap): rank 0's shard of a proof sharded %d ways "
+                              "vs the same phases unsharded; the scatter of (m*32 B)/%d per xGMI link is not included" % (W, W)}
+        ctx.free(d_h)
+        Pk.close()
+
+    dense_line = None
+    if world == 1 and not args.no_dense and args.workload == "synthetic" and args.bit_fraction > 0:
+        # the same size with a witness of uniform field elements: no 0/1 shortcut in the R1CS evaluation, no subset-sum
+        # tables, five full-width Pippenger jobs (window tables on all five queries)
+        sd = synth.SynthR1CS(args.log_m, 2, 0.0, args.seed)
+        rd = sd.load(ctx)
+        Pd = ctx.setup(rd, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+        wd = ctx.host_alloc(len(sd.witness))
+        wd[:] = sd.witness
+        for _ in range(2):
+            ctx.prove(Pd, rd, wd, r_blind, s_blind)
         torch.cuda.synchronize()
+        nd = max(3, args.steps // 2)
         t1 = time.perf_counter()
-        for _ in range(5):
-            ctx.msm_g1_dev(d_b, d_s, m)
+        for _ in range(nd):
+            ctx.prove(Pd, rd, wd, r_blind, s_blind)
         torch.cuda.synchronize()
-        msm_line = {"points_per_s": 5 * m / (time.perf_counter() - t1), "points": m, "unit": "points/s",
-                    "note": "zg_msm_g1_dev, 2^%d bases, uniform 253-bit scalars, includes the ABI-form -> device-form "
-                            "conversion of the bases on every call" % args.log_m}
-        ctx.free(d_b); ctx.free(d_s)
+        el = time.perf_counter() - t1
+        dense_line = {"ms_per_proof": 1e3 * el / nd, "constraints_per_s": sd.n_constraints * nd / el,
+                      "tables_gb": sum(Pd.table_info(k)[1] for k in range(5)) / 1e9,
+                      "note": "bit fraction 0: every witness value and coefficient a uniform field element (config 5's shape at "
+                              "this size); zg_prove from pinned host memory"}
+        ctx.host_free(wd)
+        Pd.close(); rd.close(); sd.close()
+
+    msm_line = None
+    if not args.no_msm:
+        # second half of BASELINE.json's metric: G1 MSM points/s -- bases resident in HBM (device form + window table),
+        # uniform scalars uploaded from pinned host memory inside the timed region.  N > 1: the 2^n bases are sharded
+        # over the ranks, every rank uploads and multiplies its shard, the 96-byte partial sums are all-gathered and
+        # added (RCCL has no point-add reduction).
+        n_total = 1 << args.msm_log_n
+        n_mine = n_total // world
+        d_b = synth.synth_bases_g1(ctx, n_mine, 4242 + (rank << 32))
+        d_s = synth.synth_scalars(ctx, n_mine, 99 + rank)
+        H = ctx.msm_bases_g1_dev(d_b, n_mine, table_budget_gb=120.0)
+        ctx.free(d_b)
+        s_host = ctx.host_alloc(32 * n_mine)
+        s_host[:] = ctx.d2h(d_s, 32 * n_mine)
+        binfo = ctx.msm_bases_info(H)
+
+        def msm_step(resident):
+            part = ctx.msm_resident_dev(H, d_s, n_mine, True) if resident else ctx.msm_resident(H, s_host, n_mine, True)
+            if world > 1:
+                t = torch.from_numpy(np.frombuffer(part, dtype=np.uint8).copy()).to("cuda" if args.dist_backend == "nccl" else "cpu")
+                gathered = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(gathered, t)
+                if rank == 0:
+                    return za_amd.g1_sum(torch.cat(gathered).cpu().numpy())
+                return None
+            return part
+        msm_step(False); msm_step(True)
+        ctx.profile_enable(1)
+        ctx.profile_reset()
+        k_msm = 5
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_msm):
+            msm_step(False)
+        barrier()
+        el_up = max_over_ranks(time.perf_counter() - t1)
+        prof_msm = ctx.profile_get()
+        ctx.profile_enable(0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_msm):
+            msm_step(True)
+        barrier()
+        el_res = max_over_ranks(time.perf_counter() - t1)
+        msm_line = {"points_per_s": k_msm * n_total / el_up, "points": n_total, "unit": "points/s", "ms_per_msm": 1e3 * el_up / k_msm,
+                    "points_per_s_scalars_resident": k_msm * n_total / el_res, "ms_per_msm_scalars_resident": 1e3 * el_res / k_msm,
+                    "sharding": "%d ranks x 2^%d/%d bases" % (world, args.msm_log_n, world) if world > 1 else "single GPU",
+                    "table": {"gb": binfo["table_bytes"] / 1e9, "c": binfo["c"], "digits": binfo["nwin"]},
+                    "roofline": acc_roofline(prof_msm),
+                    "note": "zg_msm_resident: 2^%d G1 bases resident (device form + fixed-base window table), uniform 253-bit "
+                            "scalars uploaded from pinned host memory in 4 chunks overlapped with the 4 dependent parts of the "
+                            "multiexp; *_scalars_resident = zg_msm_resident_dev" % args.msm_log_n}
+        ctx.host_free(s_host)
+        ctx.msm_bases_free(H)
+        ctx.free(d_s)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-        acc_ms, acc_n, acc_bytes, acc_units = prof["msm_accumulate_g1"]
-        roof = None
-        if acc_n:
-            achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("msm_accumulate_g1_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "launches": acc_n, "avg_launch_ms": acc_ms / acc_n,
-                    "algorithmic_bytes_per_launch": acc_bytes / acc_n}
-            # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add
-            # = 8 mul + 2 sqr in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32.  Peak = tools/ubench_valu.hip:
-            # 467.5 G wave-instr/s * 64 lanes on this chip.
-            mads = acc_units * (8 * 162 + 2 * 126)
-            roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "achieved": mads / (acc_ms * 1e-3),
-                                     "peak": 467.5e9 * 64, "frac": mads / (acc_ms * 1e-3) / (467.5e9 * 64),
-                                     "mixed_adds_per_launch": acc_units / acc_n}
-            # all VALU instructions, not only the multiplications' mads: instructions per mixed add from the
-            # SQ_INSTS_VALU pass (profiles/r01_pmc_valu_instructions.json) against the same measured issue rate
-            vpath = os.path.join(ROOT, "profiles", "r01_pmc_valu_instructions.json")
-            if os.path.exists(vpath):
-                try:
-                    ipm = json.load(open(vpath))["k_accumulate_g1_valu_instructions_per_wave_mixed_add"]
-                    roof["alu_secondary"]["valu_instructions_per_mixed_add"] = ipm
-                    roof["alu_secondary"]["issue_frac"] = acc_units * ipm / (acc_ms * 1e-3) / (467.5e9 * 64)
-                except Exception:
-                    pass
+        roof = acc_roofline(prof, traffic=profile_json("pmc_traffic", "msm_accumulate_g1_bytes_per_launch"),
+                            ipm=profile_json("pmc_valu_instructions", "k_accumulate_g1_valu_instructions_per_wave_mixed_add"))
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -308,9 +462,12 @@ def main():
                                    % (100 * args.bit_fraction, args.seed, args.log_m,
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
                                       else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
+                       "step": "zg_prove: witness (%d bytes) uploaded from pinned host memory inside every step, R1CS and key resident"
+                               % witness_bytes,
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
+            "prove_dev_ms": prove_dev_ms,
             "phases_ms_last_step": phases,
             "kernel_ms_per_step": {k: v[0] / n_break for k, v in prof_all.items()},
             "setup_s": t_setup,
@@ -318,8 +475,14 @@ def main():
                                   "gb": P.table_info(k)[1] / 1e9} for k, name in enumerate(("h", "l", "a", "b_g1", "b_g2"))},
             "proof_sha": __import__("hashlib").sha256(bytes(proof)).hexdigest()[:16] if proof is not None else None,
         }
+        if dist_line:
+            line["sharded_phases"] = dist_line
         if msm_line:
             line["g1_msm"] = msm_line
+        if dense_line:
+            line["dense_witness"] = dense_line
+        if shard_line:
+            line["shard_model"] = shard_line
         if conc_line:
             line["concurrent_provers"] = conc_line
         if not args.no_cpu_baseline and world == 1 and args.workload == "synthetic":
@@ -336,6 +499,7 @@ def main():
     # explicit teardown (keeps profilers that hook process exit happy)
     try:
         ctx.free(d_w)
+        ctx.host_free(w_host)
         P.close()
         r1.close()
         ctx.close()

@@ -105,6 +105,9 @@ int zg_msm_bases_info(const zg_msm_bases* b, uint64_t info[4]);
 int zg_msm_resident(zg_ctx* ctx, zg_msm_bases* b, const uint8_t* scalars32, size_t n, int dense_hint, uint8_t* out_jac);
 int zg_msm_resident_dev(zg_ctx* ctx, const zg_msm_bases* b, const void* d_scalars, size_t n, int dense_hint,
                         uint8_t* out_jac);
+/* Sum of `count` Jacobian G1 points (96 bytes each, as returned above): combines the partial results of a multiexp
+ * sharded over several GPUs once they have been gathered.  Host, no ctx. */
+int zg_g1_sum(const uint8_t* jac96, size_t count, uint8_t out_jac[96]);
 /* Pinned (page-locked) host memory for witnesses and scalars handed to zg_prove / zg_msm_resident. */
 int zg_host_alloc(zg_ctx* ctx, size_t bytes, void** out);
 int zg_host_free(zg_ctx* ctx, void* p);

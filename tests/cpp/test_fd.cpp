@@ -6,8 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <vector>
 
-#include "../../za_amd/csrc/ecd.h"
+#include "../../za_amd/csrc/nttd.h"
 
 using namespace zg;
 
@@ -84,6 +85,26 @@ static void test_field(const char* name) {
         CHECK(canon_of<P29>(big.reduce()) == bigm.from_mont());
         CHECK(canon_of<P29>(big * bd) == (bigm * bm).from_mont());
         CHECK(big.is_zero_mod_p() == bigm.is_zero());
+        // lazy limbs: sums / differences without carry propagation feeding multiplications, one-reduction a0 b0 + a1 b1
+        {
+            D l2 = D::add_lazy(ad, bd);                                   // limbs < 2^30
+            CHECK(canon_of<P29>(l2 * bd) == ((am + bm) * bm).from_mont());
+            CHECK(canon_of<P29>(l2.norm()) == (am + bm).from_mont());
+            D l3 = D::add_lazy(l2, ad);                                   // limbs < 3 * 2^29
+            D dl = D::template sub_lazy<4, 31>(bd, l3);                   // b - (2a + b) + 4p
+            CHECK(canon_of<P29>(dl.norm()) == (bm - (am + am + bm)).from_mont());
+            D d29 = D::template sub_lazy<2, 29>(ad, bd);                  // limbs < 3 * 2^29: still a valid factor
+            CHECK(canon_of<P29>(d29 * ad) == ((am - bm) * am).from_mont());
+            D nb = bd.template neg_lazy<2, 29>();
+            CHECK(canon_of<P29>(nb * ad) == (bm.neg() * am).from_mont());
+            CHECK(canon_of<P29>(D::mac2(ad, bd, d29.norm(), nb)) == (am * bm + (am - bm) * bm.neg()).from_mont());
+            CHECK(canon_of<P29>(D::mac2(ad, ad, bd, bd)) == (am * am + bm * bm).from_mont());
+            // the one-multiply zero filter never misses a multiple of p
+            D z = D::template sub<2>(ad, ad);
+            CHECK(z.template maybe_zero_mod_p<16>() && (z + z + z).template maybe_zero_mod_p<16>());
+            CHECK(D::add_lazy(z, z).template maybe_zero_mod_p<16>());
+            if (!(am - bm).is_zero()) CHECK(!(d29.template maybe_zero_mod_p<16>() && d29.norm().is_zero_mod_p()));
+        }
         // pack / unpack of a reduced value
         F mem; big.reduce().store(&mem);
         CHECK(canon_of<P29>(D::load_red(&mem)) == bigm.from_mont());
@@ -166,7 +187,7 @@ static void test_curve(const char* name, const Affine<F>& gen) {
             const Affine<F>& b = (k & 1) ? q : r;
             const AffD<L>& bd = (k & 1) ? qd : rd;
             hacc = hacc.add_mixed(neg ? b.neg() : b);
-            dacc = dacc.add_mixed(neg ? bd.negated() : bd);
+            dacc = dacc.add_mixed(neg ? ((k & 2) ? bd.negated_lazy() : bd.negated()) : bd);
             CHECK((same_point<L, F>(dacc, hacc)));
         }
         // store / load round trip
@@ -186,6 +207,9 @@ static void test_curve(const char* name, const Affine<F>& gen) {
         XD one = XD::from_affine(pd);
         CHECK((same_point<L, F>(one.add_mixed(pd), XH::from_affine(p).dbl())));
         CHECK(one.add_mixed(pd.negated()).is_inf());
+        CHECK(one.add_mixed(pd.negated_lazy()).is_inf());
+        CHECK((same_point<L, F>(XD::inf().add_mixed(pd.negated_lazy()).add_mixed(qd), XH::from_affine(p.neg()).add_mixed(q))));
+        CHECK((same_point<L, F>(XD::from_affine(pd.negated()).add_mixed(pd.negated_lazy()), XH::from_affine(p.neg()).dbl())));
         CHECK((same_point<L, F>(XD::inf().add_mixed(pd), XH::from_affine(p))));
         Affine<F> infm = Affine<F>::inf();
         CHECK((same_point<L, F>(one.add_mixed(AffD<L>::load(&infm)), XH::from_affine(p))));
@@ -206,7 +230,91 @@ static void test_curve(const char* name, const Affine<F>& gen) {
     printf("%s curve ok\n", name);
 }
 
+// ---- NTT butterflies: a whole pass of k stages on a small tile, exactly as k_ntt_pass schedules it (an odd stage
+// count starts with one radix-2 stage, then radix-4 pairs; DIF reduces every 2nd stage and after the last one), with
+// the bound tracking of ZG_FD_DEBUG checking every lazy sum / difference, against a plain radix-2 transform in Fr.
+static void test_ntt_passes() {
+    for (int k = 1; k <= 9; k++) {
+        for (int dit = 0; dit < 2; dit++) {
+            const int n = 1 << k;
+            // omega of order n
+            Fr g = Fr::from_u64(7);
+            uint32_t e[8];
+            for (int i = 0; i < 8; i++) e[i] = FrParams::MOD[i];
+            e[0] -= 1;
+            // (r - 1) / n
+            uint32_t q[8];
+            for (int i = 0; i < 8; i++) q[i] = (e[i] >> k) | (i < 7 ? (e[i + 1] << (32 - k)) : 0);
+            Fr omega = g.pow(q);
+            std::vector<Fr> in(n), ref(n);
+            for (int i = 0; i < n; i++) in[i] = rand_canon<FrParams>().to_mont();
+            // reference: out[j] = sum_i in[i] omega^(i j)
+            std::vector<Fr> wpow(n);
+            wpow[0] = Fr::one();
+            for (int i = 1; i < n; i++) wpow[i] = wpow[i - 1] * omega;
+            for (int j = 0; j < n; j++) {
+                Fr acc = Fr::zero();
+                for (int i = 0; i < n; i++) acc = acc + in[i] * wpow[(size_t)i * j % n];
+                ref[j] = acc;
+            }
+            auto brev = [&](int x) { int r = 0; for (int b = 0; b < k; b++) r |= ((x >> b) & 1) << (k - 1 - b); return r; };
+            // tile of lazy values (device form): worst-case entry bound 2.01 p, as after load_red
+            std::vector<FrD> t(n);
+            for (int i = 0; i < n; i++) {
+                Fr c = in[dit ? brev(i) : i].from_mont();
+                t[i] = fd_of<Fr29>(c);
+                t[i].ub = 2.01;
+            }
+            auto tw = [&](size_t exp_) {   // omega^exp as a canonical device value
+                Fr c = wpow[exp_ % n].from_mont();
+                FrD w = fd_of<Fr29>(c).canonical();
+                return w;
+            };
+            auto reduces = [&](int it) { return (it & 1) != 0 || it == k - 1; };
+            int it = 0;
+            if (k & 1) {
+                const int qb = dit ? 0 : k - 1;
+                for (int b = 0; b < n / 2; b++) {
+                    int i0 = ((b >> qb) << (qb + 1)) | (b & ((1 << qb) - 1)), i1 = i0 | (1 << qb);
+                    size_t texp = (size_t)(i0 & ((1 << qb) - 1)) << (k - 1 - qb);
+                    if (dit) ntt_dit2(t[i0], t[i1], tw(texp));
+                    else ntt_dif2(t[i0], t[i1], tw(texp), reduces(0));
+                }
+                it = 1;
+            }
+            for (; it < k; it += 2) {
+                const int qlo = dit ? it : k - 2 - it;
+                for (int gq = 0; gq < n / 4; gq++) {
+                    int i00 = ((gq >> qlo) << (qlo + 2)) | (gq & ((1 << qlo) - 1));
+                    int i01 = i00 | (1 << qlo), i10 = i00 | (2 << qlo), i11 = i01 | i10;
+                    size_t low = (size_t)(i00 & ((1 << qlo) - 1));
+                    size_t t1 = low << (k - 1 - qlo), t2 = low << (k - 2 - qlo), t3 = t2 + ((size_t)1 << (k - 2));
+                    if (dit) ntt_dit4(t[i00], t[i01], t[i10], t[i11], tw(t1), tw(t2), tw(t3));
+                    else ntt_dif4(t[i00], t[i01], t[i10], t[i11], tw(t1), tw(t2), tw(t3), reduces(it), reduces(it + 1));
+                }
+            }
+            for (int i = 0; i < n; i++) {
+                Fr got;
+                t[i].reduce().store(&got);   // what the pass writes back (asserts the 2^256 packing bound)
+                Fr want = ref[dit ? i : brev(i)];
+                Fr got_m = canon_of<Fr29>(FrD::load_red(&got)).to_mont();
+                CHECK(got_m == want);
+            }
+        }
+    }
+    // twiddle tables in limb form
+    {
+        Fr c = rand_canon<FrParams>();
+        FrD w = fd_of<Fr29>(c).canonical();
+        FrLimbs mem;
+        store_limbs(&mem, w);
+        CHECK(canon_of<Fr29>(load_limbs(&mem)) == c);
+    }
+    printf("NTT passes ok\n");
+}
+
 int main() {
+    test_ntt_passes();
     test_field<Fq29>("Fq");
     test_field<Fr29>("Fr");
     G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};

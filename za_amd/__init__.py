@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "zg_dev_alloc", "zg_dev_free", "zg_h2d", "zg_d2h",
     "zg_msm_g1", "zg_msm_g2", "zg_msm_g1_dev", "zg_msm_g2_dev",
     "zg_msm_bases_g1", "zg_msm_bases_g1_dev", "zg_msm_bases_g2", "zg_msm_bases_free", "zg_msm_bases_info",
-    "zg_msm_resident", "zg_msm_resident_dev", "zg_host_alloc", "zg_host_free",
+    "zg_msm_resident", "zg_msm_resident_dev", "zg_host_alloc", "zg_host_free", "zg_g1_sum",
     "zg_ntt_fr", "zg_ntt_fr_dev", "zg_h_scalars",
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
@@ -497,6 +497,17 @@ def vk_json(vk_bytes, input_names=()):
     if rc:
         raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
     return buf.value.decode()
+
+
+def g1_sum(jac_points):
+    """Sum of 96-byte Jacobian G1 results (bytes / uint8 array holding k of them)."""
+    lib = load_library()
+    a = _u8(jac_points)
+    out = np.zeros(96, dtype=np.uint8)
+    rc = lib.zg_g1_sum(_ptr(a), C.c_size_t(a.size // 96), _ptr(out))
+    if rc:
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return out.tobytes()
 
 
 def _thread_error(lib, rc):

@@ -39,6 +39,7 @@ struct Ctx {
     hipEvent_t part_ev[2 * (MSM_SLOTS - 4)] = {nullptr};   // (sorted, accumulated) per part of the h job
     hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip): borrowed pointers
     hipEvent_t gate_w = nullptr, gate_h = nullptr;     // the ctx's own gate events (created lazily, destroyed by zg_free)
+    hipEvent_t tm_ev[3] = {nullptr, nullptr, nullptr};  // timing of the H pipeline inside zg_prove_dev: start, R1CS evaluation done, H done
     bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
 };

@@ -37,6 +37,28 @@ struct FqL {
     static ZG_HD T mul(const T& a, const T& b) { return a * b; }
     static ZG_HD T sqr(const T& a) { return a.sqr(); }
     static ZG_HD T inv(const T& a) { return a.inv(); }
+    // hot-path variants (add_mixed): over Fq2 they skip the reduction of the result; here they are the plain operations
+    template <int KB>
+    static ZG_HD T mulx(const T& a, const T& b) { return a * b; }
+    template <int K>
+    static ZG_HD T sqrx(const T& a) { return a.sqr(); }
+    // lazy-limb forms (fd.h): results may only feed a multiplication (or norm())
+    static ZG_HD T add_lazy(const T& a, const T& b) { return T::add_lazy(a, b); }
+    template <int K, int S>
+    static ZG_HD T sub_lazy(const T& a, const T& b) { return T::template sub_lazy<K, S>(a, b); }
+    static ZG_HD T norm(const T& a) { return a.norm(); }
+    // -y for a canonical y (as 2p - y): only ever multiplied
+    static ZG_HD T neg_canon_lazy(const T& y) { return y.template neg_lazy<2, 29>(); }   // 2p - y: the spread form of 1p has no room in its top limb
+    template <int KMAX>
+    static ZG_HD bool maybe_zero_mod_p(const T& a) { return a.template maybe_zero_mod_p<KMAX>(); }
+    // r*t - y*w for normalised r, y, w (w < 2p) and t = qq - x3 formed inside: ONE reduction for both products.
+    // qq, x3 normalised, x3 < KX p.
+    template <int KX>
+    static ZG_HD T mul_sub_of_diff(const T& r, const T& qq, const T& x3, const T& y, const T& w) {
+        const T t = T::template sub_lazy<KX, 29>(qq, x3);
+        const T nw = w.template neg_lazy<2, 29>();
+        return T::mac2(r, t, y, nw);
+    }
 };
 
 struct Fq2D {
@@ -66,19 +88,47 @@ struct Fq2L {
     static ZG_HD T sub(const T& a, const T& b) {
         return T{FqD::sub<K>(a.c0, b.c0), FqD::sub<K>(a.c1, b.c1)};
     }
-    // Karatsuba; component bounds up to 18 p are safe (aa, bb <= 18*18/168.8 + 1 < 3)
-    static ZG_HD T mul(const T& a, const T& b) {
-        FqD aa = a.c0 * b.c0;
-        FqD bb = a.c1 * b.c1;
-        FqD o = (a.c0 + a.c1) * (b.c0 + b.c1);
-        return T{FqD::sub<3>(aa, bb).reduce(), FqD::sub<6>(o, aa + bb).reduce()};
+    // c0 = a0 b0 - a1 b1 and c1 = a0 b1 + a1 b0, each as ONE fused multiply-accumulate with a single Montgomery
+    // reduction (FqD::mac2): 2 x 243 multiply-adds and no additions, against Karatsuba's 3 x 162 + five additions + two
+    // reductions.  b must be normalised with components below KB p (its c1 is negated limb-wise); a may be a lazy
+    // sum of two normalised values.  Results are normalised, below (|a0||b0| + |a1| KB) / 168.8 + 1.
+    template <int KB>
+    static ZG_HD T mulx(const T& a, const T& b) {
+        const FqD nb1 = b.c1.template neg_lazy<KB, 29>();
+        return T{FqD::mac2(a.c0, b.c0, a.c1, nb1), FqD::mac2(a.c0, b.c1, a.c1, b.c0)};
     }
-    // (c0 + c1)(c0 - c1), 2 c0 c1; needs c1 <= 16 p
+    // general form: components up to 18 p in, reduce()d components out (< 2.01 p, so MB = 3 holds everywhere)
+    static ZG_HD T mul(const T& a, const T& b) {
+        const T r = mulx<18>(a, b);
+        return T{r.c0.reduce(), r.c1.reduce()};
+    }
+    // (c0 + c1)(c0 - c1), c0 * 2 c1 with the sums formed limb-wise; components normalised and below K p
+    template <int K>
+    static ZG_HD T sqrx(const T& a) {
+        const FqD s = FqD::add_lazy(a.c0, a.c1);
+        const FqD d = FqD::sub<K>(a.c0, a.c1);
+        return T{s * d, a.c0 * FqD::add_lazy(a.c1, a.c1)};
+    }
     static ZG_HD T sqr(const T& a) {
-        FqD s = a.c0 + a.c1;
-        FqD d = FqD::sub<16>(a.c0, a.c1);
-        FqD m = a.c0 * a.c1;
-        return T{(s * d).reduce(), m.dbl().reduce()};
+        const T r = sqrx<16>(a);
+        return T{r.c0.reduce(), r.c1.reduce()};
+    }
+    static ZG_HD T add_lazy(const T& a, const T& b) { return T{FqD::add_lazy(a.c0, b.c0), FqD::add_lazy(a.c1, b.c1)}; }
+    template <int K, int S>
+    static ZG_HD T sub_lazy(const T& a, const T& b) {
+        return T{FqD::sub_lazy<K, S>(a.c0, b.c0), FqD::sub_lazy<K, S>(a.c1, b.c1)};
+    }
+    static ZG_HD T norm(const T& a) { return T{a.c0.norm(), a.c1.norm()}; }
+    static ZG_HD T neg_canon_lazy(const T& y) { return T{y.c0.template neg_lazy<2, 29>(), y.c1.template neg_lazy<2, 29>()}; }
+    template <int KMAX>
+    static ZG_HD bool maybe_zero_mod_p(const T& a) {
+        return a.c0.template maybe_zero_mod_p<KMAX>() && a.c1.template maybe_zero_mod_p<KMAX>();
+    }
+    // r*(qq - x3) - y*w: over Fq2 the difference is normalised (a lazy 3-limb-unit operand would overflow a mac2 column)
+    template <int KX>
+    static ZG_HD T mul_sub_of_diff(const T& r, const T& qq, const T& x3, const T& y, const T& w) {
+        const T t = sub<KX>(qq, x3);
+        return sub<MB>(mulx<MB + 2 * MB>(t, r), mulx<MB>(y, w));
     }
     static ZG_HD T inv(const T& a) {
         FqD n = (a.c0.sqr() + a.c1.sqr()).inv();
@@ -101,6 +151,19 @@ struct AffD {
     ZG_HD AffD negated() const {  // y in [0, p]  ->  p - y
         AffD r = *this;
         if (!inf) r.y = L::template sub<1>(L::zero(), y);
+        return r;
+    }
+    // normalised coordinates again (the rare doubling branch of add_mixed needs sums of y)
+    ZG_HD AffD y_canonical() const {
+        AffD r = *this;
+        r.y = L::norm(y);
+        return r;
+    }
+    // the same with limb-wise subtraction only (9 instructions): y may then only be multiplied -- which is all
+    // add_mixed does with it
+    ZG_HD AffD negated_lazy() const {
+        AffD r = *this;
+        if (!inf) r.y = L::neg_canon_lazy(y);
         return r;
     }
 };
@@ -153,24 +216,36 @@ struct XYZZd {
         T y3 = L::template sub<MB>(L::mul(m, L::template sub<3 * MB>(s, x3)), L::mul(w, p.y));
         return XYZZd{x3, y3, v, w};
     }
-    // this + affine q
+    // this + affine q  (madd-2008-s: 8M + 2S).  q.y may be a lazily negated canonical value.  Sums and differences that
+    // only feed a multiplication skip carry propagation (fd.h "lazy limbs"), the y3 = r (qq - x3) - y ppp pair of
+    // products shares one Montgomery reduction over Fq, and the doubling / inverse test starts with a one-multiply
+    // filter.  All four outputs are normalised: X <= BX, Y <= BY, ZZ, ZZZ <= MB.
     ZG_HD XYZZd add_mixed(const AffD<L>& q) const {
         if (q.inf) return *this;
-        if (is_inf()) return from_affine(q);
-        T u2 = L::mul(q.x, zz);
-        T s2 = L::mul(q.y, zzz);
+        if (is_inf()) return from_affine(q.y_canonical());
+        T u2 = L::template mulx<MB>(q.x, zz);
+        T s2 = L::template mulx<MB>(q.y, zzz);
         T p = L::template sub<BX>(u2, x);        // <= MB + BX
         T r = L::template sub<BY>(s2, y);        // <= MB + BY
-        if (L::is_zero_mod_p(p)) {
-            if (L::is_zero_mod_p(r)) return dbl_affine(q);
-            return inf();
+        // The candidate flag is made opaque to the optimiser: with a visible `filter && full test` condition clang
+        // threads the two tests into the main path and emits ~120 extra multiply-adds and ~240 moves per addition.
+        uint32_t cand = L::template maybe_zero_mod_p<BX + MB + 1>(p) ? 1u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(cand));
+#endif
+        if (cand) {
+            if (L::is_zero_mod_p(p)) {
+                if (L::is_zero_mod_p(r)) return dbl_affine(q.y_canonical());
+                return inf();
+            }
         }
-        T pp = L::sqr(p);
-        T ppp = L::mul(p, pp);
-        T qq = L::mul(x, pp);
-        T x3 = L::template sub<3 * MB>(L::sqr(r), L::add(ppp, L::add(qq, qq)));       // <= 4 MB = BX
-        T y3 = L::template sub<MB>(L::mul(r, L::template sub<BX>(qq, x3)), L::mul(y, ppp));  // <= 2 MB = BY
-        return XYZZd{x3, y3, L::mul(zz, pp), L::mul(zzz, ppp)};
+        T pp = L::template sqrx<BX + MB>(p);     // Fq2: components up to ~7 p; only ever a factor
+        T ppp = L::template mulx<2 * MB + 2>(p, pp);
+        T qq = L::template mulx<2 * MB + 2>(x, pp);
+        // x3 = r^2 - (ppp + 2 qq): the subtrahend is a limb-wise sum of three normalised values (limbs < 3 * 2^29)
+        T x3 = L::norm(L::template sub_lazy<3 * MB, 31>(L::template sqrx<BY + MB>(r), L::add_lazy(ppp, L::add_lazy(qq, qq))));   // <= 4 MB = BX
+        T y3 = L::template mul_sub_of_diff<BX>(r, qq, x3, y, ppp);                                            // <= 2 MB = BY
+        return XYZZd{x3, y3, L::template mulx<2 * MB + 2>(zz, pp), L::template mulx<MB>(zzz, ppp)};
     }
     ZG_HD XYZZd add(const XYZZd& o) const {
         if (o.is_inf()) return *this;

@@ -17,8 +17,19 @@
 // reduce() before storing).  Conversion from/to the ABI's 2^256 Montgomery form is a multiplication
 // by the constant 32 resp. 1/32.
 //
-// ZG_FD_DEBUG (host unit test only) carries an upper bound in units of p through every operation
-// and asserts the K constants, so the bounds in ec.h are machine-checked rather than hand-waved.
+// Lazy LIMBS (round 2): a limb has three spare bits in its 32-bit register, and a 64-bit column of the multiplier
+// holds 9 products a_i*b_j + 9 products m_i*p_j as long as 9*max(a_i)*max(b_j) + 9*2^58 + 2^36 < 2^64.  So sums and
+// differences that only feed a multiplication need no carry propagation at all:
+//   add_lazy(a, b)        limb-wise sum (9 instructions instead of 33)
+//   sub_lazy<K,S>(a, b)   a + C - b with C = K*p written with limbs >= 2^S - 2^(S-29) (needs limbs of b below that)
+//   neg_lazy<K,S>(b)      C - b
+//   norm()                carry propagation back to limbs < 2^29 (25 instructions)
+//   mac2(a0,b0,a1,b1)     (a0*b0 + a1*b1) / 2^261 with ONE Montgomery reduction: 243 instead of 324 multiply-adds
+// Multiplication results are always normalised.  The "lm" bound (largest limb) is tracked next to the value bound.
+//
+// ZG_FD_DEBUG (host unit test only) carries an upper bound in units of p and the largest-limb bound through every
+// operation and asserts the K constants and the column capacity, so the bounds in ecd.h are machine-checked rather
+// than hand-waved.
 #pragma once
 #include "fp.h"
 #ifdef ZG_FD_DEBUG
@@ -61,12 +72,22 @@ template <class P>
 struct alignas(4) Fd {
     static constexpr uint32_t MASK = (1u << 29) - 1u;
     uint32_t l[9];
+    static constexpr double NORM = 536870911.0;   // largest limb of a normalised value
 #ifdef ZG_FD_DEBUG
     double ub = 0;  // upper bound of the integer value in units of p
+    double lm = 0;  // upper bound of every limb (NORM when normalised)
     static constexpr double CAP = 160.0;
-#define FD_SET_UB(x, v) ((x).ub = (v), assert((x).ub < Fd::CAP))
+#define FD_SET_UB(x, v) ((x).ub = (v), (x).lm = Fd::NORM, assert((x).ub < Fd::CAP))
+#define FD_SET_LM(x, v) ((x).lm = (v), assert((x).lm < 4294967288.0))
+#define FD_NEED_NORM(x) assert((x).lm <= Fd::NORM)
+    // capacity of a multiplier column: 9 products of each listed pair + 9 m*p products + the carry from below
+    static bool column_fits(double sum_of_products) {
+        return 9.0 * sum_of_products + 9.0 * NORM * NORM + 68719476736.0 < 18446744073709551615.0;
+    }
 #else
 #define FD_SET_UB(x, v) ((void)0)
+#define FD_SET_LM(x, v) ((void)0)
+#define FD_NEED_NORM(x) ((void)0)
 #endif
 
     static ZG_HD Fd zero() {
@@ -101,6 +122,7 @@ struct alignas(4) Fd {
     ZG_HD void pack(uint32_t w[8]) const {
 #ifdef ZG_FD_DEBUG
         assert(ub <= 5.28);
+        assert(lm <= NORM);
 #endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -126,6 +148,9 @@ struct alignas(4) Fd {
     }
 
     friend ZG_HD Fd operator+(const Fd& a, const Fd& b) {
+#ifdef ZG_FD_DEBUG
+        assert(a.lm + b.lm < 2147483647.0);
+#endif
         int32_t d[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) d[i] = (int32_t)(a.l[i] + b.l[i]);
@@ -155,6 +180,9 @@ struct alignas(4) Fd {
             assert(false);
         }
 #endif
+#ifdef ZG_FD_DEBUG
+        assert(a.lm + NORM < 2147483647.0 && b.lm < 1073741824.0);
+#endif
         uint32_t kpv[9];
         kp<K>(kpv);
         int32_t d[9];
@@ -164,11 +192,105 @@ struct alignas(4) Fd {
         FD_SET_UB(r, a.ub + K);
         return r;
     }
+
+    // ---- lazy limbs ---------------------------------------------------------------------------------------------
+    // limb-wise sum, no carries
+    static ZG_HD Fd add_lazy(const Fd& a, const Fd& b) {
+        Fd r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+#ifdef ZG_FD_DEBUG
+        r.ub = a.ub + b.ub;
+        assert(r.ub < CAP);
+        FD_SET_LM(r, a.lm + b.lm);
+#endif
+        return r;
+    }
+    // K*p with every limb but the top one raised by 2^S (and the next one lowered by 2^(S-29) to compensate):
+    // limbs 0..7 are >= 2^S - 2^(S-29), so c - b needs no borrow for limbs of b up to that
+    template <int K, int S>
+    static ZG_HD void kp_spread(uint32_t out[9]) {
+        uint32_t base[9];
+        kp<K>(base);
+        constexpr uint32_t UP = 1u << S, DOWN = 1u << (S - 29);
+#pragma unroll
+        for (int i = 0; i < 9; i++) out[i] = base[i] + (i < 8 ? UP : 0u) - (i > 0 ? DOWN : 0u);
+    }
+    // a + K*p - b  without carry propagation; needs value(b) < K*p (with the top-limb margin asserted below) and
+    // every limb of b at most 2^S - 2^(S-29)
+    template <int K, int S>
+    static ZG_HD Fd sub_lazy(const Fd& a, const Fd& b) {
+        uint32_t c[9];
+        kp_spread<K, S>(c);
+        Fd r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (c[i] - b.l[i]);
+#ifdef ZG_FD_DEBUG
+        if (!(b.lm <= (double)(1u << S) - (double)(1u << (S - 29)))) {
+            fprintf(stderr, "Fd::sub_lazy<%d,%d>: subtrahend limb bound %.0f\n", K, S, b.lm);
+            assert(false);
+        }
+        // top limb: floor(V_b / 2^232) <= ub(b) * (P8 + 1) must not exceed c[8]
+        if (!(b.ub * ((double)P::P[8] + 1.0) <= (double)c[8])) {
+            fprintf(stderr, "Fd::sub_lazy<%d,%d>: subtrahend bound %.3f exceeds the top limb of K*p\n", K, S, b.ub);
+            assert(false);
+        }
+        r.ub = a.ub + K;
+        assert(r.ub < CAP);
+        FD_SET_LM(r, a.lm + (double)(1u << S) + NORM);
+#endif
+        return r;
+    }
+    template <int K, int S>
+    ZG_HD Fd neg_lazy() const {
+        uint32_t c[9];
+        kp_spread<K, S>(c);
+        Fd r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = c[i] - l[i];
+#ifdef ZG_FD_DEBUG
+        assert(lm <= (double)(1u << S) - (double)(1u << (S - 29)));
+        assert(ub * ((double)P::P[8] + 1.0) <= (double)c[8]);
+        r.ub = K;
+        FD_SET_LM(r, (double)(1u << S) + NORM);
+#endif
+        return r;
+    }
+    // carry propagation: limbs back below 2^29 (the value is unchanged)
+    ZG_HD Fd norm() const {
+        Fd r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t t = l[i] + c;
+            r.l[i] = t & MASK;
+            c = t >> 29;
+        }
+        r.l[8] = l[8] + c;
+#ifdef ZG_FD_DEBUG
+        r.ub = ub;
+        r.lm = NORM;
+#endif
+        return r;
+    }
+    // cheap necessary condition for value == 0 (mod p): V = k*p with k <= KMAX means the Montgomery quotient digit of
+    // the lowest limb is -k mod 2^29.  False positives have probability ~KMAX / 2^29: follow with is_zero_mod_p().
+    template <int KMAX>
+    ZG_HD bool maybe_zero_mod_p() const {
+        const uint32_t k = (0u - l[0] * P::NINV) & MASK;   // = V * p^-1 mod 2^29
+        return k <= (uint32_t)KMAX;
+    }
     template <int K>
     ZG_HD Fd neg() const { return sub<K>(zero(), *this); }
 
     // Montgomery product, product scanning with 64-bit columns (no carries inside a column)
     friend ZG_HD Fd operator*(const Fd& a, const Fd& b) {
+#ifdef ZG_FD_DEBUG
+        if (!column_fits(a.lm * b.lm)) {
+            fprintf(stderr, "Fd::mul: limb bounds %.0f x %.0f overflow a column\n", a.lm, b.lm);
+            assert(false);
+        }
+#endif
         uint32_t m[9];
         Fd r;
         uint64_t acc = 0;
@@ -196,6 +318,9 @@ struct alignas(4) Fd {
         return r;
     }
     ZG_HD Fd sqr() const {
+#ifdef ZG_FD_DEBUG
+        assert(column_fits(lm * lm) && lm < 2147483648.0);
+#endif
         uint32_t m[9], a2[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) a2[i] = l[i] << 1;
@@ -227,8 +352,49 @@ struct alignas(4) Fd {
         return r;
     }
 
+    // (a0*b0 + a1*b1) / 2^261 with one Montgomery reduction (162 + 81 multiply-adds instead of 2 x 162); the result is
+    // normalised and below (A0 B0 + A1 B1) / 2^261 + p
+    static ZG_HD Fd mac2(const Fd& a0, const Fd& b0, const Fd& a1, const Fd& b1) {
+#ifdef ZG_FD_DEBUG
+        if (!column_fits(a0.lm * b0.lm + a1.lm * b1.lm)) {
+            fprintf(stderr, "Fd::mac2: limb bounds %.0f x %.0f + %.0f x %.0f overflow a column\n", a0.lm, b0.lm, a1.lm, b1.lm);
+            assert(false);
+        }
+#endif
+        uint32_t m[9];
+        Fd r;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)a0.l[i] * b0.l[k - i];
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)a1.l[i] * b1.l[k - i];
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+            m[k] = ((uint32_t)acc * P::NINV) & MASK;
+            acc += (uint64_t)m[k] * P::P[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a0.l[i] * b0.l[k - i];
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a1.l[i] * b1.l[k - i];
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * P::P[k - i];
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        FD_SET_UB(r, (a0.ub * b0.ub + a1.ub * b1.ub) / 168.8 + 1.0);
+        return r;
+    }
+
     // V < 2^261  ->  same residue, < 2.01 p.  q = floor(top / (p_top + 1)) never over-estimates V / p.
     ZG_HD Fd reduce() const {
+        FD_NEED_NORM(*this);
         constexpr uint32_t PTOP1 = P::P[8] + 1u;                       // (p >> 232) + 1
         constexpr uint32_t RECIP = (uint32_t)(0xFFFFFFFFull / PTOP1);  // floor((2^32 - 1) / PTOP1)
         uint32_t q = (uint32_t)(((uint64_t)l[8] * RECIP) >> 32);       // <= floor(l8 / PTOP1)

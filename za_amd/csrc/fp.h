@@ -12,8 +12,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ZG_HD __host__ __device__ __forceinline__
+#define ZG_HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #else
 #define ZG_HD inline
+#define ZG_HD_NOINLINE __attribute__((noinline))
 #endif
 
 namespace zg {

@@ -564,11 +564,33 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
     uint32_t end = offsets[key + 1];
     if (end > start + Tk) end = start + Tk;
     XYZZd<L> acc = XYZZd<L>::inf();
-    for (uint32_t k = start; k < end; k++) {
-        uint32_t e = sorted[k];
-        AffD<L> p = AffD<L>::load(&bases[e & 0x7fffffffu]);
-        if (e >> 31) p = p.negated();
-        acc = acc.add_mixed(p);
+    if constexpr (sizeof(F) == sizeof(Fq)) {
+        // Software pipeline: the gather of point k+1 (index two steps ahead) is in flight while point k is added, so the
+        // ~1 us of dependent load latency (sorted[k] -> bases[...]) hides behind the ~5 us mixed addition instead of
+        // parking the wave (SQ_WAIT_ANY was 13 % of the wave cycles).  16 more VGPRs; G2 has none to spare.
+        if (start < end) {
+            uint32_t e = sorted[start];
+            uint32_t e_next = start + 1 < end ? sorted[start + 1] : 0u;
+            Affine<F> cur = bases[e & 0x7fffffffu];
+            for (uint32_t k = start; k < end; k++) {
+                Affine<F> nxt = cur;
+                if (k + 1 < end) nxt = bases[e_next & 0x7fffffffu];
+                const uint32_t e_nn = k + 2 < end ? sorted[k + 2] : 0u;
+                AffD<L> p = AffD<L>::load(&cur);
+                if (e >> 31) p = p.negated_lazy();   // -y is only multiplied inside add_mixed: no carry propagation
+                acc = acc.add_mixed(p);
+                cur = nxt;
+                e = e_next;
+                e_next = e_nn;
+            }
+        }
+    } else {
+        for (uint32_t k = start; k < end; k++) {
+            uint32_t e = sorted[k];
+            AffD<L> p = AffD<L>::load(&bases[e & 0x7fffffffu]);
+            if (e >> 31) p = p.negated_lazy();
+            acc = acc.add_mixed(p);
+        }
     }
     acc.store(&partial[t]);
 }

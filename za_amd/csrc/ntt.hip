@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "nttd.h"
 
 namespace zg {
 
@@ -25,7 +26,7 @@ static constexpr int GEOM_LO = 10;        // low-table bits for the g^i two-leve
 
 struct NttTables {
     uint32_t log_m = 0;
-    DevBuf tw_fwd, tw_inv;              // omega^i, omega^-i, i < m/2   (Montgomery)
+    DevBuf tw_fwd, tw_inv;              // omega^i, omega^-i, i < m/2   (canonical M261 residues as 9 limbs, FrLimbs)
     DevBuf g_lo, g_hi, g_hi_minv;       // g^j (j < 2^lo), g^(k 2^lo), g^(k 2^lo)/m       (M261)
     DevBuf gi_lo, gi_hi, gi_hi_canon;   // g^-j, g^-(k 2^lo)/m (Montgomery) and the same hi table in canonical form
     Fr minv;                            // 1/m          (M261, for kernels)
@@ -45,6 +46,19 @@ __global__ void __launch_bounds__(256) k_powers(Fr* __restrict__ out, size_t n, 
     FrD cur = base.pow_u64(lo) * FrD::load_canon(&scale_m);
     for (size_t i = lo; i < hi; i++) {
         cur.canonical().store(&out[i]);
+        cur = cur * base;
+    }
+}
+// the same powers in limb form (twiddle tables: nttd.h FrLimbs)
+__global__ void __launch_bounds__(256) k_powers_limbs(FrLimbs* __restrict__ out, size_t n, Fr base_m, uint32_t run) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * run;
+    if (lo >= n) return;
+    size_t hi = lo + run < n ? lo + run : n;
+    const FrD base = FrD::load_canon(&base_m);
+    FrD cur = base.pow_u64(lo);
+    for (size_t i = lo; i < hi; i++) {
+        store_limbs(&out[i], cur.canonical());
         cur = cur * base;
     }
 }
@@ -68,6 +82,15 @@ static int launch_powers(Ctx* ctx, Fr* out, size_t n, const Fr& base, const Fr& 
     size_t threads = (n + run - 1) / run;
     hipLaunchKernelGGL(k_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
                        host_to_m261(base), host_to_m261(scale), run);
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+static int launch_powers_limbs(Ctx* ctx, FrLimbs* out, size_t n, const Fr& base) {
+    uint32_t run = 64;
+    size_t threads = (n + run - 1) / run;
+    hipLaunchKernelGGL(k_powers_limbs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
+                       host_to_m261(base), run);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -105,11 +128,12 @@ static int get_tables(Ctx* ctx, uint32_t log_m, NttTables** out) {
     };
     T->lo_bits = (int)log_m < GEOM_LO ? (int)log_m : GEOM_LO;
     const size_t nlo = (size_t)1 << T->lo_bits, nhi = m >> T->lo_bits;
-    A(T->tw_fwd, half); A(T->tw_inv, half);
+    if (T->tw_fwd.alloc(half * sizeof(FrLimbs)) != hipSuccess || T->tw_inv.alloc(half * sizeof(FrLimbs)) != hipSuccess)
+        rc = fail(ctx, ZG_E_HIP, "hipMalloc of NTT table failed");
     A(T->g_lo, nlo); A(T->g_hi, nhi); A(T->g_hi_minv, nhi); A(T->gi_lo, nlo); A(T->gi_hi, nhi); A(T->gi_hi_canon, nhi);
     if (rc != ZG_OK) { delete T; return rc; }
-    rc = launch_powers(ctx, T->tw_fwd.as<Fr>(), half, omega, Fr::one());
-    if (!rc) rc = launch_powers(ctx, T->tw_inv.as<Fr>(), half, omega_inv, Fr::one());
+    rc = launch_powers_limbs(ctx, T->tw_fwd.as<FrLimbs>(), half, omega);
+    if (!rc) rc = launch_powers_limbs(ctx, T->tw_inv.as<FrLimbs>(), half, omega_inv);
     if (!rc) rc = launch_powers(ctx, T->g_lo.as<Fr>(), nlo, g, Fr::one());
     if (!rc) rc = launch_powers(ctx, T->g_hi.as<Fr>(), nhi, g.pow_u64(nlo), Fr::one());
     if (!rc) rc = launch_powers(ctx, T->g_hi_minv.as<Fr>(), nhi, g.pow_u64(nlo), T->minv_host);
@@ -160,7 +184,7 @@ struct PassFuse {
 };
 
 template <bool DIT>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, const Fr* __restrict__ tw, int log_m, int s_lo,
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
                                                   int k, int j, int contiguous, PassFuse fz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem);   // 9 limbs per element
@@ -219,16 +243,11 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
             size_t e0 = gidx(i0);
             size_t texp = (e0 & (((size_t)1 << s) - 1)) << (log_m - 1 - s);
             FrD u = lds_get(i0), v = lds_get(i1);
-            const FrD w = FrD::load_canon(&tw[texp]);
-            if (DIT) {
-                FrD t = v * w;                       // < 1.2 p whatever v's bound (<= 18 p)
-                lds_put(i0, u + t);                  // bounds grow by at most 2 p per stage: <= 2.01 + 2k
-                lds_put(i1, FrD::sub<2>(u, t));
-            } else {
-                FrD sm = u + v;                      // <= 4.02 (after a reducing stage) or 8.04
-                lds_put(i1, FrD::sub<5>(u, v) * w);  // v <= 4.02
-                lds_put(i0, red ? sm.reduce() : sm);
-            }
+            const FrD w = load_limbs(&tw[texp]);
+            if (DIT) ntt_dit2(u, v, w);          // bounds grow by at most 2 p per stage: <= 2.01 + 2k
+            else ntt_dif2(u, v, w, red);         // v <= 4.02 p on entry
+            lds_put(i0, u);
+            lds_put(i1, v);
         }
         __syncthreads();
         it = 1;
@@ -251,31 +270,13 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
             const size_t t2 = lowbits << (log_m - 2 - s);          // high stage, butterfly (00, 10)
             const size_t t3 = t2 + ((size_t)1 << (log_m - 2));     // high stage, butterfly (01, 11)
             FrD x0 = lds_get(i00), x1 = lds_get(i01), x2 = lds_get(i10), x3 = lds_get(i11);
-            if (DIT) {
-                const FrD w1 = FrD::load_canon(&tw[t1]);
-                FrD ta = x1 * w1, tb = x3 * w1;
-                FrD a0 = x0 + ta, a1 = FrD::sub<2>(x0, ta), a2 = x2 + tb, a3 = FrD::sub<2>(x2, tb);
-                FrD tc = a2 * FrD::load_canon(&tw[t2]), td = a3 * FrD::load_canon(&tw[t3]);
-                lds_put(i00, a0 + tc);
-                lds_put(i10, FrD::sub<2>(a0, tc));
-                lds_put(i01, a1 + td);
-                lds_put(i11, FrD::sub<2>(a1, td));
-            } else {
-                const bool red_hi = reduces(it), red_lo = reduces(it + 1);
-                FrD b0 = x0 + x2, b1 = x1 + x3;
-                FrD b2 = FrD::sub<5>(x0, x2) * FrD::load_canon(&tw[t2]);
-                FrD b3 = FrD::sub<5>(x1, x3) * FrD::load_canon(&tw[t3]);
-                if (red_hi) {
-                    b0 = b0.reduce();
-                    b1 = b1.reduce();
-                }
-                const FrD w1 = FrD::load_canon(&tw[t1]);
-                FrD y00 = b0 + b1, y10 = b2 + b3;
-                lds_put(i01, FrD::sub<5>(b0, b1) * w1);
-                lds_put(i11, FrD::sub<5>(b2, b3) * w1);
-                lds_put(i00, red_lo ? y00.reduce() : y00);
-                lds_put(i10, red_lo ? y10.reduce() : y10);
-            }
+            const FrD w1 = load_limbs(&tw[t1]), w2 = load_limbs(&tw[t2]), w3 = load_limbs(&tw[t3]);
+            if (DIT) ntt_dit4(x0, x1, x2, x3, w1, w2, w3);
+            else ntt_dif4(x0, x1, x2, x3, w1, w2, w3, reduces(it), reduces(it + 1));
+            lds_put(i00, x0);
+            lds_put(i01, x1);
+            lds_put(i10, x2);
+            lds_put(i11, x3);
         }
         __syncthreads();
     }
@@ -349,7 +350,7 @@ static PassFuse no_fuse() {
 // natural out (stages low -> high).  `first` / `last` carry the element-wise work fused into the first pass's
 // loads / the last pass's stores.
 template <bool DIT>
-static int run_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m, const PassFuse& first, const PassFuse& last) {
+static int run_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, const PassFuse& first, const PassFuse& last) {
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
         ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -407,7 +408,7 @@ static int run_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m, const PassF
 }
 
 // natural order in -> bit-reversed order out
-static int dif_passes(Ctx* ctx, Fr* d, const Fr* tw, uint32_t log_m) {
+static int dif_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m) {
     return run_passes<false>(ctx, d, tw, log_m, no_fuse(), no_fuse());
 }
 
@@ -420,7 +421,7 @@ static int ntt_core(Ctx* ctx, NttTables* T, Fr* d, bool inverse, bool coset) {
                            T->lo_bits);
     }
     if (log_m > 0) {
-        ZG_TRY(dif_passes(ctx, d, inverse ? T->tw_inv.as<Fr>() : T->tw_fwd.as<Fr>(), log_m));
+        ZG_TRY(dif_passes(ctx, d, inverse ? T->tw_inv.as<FrLimbs>() : T->tw_fwd.as<FrLimbs>(), log_m));
         hipLaunchKernelGGL(k_bitrev, dim3(blocks_for(m)), dim3(256), 0, st, d, (int)log_m);
     }
     if (inverse) {
@@ -497,8 +498,8 @@ int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out)
     PassFuse pre_g = no_fuse();   // coefficients * g^i * (1/m): the 1/m of the preceding inverse transform rides along
     pre_g.pre = 1; pre_g.hi = T->g_hi_minv.as<Fr>(); pre_g.lo = T->g_lo.as<Fr>(); pre_g.lo_bits = T->lo_bits;
     for (int k = 0; k < 3; k++) {
-        ZG_TRY(run_passes<true>(ctx, v[k], T->tw_inv.as<Fr>(), log_m, no_fuse(), no_fuse()));
-        ZG_TRY(run_passes<false>(ctx, v[k], T->tw_fwd.as<Fr>(), log_m, pre_g, no_fuse()));
+        ZG_TRY(run_passes<true>(ctx, v[k], T->tw_inv.as<FrLimbs>(), log_m, no_fuse(), no_fuse()));
+        ZG_TRY(run_passes<false>(ctx, v[k], T->tw_fwd.as<FrLimbs>(), log_m, pre_g, no_fuse()));
     }
     PassFuse pre_m = no_fuse();
     pre_m.pre = 2; pre_m.b = d_b; pre_m.c = d_c; pre_m.s = T->zinv;
@@ -506,7 +507,7 @@ int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out)
     post.post = 3; post.phi = T->gi_hi_canon.as<Fr>(); post.plo = T->gi_lo.as<Fr>(); post.lo_bits = T->lo_bits;
     post.out = d_h_out;
     if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
-    ZG_TRY(run_passes<true>(ctx, d_a, T->tw_inv.as<Fr>(), log_m, pre_m, post));
+    ZG_TRY(run_passes<true>(ctx, d_a, T->tw_inv.as<FrLimbs>(), log_m, pre_m, post));
     return ZG_OK;
 }
 

@@ -258,6 +258,8 @@ extern "C" void zg_free(zg_ctx* ctx) {
         if (p.e1) (void)hipEventDestroy(p.e1);
     }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    for (auto& e : ctx->tm_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->gate_w) (void)hipEventDestroy(ctx->gate_w);
     if (ctx->gate_h) (void)hipEventDestroy(ctx->gate_h);
     delete ctx->prove_ws;
@@ -1033,11 +1035,13 @@ static int check_query_sizes(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) 
 static int gate_events(zg_ctx* ctx) {
     if (!ctx->gate_w) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_w, hipEventDisableTiming));
     if (!ctx->gate_h) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_h, hipEventDisableTiming));
+    for (auto& e : ctx->tm_ev)
+        if (!e) ZG_HIP(ctx, hipEventCreate(&e));
     return ZG_OK;
 }
 
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
-static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) {
+static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr) {
     const size_t m = (size_t)1 << r->log_m;
     ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
@@ -1046,6 +1050,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
         abc[k] = ws.abc[k].as<Fr>();
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
+    if (ev_eval_done) ZG_HIP(ctx, hipEventRecord(ev_eval_done, ctx->stream));
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
@@ -1350,7 +1355,9 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     // on its completion, and let the job scheduler overlap everything.
     ZG_TRY(gate_events(ctx));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
-    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p));
+    ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1]));
+    ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
     ctx->ev_witness = ctx->gate_w;
     ctx->ev_h = ctx->gate_h;
@@ -1359,7 +1366,13 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ctx->ev_witness = ctx->ev_h = nullptr;
     ctx->witness_gate_armed = false;
     ZG_TRY(rc_p);
-    ctx->timings[1] = ctx->timings[2] = 0;   // overlapped with the MSMs: see zg_profile_* for kernel times
+    {   // stream time of the R1CS evaluation and of the H pipeline (7 NTTs), which share the GPU with the witness MSMs
+        float ms_eval = 0, ms_h = 0;
+        (void)hipEventElapsedTime(&ms_eval, ctx->tm_ev[0], ctx->tm_ev[1]);
+        (void)hipEventElapsedTime(&ms_h, ctx->tm_ev[1], ctx->tm_ev[2]);
+        ctx->timings[1] = ms_eval;
+        ctx->timings[2] = ms_h;
+    }
     ZG_TRY(zg_prove_combine(ctx, p, partials, 1, r_le, s_le, proof_out));
     ctx->timings[5] = now_ms() - t0;
     return ZG_OK;
@@ -1408,6 +1421,18 @@ extern "C" int zg_prove_random(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     return zg_prove(ctx, p, r, witness32, rs[0], rs[1], proof_out);
 } catch (...) {
     return zg::on_exception(ctx);
+}
+
+// sum of `count` Jacobian points (the 96-byte G1 form zg_msm_* return): the "reduce" of a sharded standalone multiexp
+// after the ranks' partial sums have been gathered (RCCL has no point-add reduction)
+extern "C" int zg_g1_sum(const uint8_t* jac96, size_t count, uint8_t out_jac[96]) try {
+    if (!out_jac || (count && !jac96)) return ZG_E_INVALID_ARG;
+    G1XYZZ acc = G1XYZZ::inf();
+    for (size_t k = 0; k < count; k++) acc = acc.add(jac_from_bytes<Fq>(jac96 + 96 * k));
+    jac_bytes(out_jac, acc);
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 
 extern "C" int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, char* out,

@@ -31,8 +31,10 @@ def _merge_partials(h_part, w_part):
     return out
 
 
-def sharded_prove(engine, r, s, group=None):
+def sharded_prove(engine, r, s, group=None, timings=None):
     """Collective: every rank calls it; rank 0 returns the 256-byte proof, the others None.
+    timings (optional dict) receives this rank's host wall times in ms: witness_msm, h_wait (rank 0: what is left
+    of R1CS evaluation + 7 NTTs after the witness MSMs returned), scatter, h_msm, gather, combine.
 
     engine.h_chunk_entries          number of H scalars per rank (ceil(n_h / world))
     engine.start_h()                rank 0: queue R1CS evaluation + the 7 NTTs, do not wait
@@ -43,20 +45,28 @@ def sharded_prove(engine, r, s, group=None):
     The witness MSMs (l, a, b_g1, b_g2) need no H, so every rank runs its shards of them while rank 0's NTT
     pipeline is in flight; only the h MSM waits for the scatter.
     """
+    import time
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nbytes = engine.h_chunk_entries * 32
+    tm = {}
+    t0 = time.perf_counter()
     if rank == 0:
         engine.start_h()
     w_part = engine.partials(None, WITNESS_MASK)
+    t1 = time.perf_counter()
+    tm["witness_msm"] = 1e3 * (t1 - t0)
     mine = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
     if rank == 0:
         h_all = engine.finish_h()
+        tm["h_wait"] = 1e3 * (time.perf_counter() - t1)
+        tm["h_total"] = 1e3 * (time.perf_counter() - t0)
         assert h_all.numel() == world * nbytes
         scatter_list = list(h_all.view(world, nbytes).unbind(0))
     else:
         scatter_list = None
     # gloo (CPU tests, or a debugging run of several ranks on one GPU) moves bytes through host memory
     staged = world > 1 and dist.get_backend(group) == "gloo" and mine.is_cuda
+    t2 = time.perf_counter()
     if world > 1:
         if staged:
             host = torch.empty(nbytes, dtype=torch.uint8)
@@ -69,7 +79,11 @@ def sharded_prove(engine, r, s, group=None):
             torch.cuda.current_stream(mine.device).synchronize()
     else:
         mine = scatter_list[0]
+    t3 = time.perf_counter()
+    tm["scatter"] = 1e3 * (t3 - t2)
     part = _merge_partials(engine.partials(mine, H_MASK), w_part)
+    t4 = time.perf_counter()
+    tm["h_msm"] = 1e3 * (t4 - t3)
     if world > 1:
         if staged:
             part = part.cpu()
@@ -77,10 +91,17 @@ def sharded_prove(engine, r, s, group=None):
         dist.all_gather(gathered, part, group=group)
     else:
         gathered = [part]
+    t5 = time.perf_counter()
+    tm["gather"] = 1e3 * (t5 - t4)
+    if timings is not None:
+        timings.update(tm)
     if rank != 0:
         return None
     allp = torch.cat(gathered).cpu().numpy()
-    return engine.combine(allp, world, r, s)
+    proof = engine.combine(allp, world, r, s)
+    if timings is not None:
+        timings["combine"] = 1e3 * (time.perf_counter() - t5)
+    return proof
 
 
 class GpuEngine:
