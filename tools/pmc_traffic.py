@@ -1,9 +1,11 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
-per-launch HBM traffic of the dominant kernel, with the gfx950 correction of
-/opt/skills/guides/MI355X_MICROARCH.md section HBM: counters are in KiB; FETCH_SIZE under-reports wide
-(16 B/lane) coalesced reads by exactly 2x -- k_accumulate reads its bases with dwordx4 loads, so the
-fetch side is doubled; WRITE_SIZE is uncalibrated and taken as is.
-usage: pmc_traffic.py <fetch counter csv> <write counter csv> <out json>"""
+per-launch HBM traffic of the dominant kernel.  Counters are in KiB.  /opt/skills/guides/MI355X_MICROARCH.md (HBM
+section): FETCH_SIZE reports exactly half the bytes of a wide COALESCED streaming read and is uncalibrated for other
+patterns.  k_accumulate's traffic is one 64-byte random gather per lane, so the factor was calibrated on exactly that
+pattern with a known byte count (tools/ubench_gather.hip, profiles/r02_pmc_calibration.json): FETCH_SIZE * 1024 =
+1.02 x the gathered bytes (factor 1, not 2; the streaming kernel of the same run confirms the guide's 2.0), and
+WRITE_SIZE * 1024 = the written bytes exactly.
+usage: pmc_traffic.py <fetch counter csv> <write counter csv> <out json> [fetch factor, default 1.0]"""
 import csv
 import json
 import sys
@@ -24,19 +26,21 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "bytes per launch; FETCH_SIZE*1024*2 (gfx950 wide-read correction) + WRITE_SIZE*1024",
-           "kernels": {}}
+    ff = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+    out = {"note": "bytes per launch; FETCH_SIZE*1024*%.2f (factor calibrated on 64-byte random gathers, see "
+                   "r02_pmc_calibration.json) + WRITE_SIZE*1024" % ff,
+           "fetch_factor": ff, "kernels": {}}
     for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         f, nf = fetch[k]
         w, nw = write.get(k, [0.0, 1])
-        out["kernels"][k[:90]] = {"launches": nf, "fetch_bytes_per_launch": 2 * 1024 * f / nf,
+        out["kernels"][k[:90]] = {"launches": nf, "fetch_bytes_per_launch": ff * 1024 * f / nf,
                                   "write_bytes_per_launch": 1024 * w / max(nw, 1)}
     acc = [k for k in fetch if "k_accumulate" in k and "FqParams" in k]
     if acc:
         k = acc[0]
         f, nf = fetch[k]
         w, nw = write.get(k, [0.0, 1])
-        out["msm_accumulate_g1_bytes_per_launch"] = 2 * 1024 * f / nf + 1024 * w / max(nw, 1)
+        out["msm_accumulate_g1_bytes_per_launch"] = ff * 1024 * f / nf + 1024 * w / max(nw, 1)
         out["msm_accumulate_g1_launches"] = nf
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
