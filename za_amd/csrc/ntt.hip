@@ -19,9 +19,10 @@
 namespace zg {
 
 static constexpr int NTT_KMAX = 8;        // butterfly stages fused per pass
-static constexpr int NTT_THREADS = 512;   // two 72 KB tiles per CU: 512 threads give 4 waves per SIMD to hide the twiddle loads
-                                          // (256: +0.4 ms per 2^22 proof, 1024: +0.8 ms)
-static constexpr int NTT_LOG_TILE = 11;   // 2^11 elements * 32 B = 64 KiB of LDS per workgroup
+static constexpr int NTT_THREADS = 256;   // one butterfly quad per thread and round; four 36 KB tiles per CU (4 waves per SIMD)
+static constexpr int NTT_LOG_TILE = 10;   // 2^10 elements * 36 B = 36 KiB of LDS per workgroup: four workgroups per CU in different phases
+                                          // (load / butterflies / store) overlap where two 72 KB tiles of 512 threads did not:
+                                          // 2^22 H pipeline alone 4.79 -> 4.44 ms (2^9 tiles / 128 threads: 4.72)
 static constexpr int GEOM_LO = 10;        // low-table bits for the g^i two-level power tables
 
 struct NttTables {
@@ -215,9 +216,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
         for (int q = 0; q < 9; q++) lds[9 * li + q] = v.l[q];
     };
     const size_t lomask = ((size_t)1 << fz.lo_bits) - 1;
-    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
-        const size_t g = gidx(li);
-        FrD x = FrD::load_red(&data[g]);
+    auto ingest = [&](uint32_t li, size_t g, const Fr& raw) {
+        FrD x = FrD::load_red(&raw);
         if (fz.pre == 1) {
             x = x * (FrD::load_canon(&fz.hi[g >> fz.lo_bits]) * FrD::load_canon(&fz.lo[g & lomask]));
         } else if (fz.pre == 2) {
@@ -225,6 +225,24 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
             x = FrD::sub<3>(ab, FrD::load_red(&fz.c[g])) * FrD::load_canon(&fz.s);
         }
         lds_put(li, x);
+    };
+    if (tile_elems == 4u * NTT_THREADS) {
+        // the usual case: four elements per thread.  All four 32-byte loads are issued before the first is used, so the
+        // tile's load phase costs one HBM latency instead of four.
+        Fr raw[4];
+        size_t g4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            g4[q] = gidx(threadIdx.x + q * NTT_THREADS);
+            raw[q] = data[g4[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) ingest(threadIdx.x + q * NTT_THREADS, g4[q], raw[q]);
+    } else {
+        for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+            const size_t g = gidx(li);
+            ingest(li, g, data[g]);
+        }
     }
     __syncthreads();
     const int sh = contiguous ? 0 : j;  // position of the butterfly bits inside the local index
@@ -497,6 +515,7 @@ int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out)
     Fr* v[3] = {d_a, d_b, d_c};
     PassFuse pre_g = no_fuse();   // coefficients * g^i * (1/m): the 1/m of the preceding inverse transform rides along
     pre_g.pre = 1; pre_g.hi = T->g_hi_minv.as<Fr>(); pre_g.lo = T->g_lo.as<Fr>(); pre_g.lo_bits = T->lo_bits;
+    // (one launch per pass for all of a, b, c was measured: no gain, 4.46 -> 4.57 ms for the pipeline alone)
     for (int k = 0; k < 3; k++) {
         ZG_TRY(run_passes<true>(ctx, v[k], T->tw_inv.as<FrLimbs>(), log_m, no_fuse(), no_fuse()));
         ZG_TRY(run_passes<false>(ctx, v[k], T->tw_fwd.as<FrLimbs>(), log_m, pre_g, no_fuse()));
