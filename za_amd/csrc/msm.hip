@@ -761,6 +761,7 @@ struct MsmJob : MsmJobBase {
     XYZZ<F>* out;
     bool dense = false;   // plan from n directly, no k_classify round trip
     const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
+    uint32_t quad_base = 0;   // entry (relative to quad_table) of group 0's sums; 0 = n (the job covers the whole query)
     const Affine<F>* fbw_table = nullptr;   // fixed-base window table: [fbw_nwin][fbw_stride] affine points
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
@@ -856,7 +857,7 @@ struct MsmJob : MsmJobBase {
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
-        const uint32_t quad_n = quad_table && !fbw_table && !dense ? (uint32_t)n : 0u;
+        const uint32_t quad_n = quad_table && !fbw_table && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
         const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin);
@@ -1165,17 +1166,39 @@ int msm_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const u
 // (l, a, b_g1, b_g2) are gated on `ev_witness`, the h MSM on `ev_h` (both recorded by the caller on
 // ctx->stream; NULL = whatever is already queued there).  The witness jobs run at high stream
 // priority: their big-register G2 / tree kernels would otherwise starve behind the h accumulation.
+// sub-range [lo, hi) of a query as a job of its own (lo a multiple of 4 when the query has a subset-sum table)
+template <class F>
+static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDesc& d, size_t lo, size_t hi, XYZZ<F>* out) {
+    const uint32_t* sc = d.scalars ? (d.index ? d.scalars : d.scalars + 8 * lo) : nullptr;
+    const uint32_t* ix = d.index ? d.index + lo : nullptr;
+    std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
+                                               hi - lo, out));
+    j->dense = d.dense;
+    if (d.quad_table) {
+        j->quad_table = (const Affine<F>*)d.quad_table + lo;
+        j->quad_base = (uint32_t)(d.n - lo + 15 * (lo / 4));   // the sums start at entry n of the table, 15 per group of 4
+    }
+    if (d.fbw_table) {
+        j->fbw_table = (const Affine<F>*)d.fbw_table + lo;   // row w of the range starts at w * stride + lo
+        j->fbw_c = d.fbw_c;
+        j->fbw_nwin = d.fbw_nwin;
+        j->fbw_stride = d.fbw_stride;
+    }
+    return j;
+}
+
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
-               hipEvent_t ev_h) {
-    constexpr int NS = Ctx::MSM_SLOTS;
+               hipEvent_t ev_h, hipEvent_t ev_early) {
+    constexpr int NS = Ctx::MSM_SLOTS, HP = Ctx::H_PARTS_MAX;
+    // slots: 0 h part 0 | 1-3 l, a, b_g1 | 4 b_g2 | 5-7 further h parts | 8-10 early parts of l, a, b_g1 | 11 early part of b_g2
+    auto is_h_slot = [](int k) { return k == 0 || (k >= 5 && k <= 7); };
     if (!ctx->side_ready) {
         int lo_prio = 0, hi_prio = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
         for (int k = 0; k < NS; k++)
-            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking,
-                                                    k == 0 || k >= 5 ? lo_prio : hi_prio));
+            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? lo_prio : hi_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
-        for (int k = 0; k < 2 * (NS - 4); k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
+        for (int k = 0; k < 2 * HP; k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
         ctx->side_ready = true;
     }
     // The h job is split into parts over consecutive base ranges (see MsmJobBase::dep): part 0 on side[0], the
@@ -1187,38 +1210,43 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     if (g1[0].parts > 0) parts = g1[0].parts;
     if (const char* e = getenv("ZA_AMD_H_PARTS")) parts = atoi(e);
     if (parts < 1) parts = 1;
-    if (parts > NS - 4) parts = NS - 4;
+    if (parts > HP) parts = HP;
     if (g1[0].n < (size_t)parts * 4096) parts = 1;
     ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
     for (int k = 0; k < NS; k++) {
-        if (k >= 5 && k - 4 >= parts) continue;
-        hipEvent_t ev = (k == 0 || k >= 5) ? ev_h : ev_witness;
+        if (k >= 5 && k <= 7 && k - 4 >= parts) continue;
+        hipEvent_t ev = is_h_slot(k) ? ev_h : (k >= 8 && ev_early ? ev_early : ev_witness);
         ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
     }
-    MsmJob<Fq2> j2(ctx, scratch_slot(ctx, 4), ctx->side[4], (const G2Affine*)g2.bases, g2.scalars, g2.index, g2.n, out2);
-    MsmJob<Fq> j1(ctx, scratch_slot(ctx, 1), ctx->side[1], (const G1Affine*)g1[1].bases, g1[1].scalars, g1[1].index, g1[1].n, &out1[1]);
-    MsmJob<Fq> j3(ctx, scratch_slot(ctx, 2), ctx->side[2], (const G1Affine*)g1[2].bases, g1[2].scalars, g1[2].index, g1[2].n, &out1[2]);
-    MsmJob<Fq> j4(ctx, scratch_slot(ctx, 3), ctx->side[3], (const G1Affine*)g1[3].bases, g1[3].scalars, g1[3].index, g1[3].n, &out1[3]);
+    // witness queries: whole, or an early part (scalars complete at ev_early) + the rest
+    const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
+    static const int late_slot[4] = {1, 2, 3, 4}, early_slot[4] = {8, 9, 10, 11};
+    std::unique_ptr<MsmJob<Fq>> wj1[3][2];
+    std::unique_ptr<MsmJob<Fq2>> wj2[2];
+    G1XYZZ w1out[3][2];
+    G2XYZZ w2out[2];
+    bool split[4];
+    for (int q = 0; q < 4; q++) {
+        const MsmDesc& d = *wq[q];
+        split[q] = ev_early && d.early_n >= 4096 && d.early_n + 4096 <= d.n && (d.early_n & 3) == 0;
+        const size_t e = split[q] ? d.early_n : 0;
+        if (q < 3) {
+            if (split[q]) wj1[q][0] = make_range_job<Fq>(ctx, early_slot[q], d, 0, e, &w1out[q][0]);
+            wj1[q][1] = make_range_job<Fq>(ctx, late_slot[q], d, e, d.n, &w1out[q][1]);
+        } else {
+            if (split[q]) wj2[0] = make_range_job<Fq2>(ctx, early_slot[q], d, 0, e, &w2out[0]);
+            wj2[1] = make_range_job<Fq2>(ctx, late_slot[q], d, e, d.n, &w2out[1]);
+        }
+    }
     // h parts
-    G1XYZZ hout[NS - 4];
-    std::unique_ptr<MsmJob<Fq>> hp[NS - 4];
+    G1XYZZ hout[HP];
+    std::unique_ptr<MsmJob<Fq>> hp[HP];
     {
         const size_t n = g1[0].n, chunk = (n + parts - 1) / parts;
         for (int k = 0; k < parts; k++) {
             const size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
             const int slot = k == 0 ? 0 : 4 + k;
-            const uint32_t* sc = g1[0].scalars ? g1[0].scalars + 8 * lo : nullptr;
-            const uint32_t* ix = g1[0].index ? g1[0].index + lo : nullptr;
-            if (ix) sc = g1[0].scalars;   // scalars are addressed through the index
-            hp[k].reset(new MsmJob<Fq>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const G1Affine*)g1[0].bases + lo, sc, ix,
-                                       hi - lo, &hout[k]));
-            hp[k]->dense = g1[0].dense;
-            if (g1[0].fbw_table) {
-                hp[k]->fbw_table = (const G1Affine*)g1[0].fbw_table + lo;   // row w of the part starts at w * stride + lo
-                hp[k]->fbw_c = g1[0].fbw_c;
-                hp[k]->fbw_nwin = g1[0].fbw_nwin;
-                hp[k]->fbw_stride = g1[0].fbw_stride;
-            }
+            hp[k] = make_range_job<Fq>(ctx, slot, g1[0], lo, hi, &hout[k]);
             if (g1[0].part_gate && g1[0].part_gate[k]) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[slot], g1[0].part_gate[k], 0));
             if (parts > 1) {
                 hp[k]->ev_sorted = ctx->part_ev[2 * k];
@@ -1227,37 +1255,23 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
             }
         }
     }
-    {
-        MsmJob<Fq>* gj[3] = {&j1, &j3, &j4};
-        for (int k = 0; k < 3; k++) gj[k]->quad_table = (const G1Affine*)g1[k + 1].quad_table;
-        j2.quad_table = (const G2Affine*)g2.quad_table;
-        for (int k = 0; k < 3; k++)
-            if (g1[k + 1].fbw_table) {
-                gj[k]->fbw_table = (const G1Affine*)g1[k + 1].fbw_table;
-                gj[k]->fbw_c = g1[k + 1].fbw_c;
-                gj[k]->fbw_nwin = g1[k + 1].fbw_nwin;
-                gj[k]->fbw_stride = g1[k + 1].fbw_stride;
-            }
-        if (g2.fbw_table) {
-            j2.fbw_table = (const G2Affine*)g2.fbw_table;
-            j2.fbw_c = g2.fbw_c;
-            j2.fbw_nwin = g2.fbw_nwin;
-            j2.fbw_stride = g2.fbw_stride;
-        }
-    }
     // Priority order for the host's polling loop: the h parts (on the critical path once the NTT pipeline is done; a
-    // small proof otherwise waits ~1 ms for the host to finish queueing the witness jobs' phases), then the G2 job
-    // (the longest chain), then the G1 witness jobs.
-    MsmJobBase* jobs[4 + NS - 4];
-    for (int k = 0; k < parts; k++) jobs[k] = hp[k].get();
-    jobs[parts] = &j2;
-    jobs[parts + 1] = &j1;
-    jobs[parts + 2] = &j3;
-    jobs[parts + 3] = &j4;
-    ZG_TRY(run_jobs(ctx, jobs, 4 + parts));
+    // small proof otherwise waits ~1 ms for the host to finish queueing the witness jobs' phases), then the early
+    // witness parts (their scalars arrive first), then the G2 job (the longest chain), then the G1 witness jobs.
+    MsmJobBase* jobs[16];
+    int nj = 0;
+    for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
+    if (wj2[0]) jobs[nj++] = wj2[0].get();
+    for (int q = 0; q < 3; q++)
+        if (wj1[q][0]) jobs[nj++] = wj1[q][0].get();
+    jobs[nj++] = wj2[1].get();
+    for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q][1].get();
+    ZG_TRY(run_jobs(ctx, jobs, nj));
     G1XYZZ h = hout[0];
     for (int k = 1; k < parts; k++) h = h.add(hout[k]);
     out1[0] = h;
+    for (int q = 0; q < 3; q++) out1[q + 1] = split[q] ? w1out[q][0].add(w1out[q][1]) : w1out[q][1];
+    *out2 = split[3] ? w2out[0].add(w2out[1]) : w2out[1];
     return ZG_OK;
 }
 
@@ -1355,7 +1369,7 @@ void msm_scratch_free(Ctx* ctx) {
     }
     if (ctx->side_ready) {
         for (int k = 0; k < Ctx::MSM_SLOTS; k++) (void)hipStreamDestroy(ctx->side[k]);
-        for (int k = 0; k < 2 * (Ctx::MSM_SLOTS - 4); k++) (void)hipEventDestroy(ctx->part_ev[k]);
+        for (int k = 0; k < 2 * Ctx::H_PARTS_MAX; k++) (void)hipEventDestroy(ctx->part_ev[k]);
         (void)hipEventDestroy(ctx->side_ev);
         ctx->side_ready = false;
     }
