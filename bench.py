@@ -29,7 +29,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_ISSUE_PEAK = 467.5e9 * 64   # lane v_mad_u64_u32 / s, tools/ubench_valu.hip on this chip
-MADS_PER_MIXED_ADD = 8 * 162 + 2 * 126
+MADS_PER_MIXED_ADD = 8 * 162 + 2 * 126 - 81   # y3's two products share one reduction (fd.h mac2)
 
 
 def parse():
