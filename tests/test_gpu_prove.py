@@ -650,35 +650,3 @@ def test_dense_h_job_with_zero_one_and_extreme_coefficients(ctx, monkeypatch, lg
     assert co.prove(download_params(ctx, P), csr, wb, 0x777, 0x999, threads=8) == got
     assert za_amd.verify(pbytes, got, []) is True
 
-
-def test_two_part_witness_upload_gives_the_same_proof():
-    """ZA_AMD_W_EARLY=1: zg_prove uploads the witness in two parts and runs the l / a / b multiexps over the positions
-    that only need the first part as jobs of their own (subset-sum tables addressed from an offset, window tables from
-    a row offset).  Read once per process, so this runs in a child: bit-heavy (subset-sum tables) and dense (window
-    tables) witnesses, proof bytes against the default single-upload path."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys
-sys.path.insert(0, os.getcwd())
-import za_amd
-from za_amd import synth
-ctx = za_amd.Context(0)
-for lg, bf in ((15, 0.97), (14, 0.0), (15, 0.5)):
-    sr = synth.SynthR1CS(lg, 3, bf, 99 + lg)
-    R = sr.load(ctx)
-    m = 1 << lg
-    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 5)
-    pin = ctx.host_alloc(len(sr.witness)); pin[:] = sr.witness
-    a = ctx.prove(P, R, pin, 17, 19)
-    d_w = ctx.upload(sr.witness)
-    b = ctx.prove_dev(P, R, d_w, 17, 19)
-    print("CASE", lg, bf, a.hex() == b.hex(), [P.table_info(k)[0] for k in range(5)])
-'''
-    env = dict(os.environ, ZA_AMD_W_EARLY="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    lines = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
-    assert len(lines) == 3 and all(" True " in l for l in lines), r.stdout

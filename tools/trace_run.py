@@ -1,0 +1,17 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import za_amd
+from za_amd import synth
+ctx = za_amd.Context(0)
+sr = synth.SynthR1CS(22, 2, 0.97, 0x5A)
+R = sr.load(ctx)
+P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+pin = ctx.host_alloc(len(sr.witness)); pin[:] = sr.witness
+for i in range(3):
+    ctx.prove(P, R, pin, 5, 7)
+sys.stderr.write("=== traced proof\n"); sys.stderr.flush()
+os.environ["ZA_AMD_TRACE_NOW"] = "1"
+t0 = time.perf_counter()
+ctx.prove(P, R, pin, 5, 7)
+sys.stderr.write("=== total %.3f ms\n" % (1e3 * (time.perf_counter() - t0)))

@@ -32,7 +32,8 @@ struct Ctx {
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
     struct ProveWs* prove_ws = nullptr;
     // reusable MSM scratch (one per concurrent job) and side streams, see msm.hip
-    static constexpr int MSM_SLOTS = 12;  // 5 queries + up to 3 extra parts of the h job + 4 "early" parts of the witness queries
+    static constexpr int MSM_SLOTS = 8;   // 5 queries + up to 3 extra parts of the h job (main stream + 8 side streams:
+                                          // more would share hardware queues)
     static constexpr int H_PARTS_MAX = 4;
     struct MsmScratch* msm_scratch[MSM_SLOTS] = {nullptr};
     hipStream_t side[MSM_SLOTS] = {nullptr};
@@ -40,8 +41,6 @@ struct Ctx {
     hipEvent_t part_ev[2 * H_PARTS_MAX] = {nullptr};   // (sorted, accumulated) per part of the h job
     hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip): borrowed pointers
     hipEvent_t gate_w = nullptr, gate_h = nullptr;     // the ctx's own gate events (created lazily, destroyed by zg_free)
-    hipEvent_t gate_e = nullptr;                       // "first part of the witness has arrived" (zg_prove's chunked upload)
-    bool early_armed = false;                          // gate_e was recorded for the proof being queued
     hipEvent_t tm_ev[3] = {nullptr, nullptr, nullptr};  // timing of the H pipeline inside zg_prove_dev: start, R1CS evaluation done, H done
     bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
@@ -150,10 +149,6 @@ struct MsmDesc {
     // optional, dense jobs run in parts: part k's stream waits for part_gate[k] (e.g. "scalar chunk k has arrived")
     const hipEvent_t* part_gate = nullptr;
     int parts = 0;   // 0 = the scheduler's choice
-    // witness queries: the scalars of the first early_n positions are complete when msm_batch5's ev_early fires (the
-    // rest when ev_witness does), so those positions run as a job of their own while the upload continues.
-    // A multiple of 4 (subset-sum groups); 0 = no split.
-    size_t early_n = 0;
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);
@@ -165,7 +160,7 @@ int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_i
                         uint64_t* ones);
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
-               hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr, hipEvent_t ev_early = nullptr);
+               hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr);
 void msm_scratch_free(Ctx* ctx);
 
 // ---- ntt.hip

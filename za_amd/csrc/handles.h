@@ -17,10 +17,6 @@ struct zg_r1cs {
     zg::DevBuf a_index, b_index;
     uint64_t n_a = 0, n_b = 0;
     uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
-    // Two-part witness upload (zg_prove): the variables below split_var form the first part; the l / a / b queries'
-    // positions below l_split / a_split / b_split (multiples of 4) only use those, so their multiexps over that range
-    // can start while the second part is still on the PCIe bus.
-    uint64_t split_var = 0, l_split = 0, a_split = 0, b_split = 0;
     std::vector<uint32_t> var_of_signal;   // only for circuits loaded from a za proving key
 };
 

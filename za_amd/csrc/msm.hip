@@ -23,6 +23,7 @@
 // Algorithmic HBM bytes: 64 B base + 32 B scalar per point (G1), 128 + 32 (G2).  The kernel is
 // integer-ALU bound (about 10 field multiplications per point per window), not HBM bound.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -728,6 +729,15 @@ __global__ void __launch_bounds__(256) k_rowsum(const XYZZ<F>* __restrict__ in, 
     if (threadIdx.x == 0) acc.store(&out[blockIdx.x]);
 }
 
+// ZA_AMD_TRACE=2: host time stamps inside a job's phase (finds the HIP call a phase blocks in)
+static void trace_point(const char* what) {
+    static const int lvl = getenv("ZA_AMD_TRACE") ? atoi(getenv("ZA_AMD_TRACE")) : 0;
+    if (lvl < 2) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[za_amd trace]     %-28s %.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
 // ------------------------------------------------------------------------------------------------ host driver
 // An MSM runs in three device phases separated by two tiny host read-backs (class counts, then
 // totals).  msm_batch() drives several jobs phase by phase, each on its own HIP stream, so the
@@ -912,8 +922,10 @@ struct MsmJob : MsmJobBase {
             done = true;
             return ZG_OK;
         }
+        trace_point("phase_c enter");
         ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
         ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
+        trace_point("phase_c reserved items");
         {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
@@ -946,6 +958,7 @@ struct MsmJob : MsmJobBase {
                                S.partial.as<XYZZ<F>>());
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
+        trace_point("phase_c accumulate queued");
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
         {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
@@ -994,6 +1007,7 @@ struct MsmJob : MsmJobBase {
                 cur = outS;
             }
         }
+        trace_point("phase_c levels queued");
         // cur[w] = S_w.  Row sums of the D planes: repeat until every row is a single entry.
         const XYZZ<F>* dcur = S.dbuf[0].template as<XYZZ<F>>();
         int dpp = 1;
@@ -1038,6 +1052,7 @@ struct MsmJob : MsmJobBase {
             }
             ones_ptr = in;
         }
+        trace_point("phase_c rowsums queued");
         // read-back layout: [kw] S, [kw * bits] T in (level, window, bit) order, [1] ones
         const size_t n_t = (size_t)P.kw * bits;
         if (((size_t)P.kw + n_t + 1) * sizeof(XYZZ<F>) + 64 > MsmScratch::HOST_BYTES)
@@ -1101,6 +1116,15 @@ struct MsmJob : MsmJobBase {
 static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
     int state[16] = {0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
     int remaining = njobs;
+    // ZA_AMD_TRACE=1: host timestamps (ms since entry) of every phase transition of every job, to stderr
+    static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto stamp = [&](int j, const char* what, double t_begin) {
+        if (!trace) return;
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+        fprintf(stderr, "[za_amd trace] job %d %-8s host %.3f -> %.3f ms\n", j, what, t_begin, now);
+    };
+    auto tnow = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
     while (remaining > 0) {
         bool progressed = false;
         // launches first: a job's host-side finish() (a few hundred point operations) must not delay another
@@ -1110,14 +1134,18 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
         for (int j = 0; j < njobs; j++) {
             if (state[j] == 4) continue;
             if (state[j] == 0) {
+                const double tb = tnow();
                 ZG_TRY(jobs[j]->phase_a());
+                stamp(j, "phase_a", tb);
                 state[j] = 1;
                 progressed = true;
                 // A dense job's whole chain is known on the host: queue it now, behind the stream's event gate, so the
                 // GPU starts it the moment the NTT pipeline is done -- not when the host gets round to it (a 2^14
                 // proof waited 0.9 ms here while the host was queueing the witness jobs' phases).
                 if (jobs[j]->eager && (!jobs[j]->dep || jobs[j]->dep->launched)) {
+                    const double tb2 = tnow();
                     ZG_TRY(jobs[j]->phase_b());
+                    stamp(j, "phase_b+c", tb2);
                     state[j] = jobs[j]->chained ? 3 : 2;
                 }
                 continue;
@@ -1127,12 +1155,17 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
             hipError_t q = hipStreamQuery(jobs[j]->st);
             if (q == hipErrorNotReady) continue;
             if (q != hipSuccess) return fail(ctx, ZG_E_HIP, "stream query failed: %s", hipGetErrorString(q));
+            const double tb = tnow();
             if (state[j] == 1) {
                 ZG_TRY(jobs[j]->phase_b());
+                stamp(j, "phase_b", tb);
                 if (jobs[j]->chained) state[j]++;   // nothing left to launch
-            } else if (state[j] == 2) ZG_TRY(jobs[j]->phase_c());
-            else {
+            } else if (state[j] == 2) {
+                ZG_TRY(jobs[j]->phase_c());
+                stamp(j, "phase_c", tb);
+            } else {
                 ZG_TRY(jobs[j]->finish());
+                stamp(j, "finish", tb);
                 remaining--;
             }
             state[j]++;
@@ -1188,9 +1221,9 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
 }
 
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
-               hipEvent_t ev_h, hipEvent_t ev_early) {
+               hipEvent_t ev_h) {
     constexpr int NS = Ctx::MSM_SLOTS, HP = Ctx::H_PARTS_MAX;
-    // slots: 0 h part 0 | 1-3 l, a, b_g1 | 4 b_g2 | 5-7 further h parts | 8-10 early parts of l, a, b_g1 | 11 early part of b_g2
+    // slots: 0 h part 0 | 1-3 l, a, b_g1 | 4 b_g2 | 5-7 further h parts
     auto is_h_slot = [](int k) { return k == 0 || (k >= 5 && k <= 7); };
     if (!ctx->side_ready) {
         int lo_prio = 0, hi_prio = 0;
@@ -1215,29 +1248,16 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
     for (int k = 0; k < NS; k++) {
         if (k >= 5 && k <= 7 && k - 4 >= parts) continue;
-        hipEvent_t ev = is_h_slot(k) ? ev_h : (k >= 8 && ev_early ? ev_early : ev_witness);
+        hipEvent_t ev = is_h_slot(k) ? ev_h : ev_witness;
         ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
     }
-    // witness queries: whole, or an early part (scalars complete at ev_early) + the rest
+    // witness queries
     const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
-    static const int late_slot[4] = {1, 2, 3, 4}, early_slot[4] = {8, 9, 10, 11};
-    std::unique_ptr<MsmJob<Fq>> wj1[3][2];
-    std::unique_ptr<MsmJob<Fq2>> wj2[2];
-    G1XYZZ w1out[3][2];
-    G2XYZZ w2out[2];
-    bool split[4];
-    for (int q = 0; q < 4; q++) {
-        const MsmDesc& d = *wq[q];
-        split[q] = ev_early && d.early_n >= 4096 && d.early_n + 4096 <= d.n && (d.early_n & 3) == 0;
-        const size_t e = split[q] ? d.early_n : 0;
-        if (q < 3) {
-            if (split[q]) wj1[q][0] = make_range_job<Fq>(ctx, early_slot[q], d, 0, e, &w1out[q][0]);
-            wj1[q][1] = make_range_job<Fq>(ctx, late_slot[q], d, e, d.n, &w1out[q][1]);
-        } else {
-            if (split[q]) wj2[0] = make_range_job<Fq2>(ctx, early_slot[q], d, 0, e, &w2out[0]);
-            wj2[1] = make_range_job<Fq2>(ctx, late_slot[q], d, e, d.n, &w2out[1]);
-        }
-    }
+    static const int w_slot[4] = {1, 2, 3, 4};
+    std::unique_ptr<MsmJob<Fq>> wj1[3];
+    std::unique_ptr<MsmJob<Fq2>> wj2;
+    for (int q = 0; q < 3; q++) wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);
+    wj2 = make_range_job<Fq2>(ctx, w_slot[3], *wq[3], 0, wq[3]->n, out2);
     // h parts
     G1XYZZ hout[HP];
     std::unique_ptr<MsmJob<Fq>> hp[HP];
@@ -1256,22 +1276,17 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         }
     }
     // Priority order for the host's polling loop: the h parts (on the critical path once the NTT pipeline is done; a
-    // small proof otherwise waits ~1 ms for the host to finish queueing the witness jobs' phases), then the early
-    // witness parts (their scalars arrive first), then the G2 job (the longest chain), then the G1 witness jobs.
+    // small proof otherwise waits ~1 ms for the host to finish queueing the witness jobs' phases), then the G2 job
+    // (the longest chain), then the G1 witness jobs.
     MsmJobBase* jobs[16];
     int nj = 0;
     for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
-    if (wj2[0]) jobs[nj++] = wj2[0].get();
-    for (int q = 0; q < 3; q++)
-        if (wj1[q][0]) jobs[nj++] = wj1[q][0].get();
-    jobs[nj++] = wj2[1].get();
-    for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q][1].get();
+    jobs[nj++] = wj2.get();
+    for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q].get();
     ZG_TRY(run_jobs(ctx, jobs, nj));
     G1XYZZ h = hout[0];
     for (int k = 1; k < parts; k++) h = h.add(hout[k]);
     out1[0] = h;
-    for (int q = 0; q < 3; q++) out1[q + 1] = split[q] ? w1out[q][0].add(w1out[q][1]) : w1out[q][1];
-    *out2 = split[3] ? w2out[0].add(w2out[1]) : w2out[1];
     return ZG_OK;
 }
 

@@ -262,7 +262,6 @@ extern "C" void zg_free(zg_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->gate_w) (void)hipEventDestroy(ctx->gate_w);
     if (ctx->gate_h) (void)hipEventDestroy(ctx->gate_h);
-    if (ctx->gate_e) (void)hipEventDestroy(ctx->gate_e);
     delete ctx->prove_ws;
     ctx->prove_ws = nullptr;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -743,15 +742,6 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
         if (b_aux[i]) { b_index.push_back(n_inputs + i); r->b_aux_total++; }
     r->n_a = a_index.size();
     r->n_b = b_index.size();
-    {   // split point of the two-part witness upload: half of the aux variables (a multiple of 4 positions of l)
-        r->l_split = ((uint64_t)n_aux / 2) & ~(uint64_t)3;
-        r->split_var = (uint64_t)n_inputs + r->l_split;
-        auto below = [&](const std::vector<uint32_t>& idx) {   // the index lists are increasing
-            return (uint64_t)(std::lower_bound(idx.begin(), idx.end(), (uint32_t)r->split_var) - idx.begin()) & ~(uint64_t)3;
-        };
-        r->a_split = below(a_index);
-        r->b_split = below(b_index);
-    }
     hipStream_t st = ctx->stream;
     ZG_HIP(ctx, r->a_index.alloc(a_index.size() * 4));
     ZG_HIP(ctx, r->b_index.alloc(b_index.size() * 4));
@@ -1045,7 +1035,6 @@ static int check_query_sizes(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r) 
 static int gate_events(zg_ctx* ctx) {
     if (!ctx->gate_w) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_w, hipEventDisableTiming));
     if (!ctx->gate_h) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_h, hipEventDisableTiming));
-    if (!ctx->gate_e) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_e, hipEventDisableTiming));
     for (auto& e : ctx->tm_ev)
         if (!e) ZG_HIP(ctx, hipEventCreate(&e));
     return ZG_OK;
@@ -1265,19 +1254,12 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
             d.fbw_nwin = t.nwin;
             d.fbw_stride = (size_t)use[k].n;
         }
-        // zg_prove's two-part upload: positions below the split only need the first part of the witness
-        if (ctx->early_armed && p->world == 1 && k >= 1 && use[k].n) {
-            const uint64_t e = k == 1 ? r->l_split : k == 2 ? r->a_split : r->b_split;
-            d.early_n = (size_t)std::min<uint64_t>(e, use[k].n);
-        }
         if (k < 4) d1[k] = d; else d2 = d;
     }
     hipEvent_t ev_wit = ctx->ev_witness;
     if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
     ctx->witness_gate_armed = false;
-    const hipEvent_t ev_early = ctx->early_armed ? ctx->gate_e : nullptr;
-    ctx->early_armed = false;
-    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h, ev_early));
+    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
@@ -1418,25 +1400,10 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     // pinned memory (zg_host_alloc) the copy runs at PCIe speed, 32 (l + v) bytes: 134 MB = 2.4 ms at 2^22.
     DevBuf& dw = prove_ws(ctx).w;
     ZG_HIP(ctx, dw.reserve(nv * 32));
-    // Optional (ZA_AMD_W_EARLY=1) two-part upload: once the first part (the variables below r->split_var) has arrived,
-    // the l / a / b multiexps over the positions that only use those variables start beside the second part's
-    // transfer, instead of the GPU idling for the whole upload.  Measured at 2^22 (bit-heavy witness): 16.0 vs 15.1 ms --
-    // the eight half-size witness jobs need twice the launches, and the one host thread that drives every job's phases
-    // (the HIP launch path serialises threads) then finishes them after the h multiexp.  Off by default until the
-    // witness jobs are chained on the device like the h job.
-    static const bool early_ok = getenv("ZA_AMD_W_EARLY") && atoi(getenv("ZA_AMD_W_EARLY")) != 0;
-    const size_t first = (size_t)r->split_var * 32;
-    if (early_ok && p->world == 1 && r->l_split >= 4096 && first < nv * 32) {
-        ZG_TRY(gate_events(ctx));
-        ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, first, hipMemcpyHostToDevice, ctx->stream));
-        ZG_HIP(ctx, hipEventRecord(ctx->gate_e, ctx->stream));
-        ZG_HIP(ctx, hipMemcpyAsync((uint8_t*)dw.p + first, witness32 + first, nv * 32 - first, hipMemcpyHostToDevice, ctx->stream));
-        ctx->early_armed = true;
-    } else {
-        ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
-    }
+    // (A two-part upload with the l / a / b multiexps over the first half's positions started early was built and
+    // measured in round 2: slower, and eleven streams on eight hardware queues can deadlock -- DESIGN.md section 4.2.)
+    ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
     int rc = zg_prove_dev(ctx, p, r, dw.p, r_le, s_le, proof_out);
-    ctx->early_armed = false;
     ctx->timings[0] = (double)(nv * 32);   // bytes uploaded (the copy is not timed separately: it is in [5])
     ctx->timings[5] = now_ms() - t0;
     return rc;
