@@ -1228,6 +1228,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     if (!ctx->side_ready) {
         int lo_prio = 0, hi_prio = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
+        // (high priority for the later h parts, so that their sort is not starved by the first part's accumulation:
+        // measured, no difference)
         for (int k = 0; k < NS; k++)
             ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? lo_prio : hi_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
