@@ -1,10 +1,13 @@
+"""One traced proof (ZA_AMD_TRACE=1 host stamps of the job scheduler): python tools/trace_run.py [log_m] [bit_fraction]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import za_amd
 from za_amd import synth
 ctx = za_amd.Context(0)
-sr = synth.SynthR1CS(22, 2, 0.97, 0x5A)
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+bf = float(sys.argv[2]) if len(sys.argv) > 2 else 0.97
+sr = synth.SynthR1CS(lg, 2, bf, 0x5A)
 R = sr.load(ctx)
 P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
 pin = ctx.host_alloc(len(sr.witness)); pin[:] = sr.witness

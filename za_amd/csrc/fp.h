@@ -128,6 +128,9 @@ struct alignas(16) Fp {
     // Montgomery product a*b*2^-256 mod p.  CIOS with the two carry chains merged: the top limb of
     // p is < 2^30, so the running 33-bit carries never overflow.
     friend ZG_HD Fp operator*(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        return mul_host64(a, b);
+#else
         uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -147,8 +150,68 @@ struct alignas(16) Fp {
             t[7] = (uint32_t)(A + C);
         }
         return reduce_once(t);
+#endif
     }
     ZG_HD Fp sqr() const { return *this * *this; }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Host code (proof combination, Horner passes of the multiexp jobs, pairing, set-up glue) multiplies with 4 x 64-bit
+    // limbs and 128-bit products: the same Montgomery residue, a third of the time of the 8 x 32 form above.
+    static constexpr uint64_t mod64(int i) { return (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32); }
+    static constexpr uint64_t ninv64() {
+        uint64_t inv = 1;   // Newton: p0 * inv == 1 (mod 2^64)
+        for (int i = 0; i < 6; i++) inv *= 2 - mod64(0) * inv;
+        return 0 - inv;
+    }
+    static inline Fp mul_host64(const Fp& a, const Fp& b) {
+        typedef unsigned __int128 u128;
+        constexpr uint64_t NI = ninv64();
+        constexpr uint64_t p0 = mod64(0), p1 = mod64(1), p2 = mod64(2), p3 = mod64(3);
+        uint64_t x[4], y[4];
+        for (int i = 0; i < 4; i++) {
+            x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+            y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        }
+        uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 c = (u128)x[0] * y[i] + t0;
+            const uint64_t u0 = (uint64_t)c;
+            c = (c >> 64) + (u128)x[1] * y[i] + t1;
+            const uint64_t u1 = (uint64_t)c;
+            c = (c >> 64) + (u128)x[2] * y[i] + t2;
+            const uint64_t u2 = (uint64_t)c;
+            c = (c >> 64) + (u128)x[3] * y[i] + t3;
+            const uint64_t u3 = (uint64_t)c;
+            const uint64_t u4 = (uint64_t)(c >> 64);
+            const uint64_t m = u0 * NI;
+            c = (u128)m * p0 + u0;
+            c = (c >> 64) + (u128)m * p1 + u1;
+            t0 = (uint64_t)c;
+            c = (c >> 64) + (u128)m * p2 + u2;
+            t1 = (uint64_t)c;
+            c = (c >> 64) + (u128)m * p3 + u3;
+            t2 = (uint64_t)c;
+            t3 = (uint64_t)(c >> 64) + u4;   // operands below p < 2^254: the running value stays below 2p
+        }
+        // t - p if t >= p
+        u128 d = (u128)t0 - p0;
+        const uint64_t s0 = (uint64_t)d;
+        d = (u128)t1 - p1 - (uint64_t)((d >> 64) & 1);
+        const uint64_t s1 = (uint64_t)d;
+        d = (u128)t2 - p2 - (uint64_t)((d >> 64) & 1);
+        const uint64_t s2 = (uint64_t)d;
+        d = (u128)t3 - p3 - (uint64_t)((d >> 64) & 1);
+        const uint64_t s3 = (uint64_t)d;
+        const bool below = (uint64_t)(d >> 64) & 1;
+        const uint64_t r0 = below ? t0 : s0, r1 = below ? t1 : s1, r2 = below ? t2 : s2, r3 = below ? t3 : s3;
+        Fp r;
+        r.l[0] = (uint32_t)r0; r.l[1] = (uint32_t)(r0 >> 32);
+        r.l[2] = (uint32_t)r1; r.l[3] = (uint32_t)(r1 >> 32);
+        r.l[4] = (uint32_t)r2; r.l[5] = (uint32_t)(r2 >> 32);
+        r.l[6] = (uint32_t)r3; r.l[7] = (uint32_t)(r3 >> 32);
+        return r;
+    }
+#endif
 
     ZG_HD Fp to_mont() const {
         Fp r2;

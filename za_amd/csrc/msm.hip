@@ -29,6 +29,7 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <future>
 
 #include "common.h"
 
@@ -1116,6 +1117,7 @@ struct MsmJob : MsmJobBase {
 static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
     int state[16] = {0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
     int remaining = njobs;
+    std::vector<std::future<int>> finishing;   // (a future of std::async joins in its destructor: early returns are safe)
     // ZA_AMD_TRACE=1: host timestamps (ms since entry) of every phase transition of every job, to stderr
     static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
     const auto t_entry = std::chrono::steady_clock::now();
@@ -1164,7 +1166,15 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
                 ZG_TRY(jobs[j]->phase_c());
                 stamp(j, "phase_c", tb);
             } else {
-                ZG_TRY(jobs[j]->finish());
+                // The host part of a job (its Horner pass: ~250 doublings and additions) runs beside the polling loop
+                // when other jobs are still in flight -- a small proof or a shard otherwise ends with the jobs'
+                // host passes one after the other (0.35 ms each at 2^14).
+                if (remaining > 1) {
+                    MsmJobBase* jb = jobs[j];
+                    finishing.push_back(std::async(std::launch::async, [jb] { return jb->finish(); }));
+                } else {
+                    ZG_TRY(jobs[j]->finish());
+                }
                 stamp(j, "finish", tb);
                 remaining--;
             }
@@ -1174,7 +1184,12 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
         }
         if (!progressed) std::this_thread::yield();
     }
-    return ZG_OK;
+    int rc = ZG_OK;
+    for (auto& f : finishing) {
+        const int r = f.get();
+        if (rc == ZG_OK) rc = r;
+    }
+    return rc;
 }
 
 static MsmScratch& scratch_slot(Ctx* ctx, int slot) {
