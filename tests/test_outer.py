@@ -217,3 +217,12 @@ def test_za_gpu_driver_verify_arm(lib_built, tmp_path):
     r = subprocess.run([zb.DRIVER, "verify", "--vk", "verifier.json", "--proof", "p2.json"], cwd=tmp_path,
                        capture_output=True, text=True)
     assert r.returncode == 1 and "NOT valid" in r.stdout
+
+
+def test_untrusted_input_fuzz_smoke(lib_built):
+    """A few seconds of tools/fuzz_host_parsers.py (mutated vk / proof JSON, verifying-key bytes, pk containers) against
+    the regular build: every call returns a code.  tools/asan_host.sh runs the same fuzzer on the ASan / UBSan build."""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_host_parsers.py"), "4", "7"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "no crash" in r.stdout

@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libza_amd.so")
+# ZA_AMD_LIB: another build of the same library (tools/asan_host.sh: host code under ASan / UBSan)
+LIB_PATH = os.environ.get("ZA_AMD_LIB") or os.path.join(_HERE, "libza_amd.so")
 
 ZG_OK = 0
 ZG_E_ASSIGNMENT_MISSING = 1
