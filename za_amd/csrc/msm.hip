@@ -16,7 +16,7 @@
 //   3. k_item_*     items ordered by length (counting sort, longest first): the 64 lanes of a wave run equal loops
 //   4. k_accumulate one thread per item: gather affine bases (dwordx4 loads), XYZZ mixed adds   [dominant]
 //   5. k_bits_level / k_rowsum   bucket reduction by bit planes: per window S = sum of buckets and
-//                   T_j = sum of the buckets with index bit j set; plain sums only, four adds per thread and level
+//                   T_j = sum of the buckets with index bit j set; plain sums only, two dependent adds per level
 //   6. k_rowsum     also sums the partial sums of the "ones" bucket
 //   7. host: one Horner pass over the 254 bit positions (window value = S + sum_j 2^j T_j) + the ones sum.
 // Bases live in HBM in the device field's M261 form (fd.h); field work uses the lazy 9x29-limb arithmetic.
@@ -658,41 +658,57 @@ __device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ parti
     return r;
 }
 
-// in == nullptr: leaf level, children are buckets.  n_out = number of groups over all windows; len = groups per window.
+// One level of the reduction.  `in` holds rows_in rows of (len_out << f) entries: the first kw rows are the windows'
+// running group sums ("S rows"; in == nullptr at the leaf level: the buckets themselves), the others the bit-plane rows
+// emitted by earlier levels, which only need summing.  Every row is folded 2^f : 1; an S row also emits f new rows
+// (entries with index bit b set), appended after the rows_in existing ones.  So all rows of a level have the same
+// length, shrink together, and after the last level `out` is [kw] S, [kw * bits] T in (level, window, bit) order --
+// no separate row-sum launches (they were 0.25 ms of the 0.87 ms tail of the h multiexp).
+// Two lanes per group, two children each: lane A adds c0 + c1 while lane B adds c2 + c3 (= bit 1); they swap c1 and
+// that sum through LDS, then A finishes the group sum while B adds c1 + c3 (= bit 0) -- two dependent additions per
+// level with every lane busy, where one thread per group ran four (and held four points: 311 registers for G1,
+// spills for G2).
+static constexpr uint32_t BITS_THREADS = 128;
 template <class F>
-__global__ void __launch_bounds__(128) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
-                                                    const uint32_t* __restrict__ item_off, uint32_t n_out, uint32_t len,
-                                                    int f, XYZZ<F>* __restrict__ outS, XYZZ<F>* __restrict__ outD) {
+__global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
+                                                             const uint32_t* __restrict__ item_off, uint32_t rows_in,
+                                                             uint32_t kw, uint32_t len_out, int f,
+                                                             XYZZ<F>* __restrict__ out) {
     using L = typename LazyOf<F>::L;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_out) return;
-    const uint32_t w = g / len, idx = g - w * len;
-    const uint32_t first = g << f;
-    XYZZd<L> c0, c1;
-    if (in) {
-        c0 = XYZZd<L>::load(&in[first]);
-        c1 = XYZZd<L>::load(&in[first + 1]);
-    } else {
-        c0 = bucket_sum<L, F>(partial, item_off, first);
-        c1 = bucket_sum<L, F>(partial, item_off, first + 1);
-    }
-    if (f == 1) {
-        c0.add(c1).store(&outS[g]);
-        c1.store(&outD[(size_t)w * len + idx]);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per thread
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = t >> 1, q = t & 1u;
+    const bool in_range = g < rows_in * len_out;
+    const uint32_t row = in_range ? g / len_out : 0u, idx = g - row * len_out;
+    const bool full = row < kw;   // an S row: emits bit-plane rows
+    XYZZ<F>* outS = out + (size_t)row * len_out + idx;
+    XYZZ<F>* outD = out + ((size_t)rows_in + (size_t)row * f) * len_out + idx;   // + b * len_out for bit b
+    const uint32_t child0 = (row * len_out + idx) << f;   // rows of len_out << f entries
+    if (f == 1) {   // uniform; the last level of an odd bit count: two children, lane A does it all
+        if (in_range && q == 0) {
+            XYZZd<L> c0 = in ? XYZZd<L>::load(&in[child0]) : bucket_sum<L, F>(partial, item_off, child0);
+            XYZZd<L> c1 = in ? XYZZd<L>::load(&in[child0 + 1]) : bucket_sum<L, F>(partial, item_off, child0 + 1);
+            if (full) c1.store(outD);
+            c0.add(c1).store(outS);
+        }
         return;
     }
-    XYZZd<L> c2, c3;
-    if (in) {
-        c2 = XYZZd<L>::load(&in[first + 2]);
-        c3 = XYZZd<L>::load(&in[first + 3]);
-    } else {
-        c2 = bucket_sum<L, F>(partial, item_off, first + 2);
-        c3 = bucket_sum<L, F>(partial, item_off, first + 3);
+    // lane A: children 0, 1; lane B: children 2, 3
+    XYZZd<L> lo = XYZZd<L>::inf(), hi = XYZZd<L>::inf();
+    if (in_range) {
+        const uint32_t ch = child0 + 2u * q;
+        lo = in ? XYZZd<L>::load(&in[ch]) : bucket_sum<L, F>(partial, item_off, ch);
+        hi = in ? XYZZd<L>::load(&in[ch + 1]) : bucket_sum<L, F>(partial, item_off, ch + 1);
     }
-    c1.add(c3).store(&outD[((size_t)w * 2) * len + idx]);        // bit 0
-    XYZZd<L> p1 = c2.add(c3);
-    p1.store(&outD[((size_t)w * 2 + 1) * len + idx]);             // bit 1
-    c0.add(c1).add(p1).store(&outS[g]);
+    XYZZd<L> r = lo.add(hi);                       // A: c0 + c1;  B: c2 + c3 (bit 1)
+    (q == 0 ? hi : r).store(&lds[threadIdx.x]);    // A publishes c1, B its sum
+    if (in_range && full && q == 1) r.store(outD + len_out);
+    __syncthreads();
+    if (in_range && (q == 0 || full)) {
+        const XYZZd<L> other = XYZZd<L>::load(&lds[threadIdx.x ^ 1u]);
+        (q == 0 ? r : hi).add(other).store(q == 0 ? outS : outD);   // A: group sum;  B: c3 + c1 (bit 0)
+    }
 }
 
 // One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
@@ -977,61 +993,31 @@ struct MsmJob : MsmJobBase {
             red_f[red_nlev] = left >= 2 ? 2 : 1;
             left -= red_f[red_nlev++];
         }
-        RowMeta M{};
-        M.nlev = red_nlev;
-        size_t d_total = 0, blocks = 0;
-        {
-            uint32_t len = P.B;   // entries per window entering the level
-            for (int l = 0; l < red_nlev; l++) {
-                len >>= red_f[l];
-                M.d_off[l] = (uint32_t)d_total;
-                M.len[l] = len;
-                M.rows[l] = (uint32_t)P.kw * red_f[l];
-                M.chunks[l] = (len + ROWSUM_CH - 1) / ROWSUM_CH;
-                M.block_base[l] = (uint32_t)blocks;
-                d_total += (size_t)M.rows[l] * len;
-                blocks += (size_t)M.rows[l] * M.chunks[l];
-            }
-        }
-        ZG_HIP(ctx, S.dbuf[0].reserve(d_total * sizeof(XYZZ<F>)));
-        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve((size_t)(P.nkeys >> red_f[0]) * sizeof(XYZZ<F>)));
+        // levels: every row is folded 2^f : 1, S rows append their bit-plane rows (see k_bits_level)
+        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve((size_t)P.nkeys * sizeof(XYZZ<F>)));
         const XYZZ<F>* cur = nullptr;
         {
-            uint32_t len = P.B;
+            uint32_t len = P.B, rows = (uint32_t)P.kw;
+            size_t rb = 0;
+            int bb = 0;
             for (int l = 0; l < red_nlev; l++) {
                 len >>= red_f[l];
-                const uint32_t n_out = (uint32_t)P.kw * len;
-                XYZZ<F>* outS = S.lvl[l & 1].template as<XYZZ<F>>();
-                hipLaunchKernelGGL((k_bits_level<F>), dim3((n_out + 127) / 128), dim3(128), 0, st, cur,
-                                   S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), n_out, len, red_f[l], outS,
-                                   S.dbuf[0].template as<XYZZ<F>>() + M.d_off[l]);
-                cur = outS;
+                const size_t groups = (size_t)rows * len;
+                XYZZ<F>* outp = S.lvl[l & 1].template as<XYZZ<F>>();
+                hipLaunchKernelGGL((k_bits_level<F>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
+                                   dim3(BITS_THREADS), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
+                                   S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
+                                   outp);
+                cur = outp;
+                red_rowbase[l] = (uint32_t)rb;   // finish(): rows of level l start here (after the kw S rows)
+                red_bitbase[l] = bb;
+                rb += (size_t)P.kw * red_f[l];
+                bb += red_f[l];
+                rows += (uint32_t)P.kw * red_f[l];
             }
         }
         trace_point("phase_c levels queued");
-        // cur[w] = S_w.  Row sums of the D planes: repeat until every row is a single entry.
-        const XYZZ<F>* dcur = S.dbuf[0].template as<XYZZ<F>>();
-        int dpp = 1;
-        for (;;) {
-            bool more = false;
-            for (int l = 0; l < red_nlev; l++) more |= M.len[l] > 1;
-            if (!more) break;
-            ZG_HIP(ctx, S.dbuf[dpp].reserve(blocks * sizeof(XYZZ<F>)));
-            XYZZ<F>* dout = S.dbuf[dpp].template as<XYZZ<F>>();
-            hipLaunchKernelGGL((k_rowsum<F>), dim3((unsigned)blocks), dim3(256), 256 * sizeof(XYZZ<F>), st, dcur, M, dout);
-            size_t nb = 0;
-            for (int l = 0; l < red_nlev; l++) {
-                M.d_off[l] = M.block_base[l];
-                M.len[l] = M.chunks[l];
-                M.chunks[l] = (M.len[l] + ROWSUM_CH - 1) / ROWSUM_CH;
-                M.block_base[l] = (uint32_t)nb;
-                nb += (size_t)M.rows[l] * M.chunks[l];
-            }
-            blocks = nb;
-            dcur = dout;
-            dpp ^= 1;
-        }
-        // dcur: one entry per row, rows ordered [level][window][bit within level], starting at d_off[level]
+        // cur: [kw] S, then one entry per bit-plane row, rows ordered [level][window][bit within level]
         // ---- ones bucket: its item sums form one row
         ones_ptr = nullptr;
         if (ones_hi > ones_lo) {
@@ -1059,18 +1045,7 @@ struct MsmJob : MsmJobBase {
         if (((size_t)P.kw + n_t + 1) * sizeof(XYZZ<F>) + 64 > MsmScratch::HOST_BYTES)
             return fail(ctx, ZG_E_INVALID_ARG, "msm: read-back of %zu window sums exceeds the pinned buffer", n_t);
         XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host + 64);   // the first 64 bytes keep the meta words
-        ZG_HIP(ctx, hipMemcpyAsync(hw, cur, (size_t)P.kw * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-        {   // every row now has one entry and the levels follow each other: one copy, level order
-            size_t rb = 0;
-            int bb = 0;
-            for (int l = 0; l < red_nlev; l++) {
-                red_rowbase[l] = (uint32_t)rb;
-                red_bitbase[l] = bb;
-                rb += M.rows[l];
-                bb += red_f[l];
-            }
-            ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw, dcur + M.d_off[0], n_t * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-        }
+        ZG_HIP(ctx, hipMemcpyAsync(hw, cur, ((size_t)P.kw + n_t) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + n_t, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
