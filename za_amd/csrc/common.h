@@ -149,6 +149,10 @@ struct MsmDesc {
     // optional, dense jobs run in parts: part k's stream waits for part_gate[k] (e.g. "scalar chunk k has arrived")
     const hipEvent_t* part_gate = nullptr;
     int parts = 0;   // 0 = the scheduler's choice
+    // optional: one class byte per scalar position (0 = zero, 1 = one, 2 = anything else; addressed like `scalars`,
+    // through `index` if there is one).  The classification and the digit sort then read 1 byte instead of 32 for
+    // every 0 / 1 scalar -- a witness query of the SHA-like workload is 97 % of those, and each job makes three passes.
+    const uint8_t* cls = nullptr;
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);

@@ -170,12 +170,17 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
 
 // zeros / ones / other scalars (through the index indirection), one atomic per wave and class
 __global__ void __launch_bounds__(256) k_classify(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
-                                                  size_t n, uint32_t* __restrict__ cls /*[3]*/) {
+                                                  const uint8_t* __restrict__ wcls, size_t n,
+                                                  uint32_t* __restrict__ cls /*[3]*/) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n_round = (n + 63) & ~(size_t)63;
     uint32_t zeros = 0, ones = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        if (i < n) {
+        if (i < n && wcls) {
+            const uint32_t c = wcls[index ? (size_t)index[i] : i];
+            zeros += c == 0;
+            ones += c == 1;
+        } else if (i < n) {
             Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
             uint32_t hi = s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7];
             zeros += (hi | s.w[0]) == 0;
@@ -217,7 +222,8 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
                                               size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
                                               int lb, uint32_t ntiles, uint32_t* __restrict__ tile_tab,
-                                              uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin) {
+                                              uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
+                                              const uint8_t* __restrict__ wcls) {
     extern __shared__ uint32_t lds_bins[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;  // last bin: scalars == 1
     const uint32_t wsel = kw == 1 ? 0u : ~0u;            // folded windows (fbw table): the window goes into the value
@@ -233,10 +239,20 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
         Scalar256 s;
 #pragma unroll
         for (int q = 0; q < 8; q++) s.w[q] = 0;
-        if (live) s = load_scalar(scalars, index ? (size_t)index[i] : i);
         // use_ones_bin == 0 (dense jobs, which queue the accumulation without reading the ones bucket's size back):
         // a scalar equal to 1 takes the digit path like any other value (digit 1 of window 0)
-        const bool one = use_ones_bin && live && scalar_is_one(s), zero = !live || scalar_is_zero(s);
+        bool one, zero;
+        if (wcls) {   // class bytes: only a "real" scalar is loaded
+            const size_t si = live ? (index ? (size_t)index[i] : i) : 0;
+            const uint32_t c = live ? wcls[si] : 0u;
+            zero = c == 0;
+            one = use_ones_bin && c == 1;
+            if (c == 2 || (c == 1 && !use_ones_bin)) s = load_scalar(scalars, si);
+        } else {
+            if (live) s = load_scalar(scalars, index ? (size_t)index[i] : i);
+            one = use_ones_bin && live && scalar_is_one(s);
+            zero = !live || scalar_is_zero(s);
+        }
         if (quad_n) {
             // Subset-sum table (msm_quad_build): the four lanes of an aligned group of positions whose scalars are
             // all 0 or 1 emit ONE entry, the table's sum over the positions holding a 1.
@@ -784,6 +800,7 @@ struct MsmJob : MsmJobBase {
     const Affine<F>* d_bases;
     const uint32_t* d_scalars;
     const uint32_t* d_index;
+    const uint8_t* d_cls = nullptr;   // MsmDesc::cls for this job's range
     size_t n;
     XYZZ<F>* out;
     bool dense = false;   // plan from n directly, no k_classify round trip
@@ -826,7 +843,7 @@ struct MsmJob : MsmJobBase {
         }
         ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
-        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, n, S.meta.as<uint32_t>() + 8);
+        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8);
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, st));
         return ZG_OK;
     }
@@ -887,7 +904,8 @@ struct MsmJob : MsmJobBase {
         const uint32_t quad_n = quad_table && !fbw_table && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
         const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin);
+                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
+                           d_cls);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -900,7 +918,7 @@ struct MsmJob : MsmJobBase {
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
-                           use_ones_bin);
+                           use_ones_bin, d_cls);
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
@@ -1197,6 +1215,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
                                                hi - lo, out));
     j->dense = d.dense;
+    j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
     if (d.quad_table) {
         j->quad_table = (const Affine<F>*)d.quad_table + lo;
         j->quad_base = (uint32_t)(d.n - lo + 15 * (lo / 4));   // the sums start at entry n of the table, 15 per group of 4
@@ -1227,6 +1246,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         int w_prio = g1[1].fbw_table ? lo_prio : hi_prio, h_prio = lo_prio;
         if (const char* e = getenv("ZA_AMD_WPRIO")) w_prio = atoi(e);
         if (const char* e = getenv("ZA_AMD_HPRIO")) h_prio = atoi(e);
+        // (Confining the witness streams to 16-128 of the 256 CUs with hipExtStreamCreateWithCUMask: measured, no gain --
+        // they need few CUs; what they cost the NTT pipeline is memory passes and launches, not compute units.)
         for (int k = 0; k < NS; k++)
             ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? h_prio : w_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
@@ -1364,7 +1385,8 @@ int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_i
     ZG_HIP(ctx, cnt.alloc(16));
     ZG_HIP(ctx, hipMemsetAsync(cnt.p, 0, 16, ctx->stream));
     const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
-    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, n, cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, (const uint8_t*)nullptr, n,
+                       cnt.as<uint32_t>());
     uint32_t h[2] = {0, 0};
     ZG_HIP(ctx, hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -141,6 +141,12 @@ __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, co
 
 struct ProveWs {
     DevBuf abc[3], h, wcls, w;
+    // wcls: one class byte per witness value (k_witness_classes), shared by the evaluator and the witness multiexps.
+    // wcls_for: the witness it was computed from; wcls_fresh: computed inside the current API call (the evaluator
+    // takes it as is); wcls_armed: a proof is in flight whose multiexps may use it (zg_prove_dev, or
+    // zg_prove_h_enqueue_dev -> zg_prove_partials_ex)
+    const void* wcls_for = nullptr;
+    bool wcls_fresh = false, wcls_armed = false;
 };
 static ProveWs& prove_ws(Ctx* ctx) {
     if (!ctx->prove_ws) ctx->prove_ws = new ProveWs();
@@ -822,6 +828,17 @@ extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) try {
     return zg::on_exception(nullptr);
 }
 
+static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   // queued on ctx->stream
+    ProveWs& ws = prove_ws(ctx);
+    const size_t nv = (size_t)r->n_inputs + r->n_aux;
+    ZG_HIP(ctx, ws.wcls.reserve(nv));
+    hipLaunchKernelGGL(k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
+                       ws.wcls.as<uint8_t>());
+    ZG_HIP(ctx, hipGetLastError());
+    ws.wcls_for = d_w;
+    return ZG_OK;
+}
+
 // d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
 // stored at index bitrev(i) (what h_poly_dev consumes)
 static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev) {
@@ -833,10 +850,8 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
     ProfScope ps(ctx, PROF_R1CS_EVAL, 36 * nnz_total + 96 * (r->n_constraints + r->n_inputs));
     if (bitrev && r->log_m >= 8 && r->n_constraints) {
         ProveWs& ws = prove_ws(ctx);
-        const size_t nv = (size_t)r->n_inputs + r->n_aux;
-        ZG_HIP(ctx, ws.wcls.reserve(nv));
-        hipLaunchKernelGGL(k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, d_w, nv,
-                           ws.wcls.as<uint8_t>());
+        if (!ws.wcls_fresh || ws.wcls_for != (const void*)d_w) ZG_TRY(witness_classes(ctx, r, d_w));
+        ws.wcls_fresh = false;
         for (int k = 0; k < 3; k++)
             hipLaunchKernelGGL(k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
                                r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
@@ -1082,6 +1097,8 @@ extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void*
     // mask gates its multiexps on this event instead of on everything queued so far, so rank 0's l / a / b jobs run
     // beside its NTT passes (as they do inside zg_prove_dev) rather than after them.
     ZG_TRY(gate_events(ctx));
+    ZG_TRY(witness_classes(ctx, r, d_witness));   // before the gate: the witness multiexps read the class bytes too
+    prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ctx->witness_gate_armed = true;
     return prove_h_enqueue(ctx, r, d_witness, d_h_out);
@@ -1099,6 +1116,7 @@ struct QueryUse {
     const uint32_t* scalars;
     const uint32_t* index;
     uint64_t n;
+    const uint8_t* cls = nullptr;   // class bytes addressed like `scalars` (MsmDesc::cls)
 };
 static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
@@ -1176,7 +1194,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
 
 // the five multiexps' operands for this rank's shard (n = 0 where the mask leaves a query out)
 static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const void* d_h_shard,
-                      unsigned mask, QueryUse use[5]) {
+                      unsigned mask, QueryUse use[5], const uint8_t* wcls = nullptr) {
     const uint64_t m = (uint64_t)1 << r->log_m;
     const uint32_t* w = (const uint32_t*)d_witness;
     {   // h: first m-1 points of the query; this shard holds [lo, hi)
@@ -1189,19 +1207,20 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
         const auto& q = p->q[1];
         uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
         uint64_t n = hi > q.lo && (mask & 2u) ? hi - q.lo : 0;
-        use[1] = QueryUse{q.buf.p, w ? w + 8 * ((size_t)r->n_inputs + q.lo) : nullptr, nullptr, n};
+        use[1] = QueryUse{q.buf.p, w ? w + 8 * ((size_t)r->n_inputs + q.lo) : nullptr, nullptr, n,
+                          wcls ? wcls + (size_t)r->n_inputs + q.lo : nullptr};
     }
     {   // a: inputs (full density) then aux by a_aux_density
         const auto& q = p->q[2];
-        use[2] = QueryUse{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (mask & 4u) ? q.hi - q.lo : 0};
+        use[2] = QueryUse{q.buf.p, w, r->a_index.as<uint32_t>() + q.lo, (mask & 4u) ? q.hi - q.lo : 0, wcls};
     }
     {
         const auto& q = p->q[3];
-        use[3] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 8u) ? q.hi - q.lo : 0};
+        use[3] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 8u) ? q.hi - q.lo : 0, wcls};
     }
     {
         const auto& q = p->q[4];
-        use[4] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 16u) ? q.hi - q.lo : 0};
+        use[4] = QueryUse{q.buf.p, w, r->b_index.as<uint32_t>() + q.lo, (mask & 16u) ? q.hi - q.lo : 0, wcls};
     }
     (void)ctx;
     return ZG_OK;
@@ -1239,12 +1258,24 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     G1XYZZ g1out[4];
     G2XYZZ b2_acc;
     QueryUse use[5];
-    ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use));
+    // class bytes of the witness: from this proof's zg_prove_dev / zg_prove_h_enqueue_dev, else computed here (the
+    // multiexps of a rank that does not evaluate the R1CS) -- then the jobs wait for everything queued so far
+    ProveWs& ws = prove_ws(ctx);
+    bool own_classes = false;
+    if (mask & 0x1eu) {
+        if (!(ws.wcls_armed && ws.wcls_for == d_witness)) {
+            ZG_TRY(witness_classes(ctx, r, d_witness));
+            own_classes = true;
+        }
+    }
+    ws.wcls_armed = false;
+    ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use, (mask & 0x1eu) ? ws.wcls.as<uint8_t>() : nullptr));
     if (use[0].n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
     ZG_TRY(ensure_tables(ctx, p, use, mask));
     MsmDesc d1[4], d2;
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
+        d.cls = k == 0 ? nullptr : use[k].cls;
         const auto& t = p->fbw[k];
         if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
             d.quad_table = t.buf.p;
@@ -1258,6 +1289,7 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     }
     hipEvent_t ev_wit = ctx->ev_witness;
     if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
+    if (own_classes) ev_wit = nullptr;   // the class kernel was queued just now: gate on "everything so far"
     ctx->witness_gate_armed = false;
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
@@ -1362,6 +1394,12 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     // The witness MSMs do not depend on H: gate them on "now", queue the NTT pipeline, gate the h MSM
     // on its completion, and let the job scheduler overlap everything.
     ZG_TRY(gate_events(ctx));
+    struct ClassGuard {   // whatever way this call ends, the class bytes are not taken for a later proof's
+        ProveWs& ws;
+        ~ClassGuard() { ws.wcls_armed = ws.wcls_fresh = false; }
+    } class_guard{prove_ws(ctx)};
+    ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
+    prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1]));
