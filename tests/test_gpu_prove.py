@@ -650,3 +650,28 @@ def test_dense_h_job_with_zero_one_and_extreme_coefficients(ctx, monkeypatch, lg
     assert co.prove(download_params(ctx, P), csr, wb, 0x777, 0x999, threads=8) == got
     assert za_amd.verify(pbytes, got, []) is True
 
+
+
+def test_one_key_many_witnesses_with_moving_statistics(ctx):
+    """Consecutive proofs with ONE key whose witnesses have very different shares of 0 / 1 / other values: the scratch
+    of a multiexp slot is re-used from proof to proof and the witness multiexps take the evaluator's class bytes, so
+    every transition (bits -> field elements -> zeros -> ones -> mixed -> bits) must still give the oracle's bytes."""
+    import random
+    n_aux = (1 << 13) - 2
+    cons = [([(1 + i, 1)], [(0, 1)], [(1 + i, 1)]) for i in range(n_aux)]      # x * ONE = x: any assignment satisfies
+    r1 = g.R1CS(1, n_aux, cons)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    P, _ = ctx.setup(R, 11, 12, 13, 14, 15, want_bytes=False)
+    mp = download_params(ctx, P)
+    rng = random.Random(77)
+    bits = lambda p1: [1 if rng.random() < p1 else 0 for _ in range(n_aux)]
+    field = lambda: [rng.randrange(bn.R) for _ in range(n_aux)]
+    mixed = lambda p: [rng.randrange(bn.R) if rng.random() < p else rng.randrange(2) for _ in range(n_aux)]
+    series = [bits(0.5), field(), [0] * n_aux, [1] * n_aux, mixed(0.03), bits(0.9), mixed(0.5), [0] * (n_aux - 1) + [5],
+              bits(0.5), field(), field()]
+    for k, aux in enumerate(series):
+        w = co.witness_bytes([1] + aux)
+        r, s = 100 + k, 200 + k
+        assert ctx.prove(P, R, w, r, s) == co.prove(mp, csr, w, r, s, threads=8), "witness %d of the series" % k
+    P.close(); R.close()
