@@ -41,9 +41,13 @@ def parse():
                     help="extra line: throughput with this many concurrent provers on the GPU (1 = skip); the headline "
                          "value is always one proof at a time")
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "poseidon"],
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "poseidon", "sha256"],
                     help="synthetic = config-4-shaped random R1CS (the headline); poseidon = circomlib Poseidon(t=6) hash "
-                         "chain padded to 2^log_m (BASELINE config 3: use --log-m 20), generated in Python (~15 s at 2^20)")
+                         "chain padded to 2^log_m (BASELINE config 3: use --log-m 20), generated in Python (~15 s at 2^20); "
+                         "sha256 = bit-level SHA-256 Merkle inclusion of --depth levels (BASELINE config 4 on a real "
+                         "circuit: depth 32 is 1.48 M constraints in a 2^21 domain, depth 90 fills 2^22); --log-m is "
+                         "then derived from the circuit")
+    ap.add_argument("--depth", type=int, default=32, help="--workload sha256: levels of the Merkle path")
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
     ap.add_argument("--cpu-log-m", type=int, default=22, help="size of the bounded CPU-baseline sample (2^22 = the GPU workload itself, ~10 s of CPU)")
@@ -65,10 +69,22 @@ def cpu_baseline(ctx, args):
     from oracle import coracle as co
     from za_amd import synth
     lg = min(args.cpu_log_m, args.log_m)
-    sr = synth.SynthR1CS(lg, 2, args.bit_fraction, args.seed)
-    r1 = sr.load(ctx)
+    if args.workload == "sha256":
+        from za_amd import workloads
+
+        class _W:
+            pass
+        sr = _W()
+        (sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff, sr.witness,
+         _info) = workloads.sha256_merkle(args.depth)
+        sr.close = lambda: None
+        r1 = ctx.r1cs_load(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+        lg = r1.log_m
+    else:
+        sr = synth.SynthR1CS(lg, 2, args.bit_fraction, args.seed)
+        r1 = sr.load(ctx)
     m = 1 << lg
-    n_a = 2 + r1.a_aux_total
+    n_a = sr.n_inputs + r1.a_aux_total
     n_b = r1.b_input_total + r1.b_aux_total
     if args.synthetic_key:
         P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, 1000)
@@ -102,7 +118,7 @@ def cpu_baseline(ctx, args):
     sr.close()
     return {"value": n / dt, "unit": "constraints/s", "cores": threads, "host_cores": cores, "kind": "port",
             "sample": "oracle/c create_proof (bellman-algorithm port: c = ceil(ln n) windows, the 8 multiexps' windows "
-                      "in one %d-thread pool, radix-2 FFT) on the same synthetic workload at 2^%d constraints: "
+                      "in one %d-thread pool, radix-2 FFT) on the same workload at 2^%d constraints: "
                       "%.2f s (r1cs %.2f, H %.2f, MSM %.2f); proof bytes equal to the GPU's: %s"
                       % (threads, lg, dt, tm[0], tm[1], tm[2], ok)}
 
@@ -200,6 +216,22 @@ def main():
         del cons, wit, rp, cl, cf
         if args.synthetic_key or world > 1:
             print("--workload poseidon runs on one GPU with a key from zg_setup", file=sys.stderr)
+            sys.exit(2)
+    elif args.workload == "sha256":
+        from za_amd import workloads
+
+        class _W:
+            pass
+        sr = _W()
+        sr.n_inputs, sr.n_aux, sr.n_constraints, rp, cl, cf, wit, sha_info = workloads.sha256_merkle(args.depth)
+        sr.nnz = sha_info["nnz"]
+        sr.witness = wit
+        sr.close = lambda: None
+        r1 = ctx.r1cs_load(sr.n_inputs, sr.n_aux, sr.n_constraints, rp, cl, cf)
+        args.log_m = r1.log_m
+        del rp, cl, cf, wit
+        if args.synthetic_key or world > 1:
+            print("--workload sha256 runs on one GPU with a key from zg_setup", file=sys.stderr)
             sys.exit(2)
     else:
         sr = synth.SynthR1CS(args.log_m, 2, args.bit_fraction, args.seed)
@@ -462,6 +494,10 @@ def main():
             "config": {"workload": ("Poseidon(t=6, RF=8, RP=57, circomlib parameters) hash chain of %d permutations, config 3 "
                                     "shape, padded to n_constraints + n_inputs = 2^%d, proving key from zg_setup"
                                     % (n_perm, args.log_m)) if args.workload == "poseidon" else
+                                   ("SHA-256 Merkle inclusion, depth %d (bit-level circuit, two compressions per level, root "
+                                    "= 2 public inputs; witness and root checked against hashlib), config 4 on a real "
+                                    "circuit, domain 2^%d, proving key from zg_setup" % (args.depth, args.log_m))
+                                   if args.workload == "sha256" else
                                    "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
                                    "seed 0x%x), n_constraints + n_inputs = 2^%d, %s"
                                    % (100 * args.bit_fraction, args.seed, args.log_m,
@@ -490,7 +526,7 @@ def main():
             line["shard_model"] = shard_line
         if conc_line:
             line["concurrent_provers"] = conc_line
-        if not args.no_cpu_baseline and world == 1 and args.workload == "synthetic":
+        if not args.no_cpu_baseline and world == 1 and args.workload in ("synthetic", "sha256"):
             try:
                 line["cpu_baseline"] = cpu_baseline(ctx, args)
             except Exception as e:  # the bench line must still come out

@@ -675,3 +675,24 @@ def test_one_key_many_witnesses_with_moving_statistics(ctx):
         r, s = 100 + k, 200 + k
         assert ctx.prove(P, R, w, r, s) == co.prove(mp, csr, w, r, s, threads=8), "witness %d of the series" % k
     P.close(); R.close()
+
+
+def test_sha256_merkle_circuit_setup_prove_verify(ctx):
+    """BASELINE config 4 on a real circuit (za_amd/workloads.py::sha256_merkle, depth 2: 92 k bit-level constraints,
+    long addition rows, > 99 % bit witness): constraint check on the GPU, GPU set-up, proof equal to the C oracle's
+    bytes, pairing check with the hashlib root as the public input and rejection of another root."""
+    import za_amd
+    from za_amd import workloads
+    ni, na, nc, rp, col, cf, wit, info = workloads.sha256_merkle(2, seed=3)
+    R = ctx.r1cs_load(ni, na, nc, rp, col, cf)
+    assert R.check(wit) is None
+    P, pbytes = ctx.setup(R, 0xA1, 0xB2, 0xC3, 0xD4, 0xE5)
+    got = ctx.prove(P, R, wit, 0x1234567, 0x7654321)
+    csr = co.CsrR1CS(ni, na, nc, rp, col, cf)
+    assert co.prove(download_params(ctx, P), csr, wit, 0x1234567, 0x7654321, threads=16) == got
+    root = info["root"]
+    pub = [int.from_bytes(root[:16], "big"), int.from_bytes(root[16:], "big")]
+    assert za_amd.verify(pbytes, got, pub) is True
+    assert za_amd.verify(pbytes, got, [pub[0], pub[1] ^ 1]) is False
+    assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [2, 2, 2, 2]     # subset-sum tables on all witness queries
+    P.close(); R.close()

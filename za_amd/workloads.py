@@ -124,3 +124,297 @@ def csr_arrays(constraints):
 
 def witness_bytes(w):
     return b"".join((x % R).to_bytes(32, "little") for x in w)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SHA-256 Merkle inclusion = BASELINE.json config 4's family ("SHA256 Merkle-inclusion depth-32"): a bit-level R1CS of
+# `depth` two-to-one SHA-256 hashes (64-byte message = left || right, so two compressions per level, the second over the
+# constant padding block), a direction bit per level choosing the order, the root as two 128-bit public inputs.
+# Every wire is a bit, as in circomlib's sha256 (interop/circuits/circomlib/circuits/sha256/*.circom); the gadgets are
+# this file's own (xor: 1 constraint, ch: 1, maj: 2, k-operand addition mod 2^32: one linear row + booleanity of the
+# 32 + carry result bits), so the count per compression (~23 k) differs from circomlib's (~29 k).  The witness comes out
+# of the same pass and the root is pinned by hashlib in tests/.  Arrays are built with numpy, one gadget = 32 rows.
+_SHA_K = [
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+_SHA_H0 = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+
+class _Word:
+    """32 wires, least significant bit first: `var` = variable index per bit (-1: the bit is the constant in `val`),
+    `val` = the bit values (uint8)."""
+    __slots__ = ("var", "val")
+
+    def __init__(self, var, val):
+        self.var, self.val = var, val
+
+    @staticmethod
+    def const(x):
+        return _Word(np.full(32, -1, dtype=np.int64), np.array([(x >> i) & 1 for i in range(32)], dtype=np.uint8))
+
+    def rotr(self, r):
+        return _Word(np.roll(self.var, -r), np.roll(self.val, -r))
+
+    def shr(self, r):
+        var = np.concatenate([self.var[r:], np.full(r, -1, dtype=np.int64)])
+        val = np.concatenate([self.val[r:], np.zeros(r, dtype=np.uint8)])
+        return _Word(var, val)
+
+    def value(self):
+        return int(sum(int(b) << i for i, b in enumerate(self.val)))
+
+
+class _ShaBuilder:
+    def __init__(self, n_inputs):
+        self.n_inputs = n_inputs          # variable 0 = ONE, 1 .. n_inputs-1 public
+        self.values = [np.zeros(n_inputs, dtype=object)]
+        self.values[0][0] = 1
+        self.nvars = n_inputs
+        self.m = [dict(lens=[], cols=[], coefs=[]) for _ in range(3)]
+        self.n_rows = 0
+
+    def new_bits(self, vals):
+        v = np.arange(self.nvars, self.nvars + len(vals), dtype=np.int64)
+        self.nvars += len(vals)
+        self.values.append(np.asarray(vals, dtype=object))
+        return v
+
+    def _push(self, k, cols, coefs):
+        """cols / coefs: (rows, terms) arrays; terms with column < 0 are dropped (constant-zero operands)."""
+        cols = np.asarray(cols, dtype=np.int64)
+        coefs = np.asarray(coefs, dtype=np.int64)
+        if cols.ndim == 1:
+            cols, coefs = cols[None, :], coefs[None, :]
+        keep = (cols >= 0) & (coefs != 0)
+        self.m[k]["lens"].append(keep.sum(axis=1).astype(np.int64))
+        self.m[k]["cols"].append(cols[keep])
+        self.m[k]["coefs"].append(coefs[keep])
+
+    def rows(self, A, B, C):
+        """One batch of constraints <A, w> * <B, w> = <C, w>; each of A, B, C = (cols, coefs) with equal row counts."""
+        n = None
+        for k, (cols, coefs) in enumerate((A, B, C)):
+            cols = np.asarray(cols, dtype=np.int64)
+            n = cols.shape[0] if cols.ndim == 2 else 1
+            self._push(k, cols, coefs)
+        self.n_rows += n
+
+    # ---- gadgets over 32-bit words (bits that are constants never get a row) ----
+    def boolean(self, var):
+        n = len(var)
+        one = np.zeros(n, dtype=np.int64)
+        self.rows((var[:, None], np.ones((n, 1), dtype=np.int64)),
+                  (np.stack([var, one], axis=1), np.stack([np.ones(n, dtype=np.int64), -np.ones(n, dtype=np.int64)], axis=1)),
+                  (np.full((n, 1), -1, dtype=np.int64), np.zeros((n, 1), dtype=np.int64)))
+
+    def xor2(self, x, y):
+        val = x.val ^ y.val
+        var = np.where(x.var < 0, y.var, x.var).copy()        # one side constant 0: the other side as is
+        cx, cy = x.var < 0, y.var < 0
+        flip = (cx & (x.val == 1)) | (cy & (y.val == 1))      # xor with the constant 1: handled as 1 - bit below
+        both = ~cx & ~cy
+        if both.any():
+            nv = self.new_bits(val[both])
+            a, b = x.var[both], y.var[both]
+            n = len(nv)
+            o = np.ones(n, dtype=np.int64)
+            self.rows((a[:, None], 2 * o[:, None]), (b[:, None], o[:, None]),
+                      (np.stack([a, b, nv], axis=1), np.stack([o, o, -o], axis=1)))
+            var[both] = nv
+        if flip.any():
+            idx = np.where(flip & ~(cx & cy))[0]
+            if len(idx):                                       # 1 - bit as a new wire: (1 - b) * 1 = n
+                src = var[idx]
+                nv = self.new_bits(val[idx])
+                n = len(nv)
+                o = np.ones(n, dtype=np.int64)
+                z = np.zeros(n, dtype=np.int64)
+                self.rows((np.stack([z, src], axis=1), np.stack([o, -o], axis=1)), (z[:, None], o[:, None]), (nv[:, None], o[:, None]))
+                var[idx] = nv
+        var[cx & cy] = -1
+        return _Word(var, val)
+
+    def xor3(self, x, y, z):
+        return self.xor2(self.xor2(x, y), z)
+
+    @staticmethod
+    def _t(w, coef=1):
+        """(cols, coefs) of the 32 bits of a word with a common coefficient; a constant bit becomes coef * bit on ONE."""
+        c = np.full(32, coef, dtype=np.int64)
+        isc = w.var < 0
+        return np.where(isc, 0, w.var), np.where(isc, c * w.val.astype(np.int64), c)
+
+    @staticmethod
+    def _lc(*terms):
+        cols, coefs = zip(*terms)
+        return np.stack(cols, axis=1), np.stack(coefs, axis=1)
+
+    def ch(self, e, f, g):
+        val = (e.val & f.val) | ((1 - e.val) & g.val)
+        if all((w.var < 0).all() for w in (e, f, g)):
+            return _Word(np.full(32, -1, dtype=np.int64), val)
+        nv = self.new_bits(val)
+        o = np.ones(32, dtype=np.int64)
+        self.rows(self._lc(self._t(e)), self._lc(self._t(f), self._t(g, -1)), self._lc((nv, o), self._t(g, -1)))
+        return _Word(nv, val)
+
+    def maj(self, a, b, c):
+        val = (a.val & b.val) | (a.val & c.val) | (b.val & c.val)
+        if all((w.var < 0).all() for w in (a, b, c)):
+            return _Word(np.full(32, -1, dtype=np.int64), val)
+        tval = a.val & b.val
+        t = self.new_bits(tval)
+        o = np.ones(32, dtype=np.int64)
+        self.rows(self._lc(self._t(a)), self._lc(self._t(b)), self._lc((t, o)))
+        nv = self.new_bits(val)
+        self.rows(self._lc(self._t(c)), self._lc(self._t(a), self._t(b), (t, -2 * o)), self._lc((nv, o), (t, -o)))
+        return _Word(nv, val)
+
+    def add(self, words, const=0):
+        """Sum of the words (+ a constant) mod 2^32: one linear row  sum = result + 2^32 * carry  and booleanity of the
+        32 result bits and the carry bits."""
+        total = sum(w.value() for w in words) + const
+        kmax = (len(words) * 0xFFFFFFFF + const) >> 32
+        nc = max(kmax.bit_length(), 0)
+        bits = np.array([(total >> i) & 1 for i in range(32 + nc)], dtype=np.uint8)
+        nv = self.new_bits(bits)
+        self.boolean(nv)
+        pw = np.array([1 << i for i in range(32)], dtype=np.int64)
+        cols = [np.zeros(1, dtype=np.int64)] + [w.var for w in words]
+        cconst = const + sum(int((w.val[w.var < 0].astype(np.int64) * pw[w.var < 0]).sum()) for w in words)
+        coefs = [np.array([cconst], dtype=np.int64)] + [pw for _ in words]
+        self.rows((np.concatenate(cols), np.concatenate(coefs)), (np.zeros(1, dtype=np.int64), np.ones(1, dtype=np.int64)),
+                  (nv, np.array([1 << i for i in range(32 + nc)], dtype=np.int64)))
+        return _Word(nv[:32], bits[:32])
+
+    def big_s0(self, a):
+        return self.xor3(a.rotr(2), a.rotr(13), a.rotr(22))
+
+    def big_s1(self, e):
+        return self.xor3(e.rotr(6), e.rotr(11), e.rotr(25))
+
+    def small_s0(self, x):
+        return self.xor3(x.rotr(7), x.rotr(18), x.shr(3))
+
+    def small_s1(self, x):
+        return self.xor3(x.rotr(17), x.rotr(19), x.shr(10))
+
+    def compress(self, state, w16):
+        """One SHA-256 compression; `w16` words may be constants (then the schedule costs nothing)."""
+        W = list(w16)
+        all_const = all((w.var < 0).all() for w in W)
+        for t in range(16, 64):
+            if all_const:
+                s0 = (lambda x: ((x >> 7 | x << 25) ^ (x >> 18 | x << 14) ^ (x >> 3)) & 0xFFFFFFFF)(W[t - 15].value())
+                s1 = (lambda x: ((x >> 17 | x << 15) ^ (x >> 19 | x << 13) ^ (x >> 10)) & 0xFFFFFFFF)(W[t - 2].value())
+                W.append(_Word.const((W[t - 16].value() + s0 + W[t - 7].value() + s1) & 0xFFFFFFFF))
+            else:
+                W.append(self.add([W[t - 16], self.small_s0(W[t - 15]), W[t - 7], self.small_s1(W[t - 2])]))
+        a, b, c, d, e, f, g, h = state
+        for t in range(64):
+            s1, chv, s0, mj = self.big_s1(e), self.ch(e, f, g), self.big_s0(a), self.maj(a, b, c)
+            new_e = self.add([d, h, s1, chv, W[t]], _SHA_K[t])
+            new_a = self.add([h, s1, chv, W[t], s0, mj], _SHA_K[t])
+            a, b, c, d, e, f, g, h = new_a, a, b, c, new_e, e, f, g
+        return [self.add([x, y]) for x, y in zip(state, (a, b, c, d, e, f, g, h))]
+
+    def finish(self):
+        values = np.concatenate(self.values)
+        out = []
+        for k in range(3):
+            lens = np.concatenate(self.m[k]["lens"])
+            rp = np.zeros(len(lens) + 1, dtype=np.uint64)
+            np.cumsum(lens, out=rp[1:])
+            out.append((rp, np.concatenate(self.m[k]["cols"]).astype(np.uint32), np.concatenate(self.m[k]["coefs"])))
+        return values, out
+
+
+def _coeff_bytes(coefs):
+    """int64 coefficients -> 32-byte little-endian canonical field elements (negative values as R - |c|)."""
+    uniq, inv = np.unique(coefs, return_inverse=True)
+    table = np.frombuffer(b"".join((int(c) % R).to_bytes(32, "little") for c in uniq), dtype=np.uint8).reshape(len(uniq), 32)
+    return table[inv].reshape(-1)
+
+
+def _bytes_to_words(b):
+    """32 bytes -> 8 big-endian 32-bit integers (SHA-256's word order)."""
+    return [int.from_bytes(b[4 * i:4 * i + 4], "big") for i in range(8)]
+
+
+def sha256_merkle(depth, seed=1):
+    """R1CS + witness of a depth-`depth` SHA-256 Merkle inclusion proof.
+    Returns (n_inputs, n_aux, n_constraints, row_ptr[3], col[3], coeff_bytes[3], witness_bytes, info) in the layout
+    zg_r1cs_load / zg_prove take; info = {"root", "leaf", "siblings", "directions"} for the hashlib cross-check."""
+    rnd = hashlib.blake2b(b"sha256_merkle:%d:%d" % (depth, seed), digest_size=64).digest
+    leaf = hashlib.sha256(b"leaf" + seed.to_bytes(4, "little")).digest()
+    sibs = [hashlib.sha256(b"sib%d:%d" % (i, seed)).digest() for i in range(depth)]
+    dirs = [(rnd()[i % 64] >> (i // 64 % 8)) & 1 for i in range(depth)]
+    B = _ShaBuilder(n_inputs=3)
+
+    def private_words(b):
+        words = []
+        for x in _bytes_to_words(b):
+            bits = np.array([(x >> i) & 1 for i in range(32)], dtype=np.uint8)
+            v = B.new_bits(bits)
+            B.boolean(v)
+            words.append(_Word(v, bits))
+        return words
+
+    cur = private_words(leaf)
+    cur_bytes = leaf
+    pad = [_Word.const(0x80000000)] + [_Word.const(0)] * 14 + [_Word.const(512)]
+    o32 = np.ones(32, dtype=np.int64)
+    for lvl in range(depth):
+        sib = private_words(sibs[lvl])
+        dbit = B.new_bits(np.array([dirs[lvl]], dtype=np.uint8))
+        B.boolean(dbit)
+        left, right = [], []
+        for cw, sw in zip(cur, sib):              # left = cur + d (sib - cur), right = cur + sib - left
+            lval = np.where(dirs[lvl], sw.val, cw.val).astype(np.uint8)
+            lv = B.new_bits(lval)
+            B.rows((np.full((32, 1), dbit[0], dtype=np.int64), o32[:, None]),
+                   (np.stack([sw.var, cw.var], axis=1), np.stack([o32, -o32], axis=1)),
+                   (np.stack([lv, cw.var], axis=1), np.stack([o32, -o32], axis=1)))
+            rval = np.where(dirs[lvl], cw.val, sw.val).astype(np.uint8)
+            rv = B.new_bits(rval)
+            B.rows((np.stack([sw.var, cw.var, lv], axis=1), np.stack([o32, o32, -o32], axis=1)),
+                   (np.zeros((32, 1), dtype=np.int64), o32[:, None]), (rv[:, None], o32[:, None]))
+            left.append(_Word(lv, lval))
+            right.append(_Word(rv, rval))
+        st = B.compress([_Word.const(x) for x in _SHA_H0], left + right)
+        cur = B.compress(st, pad)
+        lb, rb = (sibs[lvl], cur_bytes) if dirs[lvl] else (cur_bytes, sibs[lvl])
+        cur_bytes = hashlib.sha256(lb + rb).digest()
+        assert b"".join(w.value().to_bytes(4, "big") for w in cur) == cur_bytes, "gadget witness != hashlib at level %d" % lvl
+    # public inputs: the root as two 128-bit integers (big-endian halves of the digest)
+    root_hi, root_lo = int.from_bytes(cur_bytes[:16], "big"), int.from_bytes(cur_bytes[16:], "big")
+    one_c, one_v = np.zeros(1, dtype=np.int64), np.ones(1, dtype=np.int64)
+    pw32 = np.array([1 << i for i in range(32)], dtype=np.int64)
+    for inp, words in ((1, cur[:4]), (2, cur[4:])):
+        # inp = w0 * 2^96 + w1 * 2^64 + w2 * 2^32 + w3 (big-endian words), built from 32-bit word values so that every
+        # coefficient fits 64 bits:  wv_j = sum 2^i bit_i;  t = wv0 * 2^32 + wv1;  u = t * 2^32 + wv2;  inp = u * 2^32 + wv3
+        wv = []
+        for w in words:
+            v = B.new_bits(np.array([w.value()], dtype=object))
+            B.rows((w.var, pw32), (one_c, one_v), (v, one_v))
+            wv.append((v[0], w.value()))
+        acc_var, acc_val = wv[0]
+        for j in (1, 2, 3):
+            nxt_val = (acc_val << 32) + wv[j][1]
+            nxt_var = inp if j == 3 else B.new_bits(np.array([nxt_val], dtype=object))[0]
+            B.rows((np.array([acc_var]), one_v), (one_c, np.array([1 << 32])), (np.array([nxt_var, wv[j][0]]), np.array([1, -1])))
+            acc_var, acc_val = nxt_var, nxt_val
+    values, mats = B.finish()
+    values[1], values[2] = root_hi, root_lo
+    n_aux = B.nvars - 3
+    row_ptr = [m[0] for m in mats]
+    col = [m[1] for m in mats]
+    coeff = [_coeff_bytes(m[2]) for m in mats]
+    wit = b"".join(int(v).to_bytes(32, "little") for v in values)
+    info = {"root": cur_bytes, "leaf": leaf, "siblings": sibs, "directions": dirs, "nnz": [int(len(c)) for c in col]}
+    return 3, n_aux, B.n_rows, row_ptr, col, coeff, wit, info
