@@ -696,3 +696,38 @@ def test_sha256_merkle_circuit_setup_prove_verify(ctx):
     assert za_amd.verify(pbytes, got, [pub[0], pub[1] ^ 1]) is False
     assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [2, 2, 2, 2]     # subset-sum tables on all witness queries
     P.close(); R.close()
+
+
+def test_long_rows_take_the_wave_per_row_evaluator(ctx):
+    """Rows with more than 32 terms (k_r1cs_eval_long: one wave per row) next to short ones, in all three matrices, with
+    field-element coefficients and values (Montgomery path), +-2^s coefficients on bits (integer path), and lengths
+    around the threshold and around the wave size."""
+    import random
+    rng = random.Random(4242)
+    n_x = 300
+    xs = [rng.randrange(bn.R) if i % 3 else rng.randrange(2) for i in range(n_x)]
+    cons, aux = [], list(xs)
+    var = lambda i: 1 + i                                  # variable 0 = ONE, aux from 1
+    for i in range(n_x):                                   # every x is constrained: x * ONE = x
+        cons.append(([(var(i), 1)], [(0, 1)], [(var(i), 1)]))
+    for length in (31, 32, 33, 63, 64, 65, 129, 200):
+        idx = rng.sample(range(n_x), length)
+        coef = [rng.choice([1, 2, bn.R - 4, 1 << 20, rng.randrange(bn.R)]) for _ in idx]
+        y = sum(c * xs[i] for c, i in zip(coef, idx)) % bn.R
+        aux.append(y)
+        yv = len(aux)                                      # its variable index
+        lc = [(var(i), c) for c, i in zip(coef, idx)]
+        cons.append((lc, [(0, 1)], [(yv, 1)]))             # long A
+        cons.append(([(0, 1)], lc, [(yv, 1)]))             # long B
+        cons.append(([(yv, 1)], [(0, 1)], lc))             # long C
+    r1 = g.R1CS(1, len(aux), cons)
+    w = [1] + aux
+    assert r1.is_satisfied(w)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    assert R.log_m >= 8
+    wb = co.witness_bytes(w)
+    assert R.check(wb) is None
+    P, _ = ctx.setup(R, 21, 22, 23, 24, 25, want_bytes=False)
+    assert ctx.prove(P, R, wb, 8, 9) == co.prove(download_params(ctx, P), csr, wb, 8, 9, threads=4)
+    P.close(); R.close()

@@ -13,6 +13,10 @@ struct zg_r1cs {
     uint32_t log_m = 0;
     zg::DevBuf row_ptr[3], col[3], coeff[3];
     zg::DevBuf ccls[3];   // per-term coefficient class (prover.hip k_coeff_prepare)
+    // rows with more than R1CS_LONG_ROW terms (a 32-bit adder's linear row has ~200): the tiled evaluator leaves them
+    // to k_r1cs_eval_long, one wave per row
+    zg::DevBuf long_rows[3];
+    uint32_t n_long[3] = {0, 0, 0};
     // dense position -> flat variable index for the a and b queries
     zg::DevBuf a_index, b_index;
     uint64_t n_a = 0, n_b = 0;

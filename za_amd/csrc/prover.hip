@@ -160,6 +160,7 @@ static ProveWs& prove_ws(Ctx* ctx) {
 // Terms whose coefficient is +-2^s and whose witness value is 0 or 1 are summed in two 128-bit integers (no gather
 // of the 32-byte operands, no field multiplication); everything else takes the Montgomery path.
 __device__ __forceinline__ uint32_t rev4(uint32_t x) { return __brev(x) >> 28; }
+static constexpr uint64_t R1CS_LONG_ROW = 32;   // terms; longer rows go to k_r1cs_eval_long
 __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                          const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
                                                          const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
@@ -168,10 +169,16 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(const uint64_t* __restr
     const uint32_t t = threadIdx.x, ta = t >> 4, tb = t & 15, mid = blockIdx.x;
     const uint64_t row = ((uint64_t)ta << (log_m - 4)) | ((uint64_t)mid << 4) | tb;
     FrD acc = FrD::zero();
+    uint64_t e_lo = 0, e_hi = 0;
+    if (row < n_rows) {
+        e_lo = row_ptr[row];
+        e_hi = row_ptr[row + 1];
+        if (e_hi - e_lo > R1CS_LONG_ROW) e_hi = e_lo;   // left to k_r1cs_eval_long (queued behind this kernel)
+    }
     if (row < n_rows) {
         uint64_t pos_lo = 0, pos_hi = 0, neg_lo = 0, neg_hi = 0;
         uint32_t since = 0;
-        for (uint64_t e = row_ptr[row], end = row_ptr[row + 1]; e < end; e++) {
+        for (uint64_t e = e_lo, end = e_hi; e < end; e++) {
             const uint32_t c = col[e];
             const uint32_t wc = wcls[c];
             if (wc == 0) continue;
@@ -213,6 +220,76 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(const uint64_t* __restr
     const uint32_t rmid = log_m > 8 ? (__brev(mid) >> (32 - (log_m - 8))) : 0u;
     const uint64_t dst = ((uint64_t)(t >> 4) << (log_m - 4)) | ((uint64_t)rmid << 4) | (t & 15);
     out[dst] = tile[src];
+}
+
+// One wave per long row (a 32-bit adder's linear row: ~200 terms, all of them bit x 2^s): a thread walking it alone
+// is 200 dependent col -> class gathers, and a third of the waves of a SHA-256 circuit contain such a row.  The lanes
+// take the terms 64 at a time, sum their share as the tiled kernel does, and the 64 partial sums are added in the field.
+__global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restrict__ rows, uint32_t n_long,
+                                                        const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                        const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
+                                                        const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
+                                                        Fr* __restrict__ out, int log_m) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n_long) return;
+    const uint64_t row = rows[wave];
+    FrD acc = FrD::zero();
+    uint64_t pos_lo = 0, pos_hi = 0, neg_lo = 0, neg_hi = 0;
+    uint32_t since = 0;
+    for (uint64_t e = row_ptr[row] + lane, end = row_ptr[row + 1]; e < end; e += 64) {
+        const uint32_t c = col[e];
+        const uint32_t wc = wcls[c];
+        if (wc == 0) continue;
+        const uint32_t k = ccls[e];
+        if (wc == 1 && k != 0) {
+            const uint64_t bit = 1ull << ((k - 1) & 63);
+            if (k <= 64) {
+                pos_lo += bit;
+                pos_hi += pos_lo < bit;
+            } else {
+                neg_lo += bit;
+                neg_hi += neg_lo < bit;
+            }
+            continue;
+        }
+        acc = acc + FrD::load_canon(&coeff[e]) * FrD::load_canon(&w[c]);
+        if (++since == 64) {
+            acc = acc.reduce();
+            since = 0;
+        }
+    }
+    acc = acc.reduce();
+    if (pos_lo | pos_hi) {
+        Fr v = Fr::zero();
+        v.l[0] = (uint32_t)pos_lo; v.l[1] = (uint32_t)(pos_lo >> 32);
+        v.l[2] = (uint32_t)pos_hi; v.l[3] = (uint32_t)(pos_hi >> 32);
+        acc = acc + FrD::to_mont(FrD::load_canon(&v));
+    }
+    if (neg_lo | neg_hi) {
+        Fr v = Fr::zero();
+        v.l[0] = (uint32_t)neg_lo; v.l[1] = (uint32_t)(neg_lo >> 32);
+        v.l[2] = (uint32_t)neg_hi; v.l[3] = (uint32_t)(neg_hi >> 32);
+        acc = FrD::sub<2>(acc, FrD::to_mont(FrD::load_canon(&v)));
+    }
+    acc = acc.reduce();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {   // field sum over the wave
+        FrD o;
+#pragma unroll
+        for (int q = 0; q < 9; q++) o.l[q] = __shfl_down(acc.l[q], d);
+#ifdef ZG_FD_DEBUG
+        o.ub = acc.ub; o.lm = acc.lm;
+#endif
+        acc = (acc + o).reduce();
+    }
+    if (lane == 0) {
+        // the tiled kernel's destination: row = (ta, mid, tb) -> (ta, bitrev(mid), tb) with ta / tb swapped and reversed
+        const uint32_t ta = (uint32_t)(row >> (log_m - 4)), tb = (uint32_t)(row & 15);
+        const uint32_t mid = (uint32_t)((row >> 4) & (((uint64_t)1 << (log_m - 8)) - 1));
+        const uint32_t rmid = log_m > 8 ? (__brev(mid) >> (32 - (log_m - 8))) : 0u;
+        const uint64_t dst = ((uint64_t)rev4(tb) << (log_m - 4)) | ((uint64_t)rmid << 4) | rev4(ta);
+        acc.store(&out[dst]);
+    }
 }
 
 int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d_coeff, const Fr* d_x, uint64_t n_rows,
@@ -768,6 +845,16 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
                                r->coeff[k].as<Fr>(), (size_t)nnz, r->ccls[k].as<uint8_t>());
         }
     }
+    std::vector<uint32_t> long_rows[3];   // (alive until the synchronize below)
+    for (int k = 0; k < 3; k++) {
+        for (uint64_t i = 0; i < n_constraints; i++)
+            if (row_ptr[k][i + 1] - row_ptr[k][i] > R1CS_LONG_ROW) long_rows[k].push_back((uint32_t)i);
+        r->n_long[k] = (uint32_t)long_rows[k].size();
+        if (r->n_long[k]) {
+            ZG_HIP(ctx, r->long_rows[k].alloc(long_rows[k].size() * 4));
+            ZG_HIP(ctx, hipMemcpyAsync(r->long_rows[k].p, long_rows[k].data(), long_rows[k].size() * 4, hipMemcpyHostToDevice, st));
+        }
+    }
     ZG_HIP(ctx, hipStreamSynchronize(st));
     ZG_HIP(ctx, hipGetLastError());
     *out = r.release();
@@ -856,6 +943,12 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
             hipLaunchKernelGGL(k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
                                r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
                                ws.wcls.as<uint8_t>(), r->n_constraints, d_abc[k], (int)r->log_m);
+        for (int k = 0; k < 3; k++)
+            if (r->n_long[k])
+                hipLaunchKernelGGL(k_r1cs_eval_long, dim3((r->n_long[k] + 3) / 4), dim3(256), 0, st,
+                                   r->long_rows[k].as<uint32_t>(), r->n_long[k], r->row_ptr[k].as<uint64_t>(),
+                                   r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
+                                   ws.wcls.as<uint8_t>(), d_abc[k], (int)r->log_m);
         hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
                            r->n_constraints, d_abc[0], rev_bits);
         ZG_HIP(ctx, hipGetLastError());
