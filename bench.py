@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-msm", action="store_true", help="skip the standalone G1 MSM line")
     ap.add_argument("--msm-log-n", type=int, default=26, help="standalone G1 MSM: 2^n bases in total (sharded over the ranks)")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-witness (bit fraction 0) line")
+    ap.add_argument("--no-sha", action="store_true", help="skip the SHA-256 Merkle (depth 32, real circuit) line")
     ap.add_argument("--shard-model", type=int, default=8,
                     help="N = 1 only: also time the phases one rank of a proof sharded W ways would run (0 = skip)")
     return ap.parse_args()
@@ -401,6 +402,36 @@ def main():
         ctx.free(d_h)
         Pk.close()
 
+    sha_line = None
+    if world == 1 and not args.no_sha and args.workload == "synthetic" and args.log_m >= 21 and not args.synthetic_key:
+        # BASELINE config 4 as it is named -- a depth-32 SHA-256 Merkle inclusion proof on a bit-level circuit (1.48 M
+        # constraints, 2^21 domain); root and witness checked against hashlib by the generator, proof checked by the
+        # pairing equation with that root as the public input
+        from za_amd import workloads
+        ni, na, nc, rp, cl, cf, wit, info = workloads.sha256_merkle(32)
+        rs = ctx.r1cs_load(ni, na, nc, rp, cl, cf)
+        Ps, pbytes = ctx.setup(rs, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172)
+        ws = ctx.host_alloc(len(wit))
+        ws[:] = np.frombuffer(wit, dtype=np.uint8)
+        for _ in range(2):
+            proof_s = ctx.prove(Ps, rs, ws, r_blind, s_blind)
+        torch.cuda.synchronize()
+        ns = max(3, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(ns):
+            proof_s = ctx.prove(Ps, rs, ws, r_blind, s_blind)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        root = info["root"]
+        ok = za_amd.verify(pbytes, proof_s, [int.from_bytes(root[:16], "big"), int.from_bytes(root[16:], "big")])
+        sha_line = {"depth": 32, "n_constraints": nc, "log_m": rs.log_m, "ms_per_proof": 1e3 * el / ns,
+                    "constraints_per_s": nc * ns / el, "proof_verifies_for_the_hashlib_root": bool(ok),
+                    "note": "za_amd/workloads.py::sha256_merkle (bit-level SHA-256, two compressions per level); zg_prove "
+                            "from pinned host memory; --workload sha256 --depth 90 fills the 2^22 domain"}
+        ctx.host_free(ws)
+        Ps.close(); rs.close()
+        del rp, cl, cf, wit, pbytes
+
     dense_line = None
     if world == 1 and not args.no_dense and args.workload == "synthetic" and args.bit_fraction > 0:
         # the same size with a witness of uniform field elements: no 0/1 shortcut in the R1CS evaluation, no subset-sum
@@ -522,6 +553,8 @@ def main():
             line["g1_msm"] = msm_line
         if dense_line:
             line["dense_witness"] = dense_line
+        if sha_line:
+            line["sha256_merkle"] = sha_line
         if shard_line:
             line["shard_model"] = shard_line
         if conc_line:
