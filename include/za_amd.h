@@ -216,6 +216,22 @@ int zg_prove(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const ui
 /* Same with the witness already resident in HBM (the timed form in bench.py). */
 int zg_prove_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
                  const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
+/* A witness in PACKED form, for circuits whose signals are mostly bits (a SHA-256 circuit: > 99 %; the upload of the
+ * 32-byte-per-value form is 2.3 ms of a 14 ms proof at 2^22, the packed form of the same witness is 1-6 MB).  Not a
+ * bellman interface: the glue that turns za's signal values (`FS`, prover/src/groth16/format.rs:203-218) into the
+ * array zg_prove takes can emit this form instead.
+ *   classes      2 bits per value, four values per byte, value i in bits 2*(i%4).. of byte i/4:
+ *                0 = the value 0, 1 = the value 1, 2 = any other value, 3 = invalid
+ *   other_index  the positions of the class-2 values, strictly increasing
+ *   others32     their values, canonical LE, in that order
+ * zg_witness_pack (host only) converts a witness32 array; it returns ZG_E_BUFFER_TOO_SMALL (and the needed count in
+ * *n_others) when more than `cap` values are of class 2.  zg_prove_packed = zg_prove on such a witness;
+ * ZG_E_BAD_FORMAT if the three arrays do not describe exactly one value per variable. */
+int zg_witness_pack(const uint8_t* witness32, size_t n_values, uint8_t* classes, uint32_t* other_index,
+                    uint8_t* others32, size_t cap, size_t* n_others);
+int zg_prove_packed(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const uint8_t* classes,
+                    const uint32_t* other_index, const uint8_t* others32, size_t n_others,
+                    const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* create_random_proof: r, s from the OS entropy source. */
 int zg_prove_random(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs,
                     const uint8_t* witness32, uint8_t proof_out[256]);

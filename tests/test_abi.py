@@ -218,3 +218,24 @@ def test_host_verifier_accepts_golden_proofs_and_rejects_wrong_inputs(lib_built)
         pr, _ = g.params_read(params)
         assert int(vj["alpha_g1"][0], 16) == pr.vk.alpha_g1[0].v
         assert int(vj["gamma_g2"][1][1], 16) == pr.vk.gamma_g2[1].c1
+
+
+def test_witness_pack_is_a_host_function(lib_built):
+    """zg_witness_pack needs no GPU: 2 bits per value (0 / 1 / other), the other values listed with their positions;
+    ZG_E_BUFFER_TOO_SMALL reports the needed capacity."""
+    import ctypes as C
+    import numpy as np
+    import za_amd
+    vals = [1, 0, 1, 5, 0, (1 << 200) + 3, 1, 1, 0, 2]
+    w = b"".join(v.to_bytes(32, "little") for v in vals)
+    cls, idx, others = za_amd.pack_witness(w)
+    assert [(cls[i >> 2] >> (2 * (i & 3))) & 3 for i in range(len(vals))] == [1, 0, 1, 2, 0, 2, 1, 1, 0, 2]
+    assert idx.tolist() == [3, 5, 9]
+    assert [int.from_bytes(bytes(others[32 * j:32 * j + 32]), "little") for j in range(3)] == [5, (1 << 200) + 3, 2]
+    lib = za_amd.load_library()
+    k = C.c_size_t()
+    wa = np.frombuffer(w, dtype=np.uint8)
+    c2 = np.zeros(3, dtype=np.uint8); i2 = np.zeros(1, dtype=np.uint32); v2 = np.zeros(32, dtype=np.uint8)
+    rc = lib.zg_witness_pack(wa.ctypes.data_as(C.c_void_p), C.c_size_t(len(vals)), c2.ctypes.data_as(C.c_void_p),
+                             i2.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p), C.c_size_t(1), C.byref(k))
+    assert rc == 23 and k.value == 3

@@ -731,3 +731,38 @@ def test_long_rows_take_the_wave_per_row_evaluator(ctx):
     P, _ = ctx.setup(R, 21, 22, 23, 24, 25, want_bytes=False)
     assert ctx.prove(P, R, wb, 8, 9) == co.prove(download_params(ctx, P), csr, wb, 8, 9, threads=4)
     P.close(); R.close()
+
+
+def test_prove_packed_equals_prove(ctx):
+    """zg_prove_packed (2-bit classes + the listed other values) against zg_prove on the same witnesses: a golden
+    fixture, a 97 %-bit synthetic circuit, a witness without a single bit, and the malformed-input refusals."""
+    import za_amd
+    from za_amd import synth
+    fx = golden("proof_chain7.json")
+    R, P, w, _ = _load_fixture(ctx, fx)
+    pk = za_amd.pack_witness(w)
+    assert ctx.prove_packed(P, R, pk, int(fx["r"], 16), int(fx["s"], 16)).hex() == fx["proof"]
+    for bitf, lg in ((0.97, 13), (0.0, 10), (1.0, 11)):
+        sr = synth.SynthR1CS(lg, 3, bitf, 99 + lg)
+        Rs = sr.load(ctx)
+        m = 1 << lg
+        Ps = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + Rs.a_aux_total, Rs.b_input_total + Rs.b_aux_total, 7)
+        packed = za_amd.pack_witness(sr.witness)
+        nv = sr.n_inputs + sr.n_aux
+        assert packed[0].size == (nv + 3) // 4 and packed[2].size == 32 * packed[1].size
+        assert ctx.prove_packed(Ps, Rs, packed, 3, 4) == ctx.prove(Ps, Rs, sr.witness, 3, 4)
+        if bitf == 0.97:
+            cls, idx, vals = [a.copy() for a in packed]
+            bad = cls.copy(); bad[5] |= 0x0C                                  # class 3
+            with pytest.raises(za_amd.ZaAmdError) as e:
+                ctx.prove_packed(Ps, Rs, (bad, idx, vals), 3, 4)
+            assert e.value.code == 20
+            with pytest.raises(za_amd.ZaAmdError):                             # one listed value too few
+                ctx.prove_packed(Ps, Rs, (cls, idx[:-1], vals[:-32]), 3, 4)
+            sw = idx.copy(); sw[[0, 1]] = sw[[1, 0]]                           # not increasing
+            with pytest.raises(za_amd.ZaAmdError):
+                ctx.prove_packed(Ps, Rs, (cls, sw, vals), 3, 4)
+            notone = cls.copy(); notone[0] &= 0xFC                             # variable 0 = 0
+            with pytest.raises(za_amd.ZaAmdError):
+                ctx.prove_packed(Ps, Rs, (notone, idx, vals), 3, 4)
+        Ps.close(); Rs.close(); sr.close()

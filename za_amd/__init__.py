@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "zg_r1cs_load", "zg_r1cs_free", "zg_r1cs_info", "zg_r1cs_eval",
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
-    "zg_prove", "zg_prove_dev", "zg_prove_random",
+    "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
     "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
@@ -326,6 +326,17 @@ class Context:
         self._check(self.lib.zg_prove(self.h, params.h, r1cs.h, _ptr(w), _ptr(rb), _ptr(sb), _ptr(out)))
         return out.tobytes()
 
+    def prove_packed(self, params, r1cs, packed, r, s):
+        """zg_prove_packed; `packed` = pack_witness(...) (its arrays may live in pinned memory: host_alloc)."""
+        classes, idx, vals = packed
+        proof = np.zeros(256, dtype=np.uint8)
+        n_others = int(idx.size)
+        self._check(self.lib.zg_prove_packed(self.h, params.h, r1cs.h, _ptr(classes), _ptr(idx) if n_others else None,
+                                             _ptr(vals) if n_others else None, C.c_size_t(n_others),
+                                             _ptr(_u8(int(r).to_bytes(32, "little"))), _ptr(_u8(int(s).to_bytes(32, "little"))),
+                                             _ptr(proof)))
+        return proof.tobytes()
+
     def prove_dev(self, params, r1cs, d_witness, r, s):
         out = np.zeros(256, dtype=np.uint8)
         rb, sb = _u8(int(r).to_bytes(32, "little")), _u8(int(s).to_bytes(32, "little"))
@@ -463,6 +474,25 @@ class Params:
         if self.h:
             self.ctx.lib.zg_params_free(self.h)
             self.h = None
+
+
+def pack_witness(witness):
+    """zg_witness_pack: (classes u8[(n+3)//4], other_index u32[k], others u8[32 k]) of a 32-byte-per-value witness."""
+    lib = load_library()
+    w = _u8(witness)
+    n = w.size // 32
+    classes = np.zeros((n + 3) // 4, dtype=np.uint8)
+    k = C.c_size_t()
+    rc = lib.zg_witness_pack(_ptr(w), C.c_size_t(n), _ptr(classes), None, None, C.c_size_t(0), C.byref(k))
+    if rc not in (0, 23):
+        raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    idx = np.zeros(max(k.value, 1), dtype=np.uint32)
+    vals = np.zeros(max(k.value, 1) * 32, dtype=np.uint8)
+    if k.value:
+        rc = lib.zg_witness_pack(_ptr(w), C.c_size_t(n), _ptr(classes), _ptr(idx), _ptr(vals), C.c_size_t(k.value), C.byref(k))
+        if rc:
+            raise ZaAmdError(rc, lib.zg_strerror(rc).decode())
+    return classes, idx[:k.value], vals[:32 * k.value]
 
 
 def pk_params_offset(pk_bytes):

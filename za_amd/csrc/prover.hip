@@ -99,6 +99,22 @@ __global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ 
     cls[i] = (hi == 0 && v.l[0] <= 1) ? (uint8_t)v.l[0] : (uint8_t)2;
 }
 
+// zg_prove_packed: classes -> 32-byte values (class 2 positions are filled by k_unpack_others)
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t* __restrict__ packed, size_t n, Fr* __restrict__ w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = (packed[i >> 2] >> (2 * (i & 3))) & 3u;
+    Fr v = Fr::zero();
+    v.l[0] = c == 1 ? 1u : 0u;
+    w[i] = v;
+}
+__global__ void __launch_bounds__(256) k_unpack_others(const uint32_t* __restrict__ idx, const Fr* __restrict__ vals, size_t n,
+                                                       Fr* __restrict__ w) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    w[idx[j]] = vals[j];
+}
+
 // out[row] = sum_e coeff[e] * w[col[e]]  for one CSR matrix; one thread per row
 __global__ void __launch_bounds__(256) k_r1cs_eval(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                    const Fr* __restrict__ coeff, const Fr* __restrict__ w,
@@ -141,6 +157,7 @@ __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, co
 
 struct ProveWs {
     DevBuf abc[3], h, wcls, w;
+    DevBuf pk_cls, pk_idx, pk_val;   // zg_prove_packed: the packed witness as uploaded
     // wcls: one class byte per witness value (k_witness_classes), shared by the evaluator and the witness multiexps.
     // wcls_for: the witness it was computed from; wcls_fresh: computed inside the current API call (the evaluator
     // takes it as is); wcls_armed: a proof is in flight whose multiexps may use it (zg_prove_dev, or
@@ -1536,6 +1553,90 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
     int rc = zg_prove_dev(ctx, p, r, dw.p, r_le, s_le, proof_out);
     ctx->timings[0] = (double)(nv * 32);   // bytes uploaded (the copy is not timed separately: it is in [5])
+    ctx->timings[5] = now_ms() - t0;
+    return rc;
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+
+// ---- packed witness (see include/za_amd.h)
+extern "C" int zg_witness_pack(const uint8_t* witness32, size_t n, uint8_t* classes, uint32_t* other_index,
+                               uint8_t* others32, size_t cap, size_t* n_others) try {
+    if (!witness32 || !classes || !n_others || (cap && (!other_index || !others32))) return ZG_E_INVALID_ARG;
+    if (n >= ((size_t)1 << 32)) return ZG_E_INVALID_ARG;
+    memset(classes, 0, (n + 3) / 4);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* v = witness32 + 32 * i;
+        uint64_t q[4];
+        memcpy(q, v, 32);
+        uint32_t c = 2;
+        if ((q[1] | q[2] | q[3]) == 0 && q[0] <= 1) c = (uint32_t)q[0];
+        if (c == 2) {
+            if (k < cap) {
+                other_index[k] = (uint32_t)i;
+                memcpy(others32 + 32 * k, v, 32);
+            }
+            k++;
+        }
+        classes[i >> 2] |= (uint8_t)(c << (2 * (i & 3)));
+    }
+    *n_others = k;
+    return k > cap ? ZG_E_BUFFER_TOO_SMALL : ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
+
+extern "C" int zg_prove_packed(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* classes,
+                               const uint32_t* other_index, const uint8_t* others32, size_t n_others,
+                               const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
+    if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
+    if (!classes || (n_others && (!other_index || !others32))) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "packed witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    double t0 = now_ms();
+    const size_t nv = (size_t)r->n_inputs + r->n_aux;
+    {   // the packed form must describe exactly one value per variable: class 3 does not exist, the class-2 positions
+        // are the listed ones (strictly increasing), and variable 0 is ONE
+        size_t twos = 0;
+        const size_t nbytes = (nv + 3) / 4;
+        auto word = [&](size_t b0, size_t len) {   // up to 8 class bytes as one integer, padding bits cleared
+            uint64_t x = 0;
+            memcpy(&x, classes + b0, len);
+            if (b0 + len == nbytes && (nv & 3)) x &= ~(~(uint64_t)0 << (8 * (len - 1) + 2 * (nv & 3)));
+            return x;
+        };
+        for (size_t b = 0; b < nbytes; b += 8) {
+            const uint64_t x = word(b, std::min<size_t>(8, nbytes - b));
+            if (x & (x >> 1) & 0x5555555555555555ull)
+                return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: class 3 among the values %zu..%zu", 4 * b, 4 * b + 31);
+            twos += (size_t)__builtin_popcountll(x & 0xAAAAAAAAAAAAAAAAull);
+        }
+        if (twos != n_others)
+            return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: %zu values of class 2 but %zu listed", twos, n_others);
+        for (size_t j = 0; j < n_others; j++) {
+            const uint32_t i = other_index[j];
+            if (i >= nv || ((classes[i >> 2] >> (2 * (i & 3))) & 3u) != 2u || (j && other_index[j - 1] >= i))
+                return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: other_index[%zu] = %u is not the next class-2 position", j, i);
+        }
+        if ((classes[0] & 3u) != 1u) return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: variable 0 must be ONE");
+    }
+    ProveWs& ws = prove_ws(ctx);
+    ZG_HIP(ctx, ws.w.reserve(nv * 32));
+    ZG_HIP(ctx, ws.pk_cls.reserve((nv + 3) / 4));
+    ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (nv + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), nv,
+                       ws.w.as<Fr>());
+    if (n_others) {
+        ZG_HIP(ctx, ws.pk_idx.reserve(n_others * 4));
+        ZG_HIP(ctx, ws.pk_val.reserve(n_others * 32));
+        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_idx.p, other_index, n_others * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_val.p, others32, n_others * 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_unpack_others, dim3((unsigned)((n_others + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ws.pk_idx.as<uint32_t>(), ws.pk_val.as<Fr>(), n_others, ws.w.as<Fr>());
+    }
+    ZG_HIP(ctx, hipGetLastError());
+    int rc = zg_prove_dev(ctx, p, r, ws.w.p, r_le, s_le, proof_out);
+    ctx->timings[0] = (double)((nv + 3) / 4 + n_others * 36);   // bytes uploaded
     ctx->timings[5] = now_ms() - t0;
     return rc;
 } catch (...) {
