@@ -110,3 +110,24 @@ def test_g1_msm_2p26_points_discrete_log_identity(ctx):
     # the per-call entry point (ABI-form bases converted on every call, per-window schedule)
     assert ctx.msm_g1_dev(d_b, d_s, n)[:64] == want
     ctx.free(d_b); ctx.free(d_s)
+
+
+def test_config4_on_its_own_circuit_sha256_merkle_depth_32(ctx):
+    """BASELINE config 4 as named: a depth-32 SHA-256 Merkle inclusion proof on the bit-level circuit of
+    za_amd/workloads.py (1.48 M constraints, 2^21 domain; root and witness asserted against hashlib by the generator).
+    zg_prove, zg_prove_packed and the C oracle give the same bytes; the pairing check takes the hashlib root."""
+    import za_amd
+    from za_amd import workloads
+    ni, na, nc, rp, col, cf, wit, info = workloads.sha256_merkle(32)
+    R = ctx.r1cs_load(ni, na, nc, rp, col, cf)
+    assert R.log_m == 21 and R.check(wit) is None
+    P, pbytes = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172)
+    r, s = 0x1234567, 0x7654321
+    got = ctx.prove(P, R, wit, r, s)
+    packed = za_amd.pack_witness(wit)
+    assert packed[1].size < 200 and ctx.prove_packed(P, R, packed, r, s) == got     # everything but a few words is a bit
+    csr = co.CsrR1CS(ni, na, nc, rp, col, cf)
+    assert co.prove(download_params(ctx, P), csr, wit, r, s, threads=THREADS) == got
+    root = info["root"]
+    assert za_amd.verify(pbytes, got, [int.from_bytes(root[:16], "big"), int.from_bytes(root[16:], "big")]) is True
+    P.close(); R.close()
