@@ -285,14 +285,22 @@ def main():
     # level 1: HIP events around the accumulation kernels only (the roofline's kernel).  Timing every kernel class
     # costs 0.5 ms per proof in event records; the full breakdown comes from a few extra untimed proofs below.
     ctx.profile_enable(1)         # on during warm-up too, so the events are created outside the timed region
+    # Part of the untimed set-up, like the tables: a few proofs until the library's pools are warm (HIP events of the
+    # profiling scopes are recycled one proof late, helper threads' stacks, pinned read-back buffers) -- without them one
+    # of the first three timed steps carries ~1.5 ms of one-time work (`step_ms` shows the per-step times).
+    for _ in range(4):
+        proof = step()
     for _ in range(args.warmup):
         proof = step()
     ctx.profile_reset()
     phase_acc.clear()
     barrier()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         proof = step()
+        step_ms.append(round(1e3 * (time.perf_counter() - ts), 3))
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
@@ -566,6 +574,7 @@ def main():
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
+            "step_ms": step_ms,
             "prove_dev_ms": prove_dev_ms,
             "prove_packed": packed_line,
             "phases_ms_last_step": phases,
