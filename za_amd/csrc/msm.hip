@@ -15,10 +15,12 @@
 //                   of one bucket, so work per thread is bounded for any scalar distribution)
 //   3. k_item_*     items ordered by length (counting sort, longest first): the 64 lanes of a wave run equal loops
 //   4. k_accumulate one thread per item: gather affine bases (dwordx4 loads), XYZZ mixed adds   [dominant]
-//   5. k_bits_level / k_rowsum   bucket reduction by bit planes: per window S = sum of buckets and
-//                   T_j = sum of the buckets with index bit j set; plain sums only, two dependent adds per level
-//   6. k_rowsum     also sums the partial sums of the "ones" bucket
-//   7. host: one Horner pass over the 254 bit positions (window value = S + sum_j 2^j T_j) + the ones sum.
+//   5. k_heavy_fold, k_bits_level   bucket reduction by bit planes: per window S = sum of buckets and T_j = sum of
+//                   the buckets with index bit j set; plain sums only, two lanes per group, two dependent adds per
+//                   level; a level also folds the bit-plane rows of the levels before it
+//   6. k_rowsum     sums the partial sums of the "ones" bucket
+//   7. host: one Horner pass over the 254 bit positions (window value = S + sum_j 2^j T_j) + the ones sum, on a
+//                   helper thread while other jobs are in flight.
 // Bases live in HBM in the device field's M261 form (fd.h); field work uses the lazy 9x29-limb arithmetic.
 // Algorithmic HBM bytes: 64 B base + 32 B scalar per point (G1), 128 + 32 (G2).  The kernel is
 // integer-ALU bound (about 10 field multiplications per point per window), not HBM bound.
@@ -40,7 +42,7 @@ static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (upper limit; see item_sizes)
 
 struct MsmScratch {
-    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], dbuf[2], ones[2], bsum, meta, heavy;
+    DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], ones[2], bsum, meta, heavy;
     static constexpr size_t HOST_BYTES = 256 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
