@@ -131,7 +131,8 @@ def acc_roofline(prof, traffic=None, ipm=None):
         return None
     achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy_ceiling": achieved / 6290.0, "traffic": traffic,
             "launches": acc_n, "avg_launch_ms": acc_ms / acc_n, "algorithmic_bytes_per_launch": acc_bytes / acc_n}
     # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
@@ -574,7 +575,13 @@ def main():
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
-            "step_ms": step_ms,
+            "step_ms": step_ms, "ms_median": float(np.median(step_ms)) if step_ms else None,
+            # a time without the R1CS evaluation, and the whole proof against the HBM roofline with the
+            # survey's algorithmic bytes 96(m-1) + 96 v + 96(l + d_A) + (96 + 160) d_B + 7 * 64 m
+            "prove_core_ms": (ms_per_step - phases["r1cs_eval_ms"]) if world == 1 and phases.get("r1cs_eval_ms") else None,
+            "prove_hbm": (lambda b: {"algorithmic_bytes": b, "achieved": b / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                                     "frac": b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS})(
+                96 * (m - 1) + 96 * n_aux + 96 * n_a + 256 * n_b + 448 * m),
             "prove_dev_ms": prove_dev_ms,
             "prove_packed": packed_line,
             "phases_ms_last_step": phases,
