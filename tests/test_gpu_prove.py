@@ -388,9 +388,10 @@ def test_witness_of_all_zero_aux_and_of_all_ones(ctx):
         assert ctx.prove(P, R, co.witness_bytes(w), 3, 4) == g.proof_bytes(exp)
 
 
-@pytest.mark.parametrize("lg", [12, 15, 20])
+@pytest.mark.parametrize("lg", [12, 14, 15, 20])
 def test_poseidon_chain_circuit_setup_prove_verify(ctx, lg):
-    """BASELINE config 3 (circomlib Poseidon t=6 chain up to 2^20 rows: dense 6-term mix rows, no bit signals, so every
+    """BASELINE config 2's size (2^14: the EdDSA-Poseidon verifier is substituted by a Poseidon chain of equal size, as
+    SURVEY 8(d) allows) and config 3 (circomlib Poseidon t=6 chain up to 2^20 rows: dense 6-term mix rows, no bit signals, so every
     scalar takes the full-width Pippenger path): GPU set-up, GPU proof equal to the C oracle's bytes with the same
     key, host pairing check on the public hash."""
     import za_amd
