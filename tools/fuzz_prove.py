@@ -54,12 +54,18 @@ while time.time() - t0 < budget:
     r, s = rng.randrange(1, 1 << 250), rng.randrange(1, 1 << 250)
     d_w = ctx.upload(sr.witness)
     P.prepare(R, d_w)
-    got = ctx.prove_dev(P, R, d_w, r, s)
+    entry = rng.choice(["dev", "dev", "host", "packed"])
+    if entry == "dev":
+        got = ctx.prove_dev(P, R, d_w, r, s)
+    elif entry == "host":
+        got = ctx.prove(P, R, sr.witness, r, s)
+    else:
+        got = ctx.prove_packed(P, R, za_amd.pack_witness(sr.witness), r, s)
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
     exp = co.prove(download_params(ctx, P), csr, sr.witness, r, s, threads=32)
     kinds = [P.table_info(k)[0] for k in range(5)]
     ok = bytes(got) == bytes(exp)
-    print("lg %2d bits %.2f inputs %d FBW %-2s parts %s tables %s -> %s" % (lg, bf, n_in, os.environ["ZA_AMD_FBW"], os.environ["ZA_AMD_H_PARTS"], kinds, "ok" if ok else "MISMATCH"), flush=True)
+    print("lg %2d bits %.2f inputs %d FBW %-2s parts %s tables %s entry %-6s -> %s" % (lg, bf, n_in, os.environ["ZA_AMD_FBW"], os.environ["ZA_AMD_H_PARTS"], kinds, entry, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)
     n_ok += 1
