@@ -41,12 +41,13 @@ def parse():
                     help="extra line: throughput with this many concurrent provers on the GPU (1 = skip); the headline "
                          "value is always one proof at a time")
     ap.add_argument("--log-m", type=int, default=22, help="domain size: n_constraints + n_inputs = 2^log_m")
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "poseidon", "sha256"],
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "poseidon", "sha256", "eddsa"],
                     help="synthetic = config-4-shaped random R1CS (the headline); poseidon = circomlib Poseidon(t=6) hash "
                          "chain padded to 2^log_m (BASELINE config 3: use --log-m 20), generated in Python (~15 s at 2^20); "
                          "sha256 = bit-level SHA-256 Merkle inclusion of --depth levels (BASELINE config 4 on a real "
                          "circuit: depth 32 is 1.48 M constraints in a 2^21 domain, depth 90 fills 2^22); --log-m is "
-                         "then derived from the circuit")
+                         "then derived from the circuit; eddsa = one EdDSA-Poseidon signature verification on Baby Jubjub "
+                         "(BASELINE config 2's statement, 7.5 k constraints, the reference's signature as witness)")
     ap.add_argument("--depth", type=int, default=32, help="--workload sha256: levels of the Merkle path")
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5A)
@@ -218,6 +219,24 @@ def main():
         del cons, wit, rp, cl, cf
         if args.synthetic_key or world > 1:
             print("--workload poseidon runs on one GPU with a key from zg_setup", file=sys.stderr)
+            sys.exit(2)
+    elif args.workload == "eddsa":
+        from za_amd import workloads
+
+        class _W:
+            pass
+        sr = _W()
+        sr.n_inputs, sr.n_aux, cons, wit = workloads.eddsa_poseidon_verifier()
+        sr.n_constraints = len(cons)
+        rp, cl, cf = workloads.csr_arrays(cons)
+        sr.nnz = [len(c) for c in cl]
+        sr.witness = workloads.witness_bytes(wit)
+        sr.close = lambda: None
+        r1 = ctx.r1cs_load(sr.n_inputs, sr.n_aux, sr.n_constraints, rp, cl, cf)
+        args.log_m = r1.log_m
+        del cons, wit, rp, cl, cf
+        if args.synthetic_key or world > 1:
+            print("--workload eddsa runs on one GPU with a key from zg_setup", file=sys.stderr)
             sys.exit(2)
     elif args.workload == "sha256":
         from za_amd import workloads
@@ -565,6 +584,9 @@ def main():
                                     "= 2 public inputs; witness and root checked against hashlib), config 4 on a real "
                                     "circuit, domain 2^%d, proving key from zg_setup" % (args.depth, args.log_m))
                                    if args.workload == "sha256" else
+                                   ("EdDSA-Poseidon signature verification on Baby Jubjub (config 2's statement, circomlib "
+                                    "parameters, the reference's test signature as witness), domain 2^%d, proving key "
+                                    "from zg_setup" % args.log_m) if args.workload == "eddsa" else
                                    "synthetic R1CS, config 4 shape (SHA256-Merkle-like: %.0f%% bit witness, SplitMix64 "
                                    "seed 0x%x), n_constraints + n_inputs = 2^%d, %s"
                                    % (100 * args.bit_fraction, args.seed, args.log_m,

@@ -390,8 +390,8 @@ def test_witness_of_all_zero_aux_and_of_all_ones(ctx):
 
 @pytest.mark.parametrize("lg", [12, 14, 15, 20])
 def test_poseidon_chain_circuit_setup_prove_verify(ctx, lg):
-    """BASELINE config 2's size (2^14: the EdDSA-Poseidon verifier is substituted by a Poseidon chain of equal size, as
-    SURVEY 8(d) allows) and config 3 (circomlib Poseidon t=6 chain up to 2^20 rows: dense 6-term mix rows, no bit signals, so every
+    """BASELINE config 2's nominal size (2^14; the EdDSA-Poseidon statement itself is
+    test_eddsa_poseidon_verifier_circuit_setup_prove_verify) and config 3 (circomlib Poseidon t=6 chain up to 2^20 rows: dense 6-term mix rows, no bit signals, so every
     scalar takes the full-width Pippenger path): GPU set-up, GPU proof equal to the C oracle's bytes with the same
     key, host pairing check on the public hash."""
     import za_amd
@@ -767,3 +767,24 @@ def test_prove_packed_equals_prove(ctx):
             with pytest.raises(za_amd.ZaAmdError):
                 ctx.prove_packed(Ps, Rs, (notone, idx, vals), 3, 4)
         Ps.close(); Rs.close(); sr.close()
+
+
+def test_eddsa_poseidon_verifier_circuit_setup_prove_verify(ctx):
+    """BASELINE config 2 on its own statement (za_amd/workloads.py::eddsa_poseidon_verifier: 7.5 k constraints, witness =
+    the reference's signature): GPU set-up, GPU proof equal to the C oracle's bytes, pairing check with (Ax, Ay, M) as
+    public inputs and rejection of another message."""
+    import za_amd
+    from za_amd import workloads
+    ni, na, cons, w = workloads.eddsa_poseidon_verifier()
+    rp, cl, cf = workloads.csr_arrays(cons)
+    R = ctx.r1cs_load(ni, na, len(cons), rp, cl, cf)
+    wb = workloads.witness_bytes(w)
+    assert R.check(wb) is None and R.log_m == 13
+    P, pbytes = ctx.setup(R, 0xA1, 0xB2, 0xC3, 0xD4, 0xE5)
+    got = ctx.prove(P, R, wb, 0x1234567, 0x7654321)
+    csr = co.CsrR1CS(ni, na, len(cons), rp, cl, cf)
+    assert co.prove(download_params(ctx, P), csr, wb, 0x1234567, 0x7654321, threads=8) == got
+    kat = workloads.EDDSA_KAT
+    assert za_amd.verify(pbytes, got, [kat["Ax"], kat["Ay"], kat["M"]]) is True
+    assert za_amd.verify(pbytes, got, [kat["Ax"], kat["Ay"], kat["M"] + 1]) is False
+    P.close(); R.close()

@@ -45,3 +45,29 @@ def test_sha256_merkle_wrong_witness_breaks_a_row():
     bad[32 * (ni + 5)] ^= 1          # flip one private leaf bit
     ok, _ = _rows_satisfied(ni, na, nc, rp, col, cf, bytes(bad))
     assert not ok
+
+
+def test_eddsa_poseidon_verifier_circuit_takes_the_reference_signature():
+    """BASELINE config 2's family: the statement of circomlib's EdDSAPoseidonVerifier with this repo's gadgets.  The
+    witness is the signature the reference's own test uses (interop/circuits/circomlib/za_test/eddsaposeidon.za:7-12):
+    it must satisfy every row, a changed message must not, and a plain Baby Jubjub computation agrees."""
+    kat = W.EDDSA_KAT
+    A, R8 = (kat["Ax"], kat["Ay"]), (kat["R8x"], kat["R8y"])
+    h = W.poseidon_hash([R8[0], R8[1], A[0], A[1], kat["M"]])
+    assert W.babyjub_mul(kat["S"], W._BJ_B8) == W.babyjub_add(R8, W.babyjub_mul(h, W.babyjub_mul(8, A)))
+    ni, na, cons, w = W.eddsa_poseidon_verifier()
+    assert ni == 4 and w[:4] == [1, kat["Ax"], kat["Ay"], kat["M"]] and 7000 < len(cons) < 8192
+
+    def val(lc, ww):
+        return sum(c * ww[v] for v, c in lc) % W.R
+    assert all(val(a, w) * val(b, w) % W.R == val(c, w) for a, b, c in cons)
+    used = {v for con in cons for lc in con for v, _ in lc}
+    assert used == set(range(ni + na))
+    for field, delta in (("M", 1), ("S", 1), ("R8x", 0)):
+        sig = dict(kat)
+        if delta:
+            sig[field] += delta
+        else:
+            sig["R8x"], sig["R8y"] = W.babyjub_add(R8, W._BJ_B8)      # another point on the curve
+        _, _, cons2, w2 = W.eddsa_poseidon_verifier(sig)
+        assert not all(val(a, w2) * val(b, w2) % W.R == val(c, w2) for a, b, c in cons2), field

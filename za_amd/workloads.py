@@ -418,3 +418,176 @@ def sha256_merkle(depth, seed=1):
     wit = b"".join(int(v).to_bytes(32, "little") for v in values)
     info = {"root": cur_bytes, "leaf": leaf, "siblings": sibs, "directions": dirs, "nnz": [int(len(c)) for c in col]}
     return 3, n_aux, B.n_rows, row_ptr, col, coeff, wit, info
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# EdDSA-Poseidon signature verification on Baby Jubjub = BASELINE.json config 2's family (circomlib's
+# EdDSAPoseidonVerifier, interop/circuits/circomlib/circuits/eddsaposeidon.circom): checks  S * B8 == R8 + h * (8 A)  with
+# h = Poseidon(R8x, R8y, Ax, Ay, M), S < the subgroup order.  The statement and the curve / hash parameters are the
+# reference's (babyjub.circom: a = 168700, d = 168696; the base point B8 of eddsaposeidon.circom:104-107; Poseidon(5, 6,
+# 8, 57)); the gadgets are this file's own (a bit-by-bit double-and-add instead of circomlib's windowed Montgomery
+# ladders), so the constraint count (~7.5 k) is of the reference circuit's order, not equal to it.  The witness is the
+# reference's own signature (interop/circuits/circomlib/za_test/eddsaposeidon.za:7-12).
+_BJ_A, _BJ_D = 168700, 168696
+_BJ_B8 = (5299619240641551281634865583518297030282874472190772894086521144482721001553,
+          16950150798460657717958625567821834550301663161624707787222815936182638968203)
+_BJ_SUBORDER = 2736030358979909402780800718157159386076813972158567259200215660948447373041
+EDDSA_KAT = {   # za_test/eddsaposeidon.za
+    "Ax": 13277427435165878497778222415993513565335242147425444199013288855685581939618,
+    "Ay": 13622229784656158136036771217484571176836296686641868549125388198837476602820,
+    "R8x": 11220723668893468001994760120794694848178115379170651044669708829805665054484,
+    "R8y": 2367470421002446880004241260470975644531657398480773647535134774673409612366,
+    "S": 1307100909096544936550139783786226891472336052773077686618468233418583414320,
+    "M": 1234,
+}
+
+
+def babyjub_add(P, Q):
+    x1, y1 = P
+    x2, y2 = Q
+    t = _BJ_D * x1 * x2 * y1 * y2 % R
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, R) % R, (y1 * y2 - _BJ_A * x1 * x2) * pow(1 - t, -1, R) % R)
+
+
+def babyjub_mul(k, P):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = babyjub_add(acc, P)
+        P = babyjub_add(P, P)
+        k >>= 1
+    return acc
+
+
+def eddsa_poseidon_verifier(sig=None):
+    """R1CS + witness of one EdDSA-Poseidon verification.  Public inputs: Ax, Ay, M; private: R8x, R8y, S.
+    Returns (n_inputs, n_aux, constraints, witness) in poseidon_chain's form (a constraint = (A, B, C), each a list of
+    (variable, coefficient))."""
+    sig = dict(EDDSA_KAT if sig is None else sig)
+    C, Mx, t = poseidon_constants(), poseidon_matrix(), _POS_T
+    w = [1, sig["Ax"] % R, sig["Ay"] % R, sig["M"] % R]
+    n_inputs = 4
+    ONE, AX, AY, MSG = 0, 1, 2, 3
+    cons = []
+
+    def new(v):
+        w.append(v % R)
+        return len(w) - 1
+
+    def val(lc):
+        return sum(c * w[v] for v, c in lc) % R
+
+    def mul(a, b):                     # new wire = <a, w> * <b, w>
+        o = new(val(a) * val(b))
+        cons.append((a, b, [(o, 1)]))
+        return o
+
+    def lin(lc):                       # new wire equal to a linear combination
+        o = new(val(lc))
+        cons.append((lc, [(ONE, 1)], [(o, 1)]))
+        return o
+
+    def bits_of(var, n, value):
+        bs = []
+        for i in range(n):
+            b = new((value >> i) & 1)
+            cons.append(([(b, 1)], [(b, 1), (ONE, -1)], []))          # b (b - 1) = 0
+            bs.append(b)
+        cons.append(([(b, 1 << i) for i, b in enumerate(bs)], [(ONE, 1)], [(var, 1)]))
+        return bs
+
+    def less_than_const(bs, bound):
+        """value(bs) < bound for a constant bound: walk from the top bit keeping `eq` = "all higher bits equal the
+        bound's"; where the bound has a 0 an equal prefix forbids a 1; at the end the value must not equal the bound
+        (an equal prefix over all bits is forbidden)."""
+        eq = None                                                       # None = the constant 1
+        for i in reversed(range(len(bs))):
+            cb = (bound >> i) & 1
+            b = bs[i]
+            if cb == 0:
+                if eq is None:
+                    cons.append(([(b, 1)], [(ONE, 1)], []))             # b = 0
+                else:
+                    cons.append(([(eq, 1)], [(b, 1)], []))              # eq * b = 0
+                    # eq stays eq * (1 - b) = eq (since eq * b = 0)
+            else:
+                eq = b if eq is None else mul([(eq, 1)], [(b, 1)])      # eq' = eq * b
+        if eq is None:
+            cons.append(([(ONE, 1)], [(ONE, 1)], []))                   # bound = 0: unsatisfiable
+        else:
+            cons.append(([(eq, 1)], [(ONE, 1)], []))                    # not all bits equal: value != bound
+
+    def point_add(x1, y1, x2, y2):
+        """Twisted Edwards addition (babyjub.circom's BabyAdd: 6 rows)."""
+        beta = mul([(x1, 1)], [(y2, 1)])
+        gamma = mul([(y1, 1)], [(x2, 1)])
+        delta = mul([(x1, -_BJ_A), (y1, 1)], [(x2, 1), (y2, 1)])
+        tau = mul([(beta, 1)], [(gamma, 1)])
+        x3v = (w[beta] + w[gamma]) * pow(1 + _BJ_D * w[tau], -1, R)
+        x3 = new(x3v)
+        cons.append(([(ONE, 1), (tau, _BJ_D)], [(x3, 1)], [(beta, 1), (gamma, 1)]))
+        y3v = (w[delta] + _BJ_A * w[beta] - w[gamma]) * pow(1 - _BJ_D * w[tau], -1, R)
+        y3 = new(y3v)
+        cons.append(([(ONE, 1), (tau, -_BJ_D)], [(y3, 1)], [(delta, 1), (beta, _BJ_A), (gamma, -1)]))
+        return x3, y3
+
+    def select(bit, x_if1, y_if1, x_if0, y_if0):
+        xs = new(w[x_if1] if w[bit] else w[x_if0])
+        cons.append(([(bit, 1)], [(x_if1, 1), (x_if0, -1)], [(xs, 1), (x_if0, -1)]))
+        ys = new(w[y_if1] if w[bit] else w[y_if0])
+        cons.append(([(bit, 1)], [(y_if1, 1), (y_if0, -1)], [(ys, 1), (y_if0, -1)]))
+        return xs, ys
+
+    r8x, r8y, s_var = new(sig["R8x"]), new(sig["R8y"]), new(sig["S"])
+    # S < subgroup order
+    s_bits = bits_of(s_var, 253, sig["S"])
+    less_than_const(s_bits, _BJ_SUBORDER)
+    # h = Poseidon(R8x, R8y, Ax, Ay, M)
+    st = [r8x, r8y, AX, AY, MSG, None]
+    for i in range(_POS_RF + _POS_RP):
+        st = [lin([(ONE, C[i])] + ([(v, 1)] if v is not None else [])) for v in st]
+        full = i < _POS_RF // 2 or i >= _POS_RF // 2 + _POS_RP
+        for k in range(t if full else 1):
+            x = st[k]
+            x2 = mul([(x, 1)], [(x, 1)])
+            x4 = mul([(x2, 1)], [(x2, 1)])
+            st[k] = mul([(x4, 1)], [(x, 1)])
+        st = [lin([(st[b], Mx[a_][b]) for b in range(t)]) for a_ in range(t)]
+    h_var = st[0]
+    h_val = w[h_var]
+    h_bits = bits_of(h_var, 254, h_val)
+    less_than_const(h_bits, R)                                          # the strict decomposition: h's bits < r
+    # 8 A (three doublings), nonzero x
+    ax8, ay8 = AX, AY
+    for _ in range(3):
+        ax8, ay8 = point_add(ax8, ay8, ax8, ay8)
+    inv = new(pow(w[ax8], -1, R) if w[ax8] else 0)
+    cons.append(([(ax8, 1)], [(inv, 1)], [(ONE, 1)]))                   # x(8A) != 0
+    # right2 = h * 8A: double-and-add from the top bit, the accumulator starts at the neutral element (0, 1)
+    accx, accy = lin([]), lin([(ONE, 1)])
+    for i in reversed(range(254)):
+        accx, accy = point_add(accx, accy, accx, accy)
+        sx, sy = point_add(accx, accy, ax8, ay8)
+        accx, accy = select(h_bits[i], sx, sy, accx, accy)
+    rx, ry = point_add(r8x, r8y, accx, accy)
+    # left = S * B8 with the constant multiples 2^i B8: a conditional addition of a constant point per bit
+    lx, ly = lin([]), lin([(ONE, 1)])
+    Pi = _BJ_B8
+    for i in range(253):
+        bx, by = Pi
+        beta = lin([(lx, by)])
+        gamma = lin([(ly, bx)])
+        tau = mul([(beta, 1)], [(gamma, 1)])
+        delta_v = (-_BJ_A * w[lx] + w[ly]) * (bx + by) % R
+        x3 = new((w[beta] + w[gamma]) * pow(1 + _BJ_D * w[tau], -1, R))
+        cons.append(([(ONE, 1), (tau, _BJ_D)], [(x3, 1)], [(beta, 1), (gamma, 1)]))
+        y3 = new((delta_v + _BJ_A * w[beta] - w[gamma]) * pow(1 - _BJ_D * w[tau], -1, R))
+        cons.append(([(ONE, 1), (tau, -_BJ_D)], [(y3, 1)],
+                     [(lx, -_BJ_A * (bx + by)), (ly, bx + by), (beta, _BJ_A), (gamma, -1)]))
+        lx, ly = select(s_bits[i], x3, y3, lx, ly)
+        Pi = babyjub_add(Pi, Pi)
+    cons.append(([(lx, 1), (rx, -1)], [(ONE, 1)], []))                  # left == right
+    cons.append(([(ly, 1), (ry, -1)], [(ONE, 1)], []))
+    # normalise coefficients into [0, r)
+    cons = [tuple([(v, c % R) for v, c in lc if c % R] for lc in con) for con in cons]
+    return n_inputs, len(w) - n_inputs, cons, w
