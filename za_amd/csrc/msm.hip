@@ -812,6 +812,8 @@ struct MsmJob : MsmJobBase {
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
     uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
+    bool order_items = true;       // items sorted by length before the accumulation (not for small jobs)
+    static constexpr uint32_t ITEM_ORDER_MIN = 16384;
     int acc_prof = -1;
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
@@ -970,18 +972,23 @@ struct MsmJob : MsmJobBase {
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
                                               ones_hi - ones_lo, st));
-            // order the items by length
-            ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
-            ZG_HIP(ctx, S.ihist.reserve(2 * ITEM_CLASSES * 4));
+            // order the items by length -- not for a small job: three launches and a memset cost more than the lanes of
+            // its few hundred waves waiting for their longest item (it is launch and latency bound, not throughput bound)
+            order_items = total_items >= ITEM_ORDER_MIN;
+            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] its scan, [1] the heavy-bucket counter
+            ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
             uint32_t* hist = S.ihist.as<uint32_t>();
-            ZG_HIP(ctx, hipMemsetAsync(hist, 0, ITEM_CLASSES * 4, st));
-            const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
-            hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist);
-            hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(64), 0, st, hist, hist + ITEM_CLASSES);
-            hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
-                               S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key,
-                               hist + ITEM_CLASSES, S.perm.as<uint32_t>());
+            ZG_HIP(ctx, hipMemsetAsync(hist, 0, (2 * ITEM_CLASSES + 1) * 4, st));
+            if (order_items) {
+                ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
+                const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
+                hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
+                                   S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist);
+                hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(64), 0, st, hist, hist + ITEM_CLASSES);
+                hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
+                                   S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key,
+                                   hist + ITEM_CLASSES, S.perm.as<uint32_t>());
+            }
         }
         {
             if (dep && dep->ev_acc) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_acc, 0));
@@ -991,8 +998,8 @@ struct MsmJob : MsmJobBase {
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
                                fbw_table ? fbw_table : quad_table ? quad_table : d_bases,
                                S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.item_key.as<uint32_t>(), S.perm.as<uint32_t>(), nkeys, t_pack, ones_key,
-                               S.partial.as<XYZZ<F>>());
+                               S.item_key.as<uint32_t>(), order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr, nkeys,
+                               t_pack, ones_key, S.partial.as<XYZZ<F>>());
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
         trace_point("phase_c accumulate queued");
@@ -1000,12 +1007,12 @@ struct MsmJob : MsmJobBase {
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
         {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
             ZG_HIP(ctx, S.heavy.reserve(((size_t)P.nkeys + 1) * 4));
-            uint32_t* hcnt = S.heavy.as<uint32_t>();
-            ZG_HIP(ctx, hipMemsetAsync(hcnt, 0, 4, st));
+            uint32_t* hcnt = S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES;   // zeroed with the histogram above
+            uint32_t* hlist = S.heavy.as<uint32_t>();
             hipLaunchKernelGGL(k_heavy_collect, dim3((P.nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               P.nkeys, hcnt, hcnt + 1);
+                               P.nkeys, hcnt, hlist);
             hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
-                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hcnt + 1);
+                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist);
         }
         const int bits = P.c - 1;
         red_nlev = 0;
