@@ -239,3 +239,67 @@ def test_witness_pack_is_a_host_function(lib_built):
     rc = lib.zg_witness_pack(wa.ctypes.data_as(C.c_void_p), C.c_size_t(len(vals)), c2.ctypes.data_as(C.c_void_p),
                              i2.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p), C.c_size_t(1), C.byref(k))
     assert rc == 23 and k.value == 3
+
+
+# ---- INTEGRATION.md's Rust FFI block vs include/za_amd.h (no Rust toolchain here: keep the paper binding honest)
+_RUST_TO_C = {
+    "i32": {"int"}, "u32": {"uint32_t", "unsigned", "unsigned int"}, "u64": {"uint64_t"}, "usize": {"size_t"},
+    "f64": {"double"}, "u8": {"uint8_t"}, "libc::c_char": {"char"}, "libc::c_void": {"void"},
+    "ZgCtx": {"zg_ctx"}, "ZgParams": {"zg_params"}, "ZgR1cs": {"zg_r1cs"}, "ZgMsmBases": {"zg_msm_bases"},
+}
+
+
+def _c_prototypes():
+    text = open(os.path.join(ROOT, "include", "za_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(zg_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        args = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        protos[name] = (" ".join(ret.split()), args)
+    return protos
+
+
+def _c_type(arg):
+    """('const uint8_t* const row_ptr[3]') -> (base type, pointer depth), arrays counting as one pointer level."""
+    depth = arg.count("*") + arg.count("[")
+    arg = re.sub(r"\[[^\]]*\]", "", arg).replace("*", " ")
+    words = [w for w in arg.split() if w not in ("const", "struct")]
+    base = " ".join(words[:-1]) if len(words) > 1 else words[0]   # the last word is the parameter name
+    return base, depth
+
+
+def _rust_type(t):
+    depth = len(re.findall(r"\*(?:const|mut)\b", t))
+    base = re.sub(r"\*(?:const|mut)\s*", "", t).strip()
+    return base, depth
+
+
+def test_integration_md_ffi_block_matches_the_header():
+    """Every `pub fn` of INTEGRATION.md section 1.1 names a function of include/za_amd.h with the same number of
+    parameters, the same pointer depth and a compatible scalar type per parameter, and the same return type."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', md, flags=re.S)
+    assert block, "INTEGRATION.md lost its extern \"C\" block"
+    body = re.sub(r"//[^\n]*", "", block.group(1))
+    fns = re.findall(r"pub fn (\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", body)
+    assert len(fns) >= 25
+    protos = _c_prototypes()
+    for name, args, ret in fns:
+        assert name in protos, "INTEGRATION.md declares %s, which include/za_amd.h does not" % name
+        c_ret, c_args = protos[name]
+        r_args = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        assert len(r_args) == len(c_args), "%s: %d parameters in INTEGRATION.md, %d in the header" % (name, len(r_args), len(c_args))
+        for ra, ca in zip(r_args, c_args):
+            (rb, rd), (cb, cd) = _rust_type(ra), _c_type(ca)
+            assert rd == cd, "%s: pointer depth of `%s` vs `%s`" % (name, ra, ca)
+            assert cb in _RUST_TO_C.get(rb, ()), "%s: `%s` does not match `%s`" % (name, ra, ca)
+        ret = (ret or "").strip()
+        if not ret:
+            assert c_ret == "void", name
+        else:
+            (rb, rd), cd = _rust_type(ret), c_ret.count("*")
+            cb = " ".join(w for w in c_ret.replace("*", " ").split() if w != "const")
+            assert rd == cd and cb in _RUST_TO_C.get(rb, ()), "%s: return type `%s` vs `%s`" % (name, ret, c_ret)
+    # the entry points a za maintainer cannot do without are in the block
+    for must in ("zg_init", "zg_params_load", "zg_r1cs_load", "zg_prove", "zg_prove_random", "zg_proof_json", "zg_verify"):
+        assert must in [f[0] for f in fns]

@@ -10,6 +10,7 @@ from oracle import bn254 as bn
 from oracle import coracle as co
 from oracle import groth16 as g
 from tests.util import download_params
+from za_amd import synth
 
 pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 8, 64)
@@ -58,15 +59,25 @@ def test_config5_shape_uniform_witness_at_2p24_matches_discrete_log_expectation(
     r, s = 0xABCDEF01, 0x10FEDCBA
     got = ctx.prove(P, R, sr.witness, r, s)
     assert [P.table_info(k)[0] for k in range(5)] == [1, 1, 1, 1, 1]
+    assert got == _dlog_expectation(ctx, sr, R, lg, seed, r, s)
+    P.close(); R.close(); sr.close()
+
+
+def _dlog_expectation(ctx, sr, R, lg, seed, r, s):
+    """The proof a synth_params key (every base k_i G, alpha = 3G, beta = 5G, delta = 7G) must give: A, B, C as scalar
+    multiples of the generators, with R1CS evaluation and H from the C oracle."""
+    m, ni = 1 << lg, sr.n_inputs
+    n_a, n_b = ni + R.a_aux_total, R.b_input_total + R.b_aux_total
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
     a, b, c, ad, bi, bd = co.r1cs_eval(csr, sr.witness, threads=THREADS)
     h = co.h_coeffs(a, b, c, sr.n_constraints + ni, lg, threads=THREADS)
     del a, b, c
-    w = np.frombuffer(bytes(sr.witness), dtype=np.uint8).reshape(-1, 32)
+    w = np.frombuffer(sr.witness, dtype=np.uint8).reshape(-1, 32)
     a_idx = np.concatenate([np.arange(ni), ni + np.nonzero(ad)[0]])
     b_idx = np.concatenate([np.nonzero(bi)[0], ni + np.nonzero(bd)[0]])
     assert len(a_idx) == n_a and len(b_idx) == n_b
     sh = co.dot_u64(h, synth.splitmix64_array(seed + 1, m - 1)) % bn.R
+    del h
     sl = co.dot_u64(w[ni:], synth.splitmix64_array(seed + 2, sr.n_aux)) % bn.R
     sa = co.dot_u64(np.ascontiguousarray(w[a_idx]), synth.splitmix64_array(seed + 3, n_a)) % bn.R
     sb = co.dot_u64(np.ascontiguousarray(w[b_idx]), synth.splitmix64_array(seed + 4, n_b)) % bn.R
@@ -77,7 +88,27 @@ def test_config5_shape_uniform_witness_at_2p24_matches_discrete_log_expectation(
     A = bn.g1_from_mont_bytes(co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eA))
     B = bn.g2_from_mont_bytes(co.g2_mul(bn.g2_to_mont_bytes(bn.G2_GEN), eB))
     Cc = bn.g1_from_mont_bytes(co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), eC))
-    assert got == g.proof_bytes((A, B, Cc))
+    return g.proof_bytes((A, B, Cc))
+
+
+def test_config5_2p26_proof_matches_discrete_log_expectation(ctx):
+    """BASELINE config 5 itself on one GPU: the 2^26 random R1CS (uniform-Fr coefficients and witness, SplitMix64 seed
+    0x26, n + l = 2^26), a key of 2^26-point queries with known discrete logs, zg_prove from host memory.  What differs
+    from 2^24 at this size: the table budget logic (h, a, b_g2 get window tables, the rest of the 288 GB goes to the
+    sort buffers), 32-bit index headroom (12 digits x 2^26 entries), four-part h job."""
+    lg = 26
+    sr = synth.SynthR1CS(lg, 2, 0.0, 0x26)
+    R = sr.load(ctx)
+    m, ni = 1 << lg, sr.n_inputs
+    n_a, n_b = ni + R.a_aux_total, R.b_input_total + R.b_aux_total
+    seed = 2600026
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, seed)
+    r, s = 0xABCDEF0123, 0x10FEDCBA98
+    got = ctx.prove(P, R, sr.witness, r, s)
+    assert P.table_info(0)[0] == 1       # the h query has its window table
+    assert ctx.prove(P, R, sr.witness, r, s) == got     # second call: cached tables / workspaces
+    want = _dlog_expectation(ctx, sr, R, lg, seed, r, s)
+    assert got == want
     P.close(); R.close(); sr.close()
 
 

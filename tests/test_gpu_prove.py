@@ -81,6 +81,54 @@ def test_random_blinding_still_verifies(ctx):
     assert not g.verify_proof(params.vk, proof, [7])
 
 
+def test_witness_is_validated_like_a_typed_assignment(ctx):
+    """bellman's `Fr` cannot hold a value >= r and its variable 0 is CS::one(): the raw 32-byte witness of zg_prove*
+    is checked on the device (k_witness_classes) and refused with BadFormat instead of giving a wrong proof."""
+    import za_amd
+    fx = golden("proof_chain7.json")
+    R, P, w, _ = _load_fixture(ctx, fx)
+    good = ctx.prove(P, R, w, 5, 7)
+    assert good.hex() == fx["proof"]
+    nv = len(w) // 32
+    for pos in (1, nv // 2, nv - 1):
+        for bad in (bn.R, bn.R + 1, 1 << 254, (1 << 256) - 1):
+            wb = bytearray(w)
+            wb[32 * pos:32 * pos + 32] = bad.to_bytes(32, "little")
+            with pytest.raises(za_amd.ZaAmdError) as e:
+                ctx.prove(P, R, bytes(wb), 5, 7)
+            assert e.value.code == za_amd.ZG_E_BAD_FORMAT and ("value %d " % pos) in str(e.value), str(e.value)
+            d_w = ctx.upload(bytes(wb))
+            with pytest.raises(za_amd.ZaAmdError) as e:
+                ctx.prove_dev(P, R, d_w, 5, 7)
+            assert e.value.code == za_amd.ZG_E_BAD_FORMAT
+            # the phase API of a rank that does not evaluate the R1CS
+            with pytest.raises(za_amd.ZaAmdError) as e:
+                ctx.prove_partials_dev(P, R, d_w, 0, mask=0x1e)
+            assert e.value.code == za_amd.ZG_E_BAD_FORMAT
+            ctx.free(d_w)
+    # r - 1 is the largest canonical value: accepted (the proof is then simply one of an unsatisfied system)
+    wb = bytearray(w)
+    wb[32 * (nv - 1):32 * nv] = (bn.R - 1).to_bytes(32, "little")
+    assert len(ctx.prove(P, R, bytes(wb), 5, 7)) == 256
+    # variable 0 must be ONE
+    for v0 in (0, 2, bn.R - 1):
+        wb = bytearray(w)
+        wb[0:32] = v0.to_bytes(32, "little")
+        with pytest.raises(za_amd.ZaAmdError) as e:
+            ctx.prove(P, R, bytes(wb), 5, 7)
+        assert e.value.code == za_amd.ZG_E_BAD_FORMAT and "ONE" in str(e.value)
+    # the packed form: a listed value >= r is caught by the same device pass
+    classes, idx, vals = za_amd.pack_witness(w)
+    if idx.size:
+        vb = np.array(vals, copy=True)
+        vb[0:32] = np.frombuffer(bn.R.to_bytes(32, "little"), dtype=np.uint8)
+        with pytest.raises(za_amd.ZaAmdError) as e:
+            ctx.prove_packed(P, R, (classes, idx, vb), 5, 7)
+        assert e.value.code == za_amd.ZG_E_BAD_FORMAT
+    # and a good witness still proves to the golden bytes afterwards (no sticky state)
+    assert ctx.prove(P, R, w, 5, 7) == good
+
+
 def test_error_behaviour(ctx):
     import za_amd
     fx = golden("proof_chain7.json")

@@ -390,7 +390,7 @@ class Context:
     def last_timings(self):
         t = (C.c_double * 6)()
         self._check(self.lib.zg_last_timings(self.h, t))
-        return dict(zip(("upload_ms", "r1cs_eval_ms", "h_ms", "msm_ms", "combine_ms", "total_ms"), list(t)))
+        return dict(zip(("upload_bytes", "r1cs_eval_ms", "h_ms", "msm_ms", "combine_ms", "total_ms"), list(t)))
 
 
 class R1CS:

@@ -1270,7 +1270,10 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     int parts = 1;
     if (g1[0].dense && g1[0].n >= ((size_t)1 << 20) && live_contexts() == 1) parts = 2;
     if (g1[0].parts > 0) parts = g1[0].parts;
-    if (const char* e = getenv("ZA_AMD_H_PARTS")) parts = atoi(e);
+    // (not when the caller gates the parts on events of its own -- zg_msm_resident's scalar chunks: its part count IS
+    // the chunking, and a different split would read scalars that have not arrived yet)
+    if (const char* e = getenv("ZA_AMD_H_PARTS"))
+        if (!g1[0].part_gate) parts = atoi(e);
     if (parts < 1) parts = 1;
     if (parts > HP) parts = HP;
     if (g1[0].n < (size_t)parts * 4096) parts = 1;

@@ -90,13 +90,30 @@ __global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_
     cls[i] = (uint8_t)k;
     (FrD::to_mont(FrD::load_canon(&c[i])) * FrD::r2()).canonical().store(&c[i]);
 }
-// witness classes: 0 = zero, 1 = one, 2 = anything else
-__global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ w, size_t n, uint8_t* __restrict__ cls) {
+// witness classes: 0 = zero, 1 = one, 2 = anything else.  The same pass validates the assignment: bellman's typed
+// `Fr` cannot hold a value >= r and its variable 0 is the constant ONE (CS::one(), prover.rs:66), so a raw 32-byte
+// witness that breaks either would give a silently wrong proof (next_digit assumes scalars below 2^254).
+// bad[0] = lowest index of a non-canonical value, bad[1] = 0 if w[0] != 1; both words start as 0xffffffff.
+__global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ w, size_t n, uint8_t* __restrict__ cls,
+                                                         uint32_t* __restrict__ bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fr v = w[i];
     const uint32_t hi = v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7];
-    cls[i] = (hi == 0 && v.l[0] <= 1) ? (uint8_t)v.l[0] : (uint8_t)2;
+    const bool small = hi == 0 && v.l[0] <= 1;
+    cls[i] = small ? (uint8_t)v.l[0] : (uint8_t)2;
+    if (i == 0 && !(small && v.l[0] == 1)) bad[1] = 0u;
+    if (v.l[7] >= FrParams::MOD[7]) {   // only then can v reach r (top word of r: 0x30644e72)
+        bool ge = true;                  // v >= r, decided at the most significant differing word
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            if (v.l[j] != FrParams::MOD[j]) {
+                ge = v.l[j] > FrParams::MOD[j];
+                break;
+            }
+        }
+        if (ge) atomicMin(&bad[0], (uint32_t)i);
+    }
 }
 
 // zg_prove_packed: classes -> 32-byte values (class 2 positions are filled by k_unpack_others)
@@ -164,6 +181,15 @@ struct ProveWs {
     // zg_prove_h_enqueue_dev -> zg_prove_partials_ex)
     const void* wcls_for = nullptr;
     bool wcls_fresh = false, wcls_armed = false;
+    // k_witness_classes' validation result: device words, their pinned host copy, the event behind the copy
+    DevBuf bad;
+    uint32_t* bad_host = nullptr;
+    hipEvent_t bad_ev = nullptr;
+    bool bad_pending = false;
+    ~ProveWs() {
+        if (bad_host) (void)hipHostFree(bad_host);
+        if (bad_ev) (void)hipEventDestroy(bad_ev);
+    }
 };
 static ProveWs& prove_ws(Ctx* ctx) {
     if (!ctx->prove_ws) ctx->prove_ws = new ProveWs();
@@ -936,10 +962,32 @@ static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   /
     ProveWs& ws = prove_ws(ctx);
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     ZG_HIP(ctx, ws.wcls.reserve(nv));
+    if (!ws.bad_host) {
+        ZG_HIP(ctx, ws.bad.reserve(8));
+        ZG_HIP(ctx, hipHostMalloc((void**)&ws.bad_host, 8, hipHostMallocDefault));
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ws.bad_ev, hipEventDisableTiming));
+    }
+    ZG_HIP(ctx, hipMemsetAsync(ws.bad.p, 0xff, 8, ctx->stream));   // "nothing wrong" = all ones in both words
     hipLaunchKernelGGL(k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
-                       ws.wcls.as<uint8_t>());
+                       ws.wcls.as<uint8_t>(), ws.bad.as<uint32_t>());
     ZG_HIP(ctx, hipGetLastError());
+    ZG_HIP(ctx, hipMemcpyAsync(ws.bad_host, ws.bad.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipEventRecord(ws.bad_ev, ctx->stream));
+    ws.bad_pending = true;
     ws.wcls_for = d_w;
+    return ZG_OK;
+}
+// The verdict of the last witness_classes pass (waits for its 8-byte read-back only, not for the stream): a witness
+// with a value >= r or with variable 0 != ONE is refused, as bellman's typed assignment cannot express it.
+static int witness_verdict(zg_ctx* ctx) {
+    ProveWs& ws = prove_ws(ctx);
+    if (!ws.bad_pending) return ZG_OK;
+    ws.bad_pending = false;
+    ZG_HIP(ctx, hipEventSynchronize(ws.bad_ev));
+    if (ws.bad_host[0] != 0xffffffffu)
+        return fail(ctx, ZG_E_BAD_FORMAT, "witness value %u is not a canonical field element (>= r)", ws.bad_host[0]);
+    if (ws.bad_host[1] != 0xffffffffu)
+        return fail(ctx, ZG_E_BAD_FORMAT, "witness value 0 must be the constant ONE");
     return ZG_OK;
 }
 
@@ -1187,7 +1235,7 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timings[1] = 0;
     ctx->timings[2] = now_ms() - t0;   // R1CS evaluation + H
-    return ZG_OK;
+    return witness_verdict(ctx);
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -1409,7 +1457,7 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     jac_bytes(partials + 288, b1_acc);
     jac_bytes(partials + 384, b2_acc);
     ctx->timings[3] = now_ms() - t0;
-    return ZG_OK;
+    return witness_verdict(ctx);
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -1506,7 +1554,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ZG_TRY(gate_events(ctx));
     struct ClassGuard {   // whatever way this call ends, the class bytes are not taken for a later proof's
         ProveWs& ws;
-        ~ClassGuard() { ws.wcls_armed = ws.wcls_fresh = false; }
+        ~ClassGuard() { ws.wcls_armed = ws.wcls_fresh = ws.bad_pending = false; }
     } class_guard{prove_ws(ctx)};
     ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;

@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -53,6 +55,10 @@ bool read_file(const char* path, std::vector<uint8_t>* out, std::string* err) {
     }
     f.seekg(0, std::ios::end);
     std::streamoff n = f.tellg();
+    if (n < 0) {   // a directory or an unseekable path
+        *err = std::string("Io(\"") + path + ": not a regular file\")";
+        return false;
+    }
     f.seekg(0);
     out->resize((size_t)n);
     if (n) f.read((char*)out->data(), n);
@@ -109,7 +115,55 @@ std::string nul_joined(const std::vector<std::string>& v) {
     }
     return o;
 }
-// {"@binwitness": "<path>"} or a bare path
+// A JSON string starting at s[q0] == '"', with its escapes decoded (\uXXXX as UTF-8): a path may contain '"' or '\\'.
+bool json_string(const std::string& s, size_t q0, std::string* out) {
+    out->clear();
+    for (size_t i = q0 + 1; i < s.size(); i++) {
+        const char ch = s[i];
+        if (ch == '"') return true;
+        if (ch != '\\') {
+            out->push_back(ch);
+            continue;
+        }
+        if (++i >= s.size()) return false;
+        switch (s[i]) {
+            case '"': out->push_back('"'); break;
+            case '\\': out->push_back('\\'); break;
+            case '/': out->push_back('/'); break;
+            case 'b': out->push_back('\b'); break;
+            case 'f': out->push_back('\f'); break;
+            case 'n': out->push_back('\n'); break;
+            case 'r': out->push_back('\r'); break;
+            case 't': out->push_back('\t'); break;
+            case 'u': {
+                if (i + 4 >= s.size()) return false;
+                unsigned cp = 0;
+                for (int d = 1; d <= 4; d++) {
+                    const char h = s[i + d];
+                    cp <<= 4;
+                    if (h >= '0' && h <= '9') cp |= (unsigned)(h - '0');
+                    else if (h >= 'a' && h <= 'f') cp |= (unsigned)(h - 'a' + 10);
+                    else if (h >= 'A' && h <= 'F') cp |= (unsigned)(h - 'A' + 10);
+                    else return false;
+                }
+                i += 4;
+                if (cp < 0x80) out->push_back((char)cp);
+                else if (cp < 0x800) {
+                    out->push_back((char)(0xC0 | (cp >> 6)));
+                    out->push_back((char)(0x80 | (cp & 0x3F)));
+                } else {
+                    out->push_back((char)(0xE0 | (cp >> 12)));
+                    out->push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+                    out->push_back((char)(0x80 | (cp & 0x3F)));
+                }
+                break;
+            }
+            default: return false;
+        }
+    }
+    return false;   // no closing quote
+}
+// {"@binwitness": "<path>"} (a JSON string, escapes honoured) or a bare path
 bool witness_path(const char* inputs, std::string* path, std::string* err) {
     std::string s(inputs);
     size_t a = s.find_first_not_of(" \t\r\n");
@@ -126,11 +180,11 @@ bool witness_path(const char* inputs, std::string* path, std::string* err) {
     size_t k = s.find(key);
     if (k != std::string::npos) {
         size_t c = s.find(':', k + key.size());
-        size_t q0 = c == std::string::npos ? c : s.find('"', c);
-        size_t q1 = q0 == std::string::npos ? q0 : s.find('"', q0 + 1);
-        if (q1 != std::string::npos) {
-            *path = s.substr(q0 + 1, q1 - q0 - 1);
-            return true;
+        size_t q0 = c == std::string::npos ? c : s.find_first_not_of(" \t\r\n", c + 1);
+        if (q0 != std::string::npos && s[q0] == '"') {
+            if (json_string(s, q0, path)) return true;
+            *err = "Json(\"invalid string for @binwitness\")";
+            return false;
         }
     }
     *err = "Evaluator(\"witness generation needs the za evaluator, which is outside this library: pass "
@@ -145,7 +199,7 @@ extern "C" void verbose(int on) {
     g_verbose = on != 0;
 }
 
-extern "C" int setup(const char* circuit_path, const char* pk_path, const char* verifier_type, char* verifier_buffer,
+static int setup_impl(const char* circuit_path, const char* pk_path, const char* verifier_type, char* verifier_buffer,
                      size_t verifier_buffer_size, char* error_buffer, size_t error_buffer_size) {
     if (!circuit_path || !pk_path || !verifier_type)
         return return_string("Unexpected(\"null argument\")", error_buffer, error_buffer_size, ERR_CUSTOM);
@@ -206,7 +260,7 @@ extern "C" int setup(const char* circuit_path, const char* pk_path, const char* 
     return return_string(verifier, verifier_buffer, verifier_buffer_size, ERR_NONE);
 }
 
-extern "C" int prove(const char* pk_path, const char* inputs, char* proof_buffer, size_t proof_buffer_size,
+static int prove_impl(const char* pk_path, const char* inputs, char* proof_buffer, size_t proof_buffer_size,
                      char* error_buffer, size_t error_buffer_size) {
     if (!pk_path || !inputs) return return_string("Unexpected(\"null argument\")", error_buffer, error_buffer_size, ERR_CUSTOM);
     std::string err, wpath;
@@ -256,7 +310,7 @@ extern "C" int prove(const char* pk_path, const char* inputs, char* proof_buffer
     return return_string(json, proof_buffer, proof_buffer_size, ERR_NONE);
 }
 
-extern "C" int verify(const char* verifying_key, const char* proof_with_inputs, char* error_buffer, size_t error_buffer_size) {
+static int verify_impl(const char* verifying_key, const char* proof_with_inputs, char* error_buffer, size_t error_buffer_size) {
     if (!verifying_key || !proof_with_inputs)
         return return_string("Unexpected(\"null argument\")", error_buffer, error_buffer_size, ERR_CUSTOM);
     size_t vk_len = 0;
@@ -278,4 +332,34 @@ extern "C" int verify(const char* verifying_key, const char* proof_with_inputs, 
     rc = zg_verify(vk.data(), vk.size(), proof, pub.data(), n_public, &ok);
     if (rc) return return_string(err_text(nullptr, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     return ok ? ERR_NONE : ERR_VERIFICATION_FAILED;
+}
+
+// No C++ exception leaves the four symbols (std::bad_alloc for a huge key, std::length_error ...): the C / Go / Rust
+// host gets code 100 with an Unexpected(..) text instead of std::terminate.
+template <class Fn>
+static int guarded(char* error_buffer, size_t error_buffer_size, Fn&& fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        return return_string("Unexpected(\"out of memory\")", error_buffer, error_buffer_size, ERR_CUSTOM);
+    } catch (const std::exception& e) {
+        return return_string(std::string("Unexpected(\"") + e.what() + "\")", error_buffer, error_buffer_size, ERR_CUSTOM);
+    } catch (...) {
+        return return_string("Unexpected(\"unknown exception\")", error_buffer, error_buffer_size, ERR_CUSTOM);
+    }
+}
+extern "C" int setup(const char* circuit_path, const char* pk_path, const char* verifier_type, char* verifier_buffer,
+                     size_t verifier_buffer_size, char* error_buffer, size_t error_buffer_size) {
+    return guarded(error_buffer, error_buffer_size, [&] {
+        return setup_impl(circuit_path, pk_path, verifier_type, verifier_buffer, verifier_buffer_size, error_buffer, error_buffer_size);
+    });
+}
+extern "C" int prove(const char* pk_path, const char* inputs, char* proof_buffer, size_t proof_buffer_size,
+                     char* error_buffer, size_t error_buffer_size) {
+    return guarded(error_buffer, error_buffer_size,
+                   [&] { return prove_impl(pk_path, inputs, proof_buffer, proof_buffer_size, error_buffer, error_buffer_size); });
+}
+extern "C" int verify(const char* verifying_key, const char* proof_with_inputs, char* error_buffer, size_t error_buffer_size) {
+    return guarded(error_buffer, error_buffer_size,
+                   [&] { return verify_impl(verifying_key, proof_with_inputs, error_buffer, error_buffer_size); });
 }

@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
         if (input.empty()) input = DEFAULT_INPUT;
         if (proof.empty()) proof = DEFAULT_PROOF;
         std::string inputs_json;
-        if (!witness.empty()) inputs_json = "{\"@binwitness\": \"" + witness + "\"}";
+        if (!witness.empty()) inputs_json = witness;   // prove() takes a bare path as it is: no JSON quoting to get wrong
         else if (!slurp(input, &inputs_json)) {
             fprintf(stderr, "cannot open inputs file\n");
             return 101;
