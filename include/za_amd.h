@@ -253,6 +253,11 @@ int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r
 int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
                          const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]);
 int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_h_out);
+/* H in EVALUATION form: d_e_out receives m canonical-LE scalars e[p] = ((A B - C) / Z)(g omega^bitrev(p)) -- the values
+ * bellman's create_proof holds just before its last transform (icoset_fft).  zg_prove* multiplies them into the key's
+ * TRANSFORMED h bases (built once per key: the same linear map applied to the points), so a proof runs six transforms
+ * instead of seven and gives the same group element; ZA_AMD_H_EVAL=0 keeps the coefficient form.  Blocking. */
+int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
 int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partials_all, int world,
                      const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */
@@ -323,11 +328,12 @@ int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline
- * line.  id: 0 msm_accumulate_g1, 1 msm_accumulate_g2, 2 msm_digit_sort, 3 msm_bucket_reduce,
- * 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval.  alg_bytes = algorithmic HBM bytes of the timed launches.
- * zg_profile_enable: 0 off, 1 = classes 0 and 1 only (the dominant kernels: about five event pairs per proof),
+ * line.  id: 0 msm_accumulate_g1 (the witness queries' G1 jobs), 1 msm_accumulate_g2, 2 msm_digit_sort,
+ * 3 msm_bucket_reduce, 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval, 7 msm_accumulate_g1_dense (the h query's job and
+ * dense-hinted standalone multiexps: every point reaches the kernel).  alg_bytes = algorithmic HBM bytes of the timed launches.
+ * zg_profile_enable: 0 off, 1 = classes 0, 1 and 7 only (the dominant kernels: about five event pairs per proof),
  * 2 = every class (about a hundred event pairs per proof, which cost 0.5 ms of a proof's wall time). */
-#define ZG_PROFILE_KERNELS 7
+#define ZG_PROFILE_KERNELS 8
 int zg_profile_enable(zg_ctx* ctx, int on);
 int zg_profile_reset(zg_ctx* ctx);
 int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes);

@@ -313,8 +313,101 @@ static void test_ntt_passes() {
     printf("NTT passes ok\n");
 }
 
+// The fused kernels of the evaluation-form H pipeline (ntt.hip: k_ntt_mid, k_ntt_tail3) through the very function
+// they run, ntt_tile_stages, with bound tracking: k DIT stages on bit-reversed input -> coset scaling -> k DIF stages ->
+// quotient (a b - c) z as a plain integer.  One "thread", whole-vector tiles of 2^1 .. 2^10 elements.
+struct HostTile {
+    std::vector<FrD>& v;
+    FrD get(uint32_t li) const { return v[li]; }
+    void put(uint32_t li, const FrD& x) const { v[li] = x; }
+};
+static void test_ntt_tile_fused() {
+    for (int k = 1; k <= 10; k++) {
+        const int n = 1 << k;
+        Fr g = Fr::from_u64(7);
+        uint32_t e[8];
+        for (int i = 0; i < 8; i++) e[i] = FrParams::MOD[i];
+        e[0] -= 1;
+        uint32_t q[8];
+        for (int i = 0; i < 8; i++) q[i] = (e[i] >> k) | (i < 7 ? (e[i + 1] << (32 - k)) : 0);
+        const Fr omega = g.pow(q), omega_inv = omega.inv();
+        std::vector<Fr> wf(n), wi(n);
+        wf[0] = wi[0] = Fr::one();
+        for (int i = 1; i < n; i++) { wf[i] = wf[i - 1] * omega; wi[i] = wi[i - 1] * omega_inv; }
+        std::vector<FrLimbs> twf(n / 2 ? n / 2 : 1), twi(n / 2 ? n / 2 : 1);
+        for (int i = 0; i < n / 2; i++) {
+            store_limbs(&twf[i], fd_of<Fr29>(wf[i].from_mont()).canonical());
+            store_limbs(&twi[i], fd_of<Fr29>(wi[i].from_mont()).canonical());
+        }
+        auto brev = [&](int x) { int r = 0; for (int b = 0; b < k; b++) r |= ((x >> b) & 1) << (k - 1 - b); return r; };
+        const Fr minv = Fr::from_u64((uint64_t)n).inv();
+        const Fr zinv = (g.pow_u64((uint64_t)n) - Fr::one()).inv();
+        std::vector<Fr> ev[3], coset[3];
+        std::vector<FrD> res[3];
+        for (int vsel = 0; vsel < 3; vsel++) {
+            ev[vsel].resize(n);
+            for (int i = 0; i < n; i++) ev[vsel][i] = rand_canon<FrParams>().to_mont();
+            // reference: coefficients c_i = (1/n) sum_j ev_j omega^(-i j); coset[j] = sum_i c_i g^i omega^(i j)
+            std::vector<Fr> coef(n);
+            for (int i = 0; i < n; i++) {
+                Fr acc = Fr::zero();
+                for (int j = 0; j < n; j++) acc = acc + ev[vsel][j] * wi[(size_t)i * j % n];
+                coef[i] = acc * minv;
+            }
+            coset[vsel].resize(n);
+            Fr gp = Fr::one();
+            std::vector<Fr> cg(n);
+            for (int i = 0; i < n; i++) { cg[i] = coef[i] * gp; gp = gp * g; }
+            for (int j = 0; j < n; j++) {
+                Fr acc = Fr::zero();
+                for (int i = 0; i < n; i++) acc = acc + cg[i] * wf[(size_t)i * j % n];
+                coset[vsel][j] = acc;
+            }
+            // the kernel's sequence on a tile in device form (entry bound 2.01 p, as after load_red)
+            std::vector<FrD> t(n);
+            for (int i = 0; i < n; i++) {
+                t[i] = fd_of<Fr29>(ev[vsel][brev(i)].from_mont());
+                t[i].ub = 2.01;
+            }
+            HostTile T{t};
+            const TileGeom G = TileGeom::make(k, 0, k, 0, 1, 0);
+            ntt_tile_stages<true>(T, G, twi.data(), 0, 1, [] {});
+            gp = Fr::one();
+            for (int i = 0; i < n; i++) {   // scaling by g^i / n: a product of two canonical table entries
+                const FrD sc = fd_of<Fr29>((gp * minv).from_mont()).canonical();
+                t[i] = t[i] * sc;
+                gp = gp * g;
+            }
+            ntt_tile_stages<false>(T, G, twf.data(), 0, 1, [] {});
+            res[vsel] = t;
+            for (int i = 0; i < n; i++) {
+                Fr mem;
+                t[i].reduce().store(&mem);
+                CHECK(canon_of<Fr29>(FrD::load_red(&mem)).to_mont() == coset[vsel][brev(i)]);
+            }
+        }
+        // quotient: (a b - c) z with z a plain integer -> plain integer
+        for (int i = 0; i < n; i++) {
+            Fr ma, mb, mc;
+            res[0][i].reduce().store(&ma);
+            res[1][i].reduce().store(&mb);
+            res[2][i].reduce().store(&mc);
+            const FrD ab = FrD::load_red(&ma) * FrD::load_red(&mb);
+            Fr zint = zinv.from_mont();   // canonical integer
+            const FrD z = FrD::load_canon(&zint);
+            Fr out;
+            (FrD::sub<3>(ab, FrD::load_red(&mc)) * z).canonical().store(&out);
+            const int j = brev(i);
+            const Fr want = ((coset[0][j] * coset[1][j] - coset[2][j]) * zinv).from_mont();
+            CHECK(out == want);
+        }
+    }
+    printf("fused NTT tiles ok\n");
+}
+
 int main() {
     test_ntt_passes();
+    test_ntt_tile_fused();
     test_field<Fq29>("Fq");
     test_field<Fr29>("Fr");
     G1Affine g1{Fq::from_u64(1), Fq::from_u64(2)};

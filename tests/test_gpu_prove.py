@@ -81,13 +81,99 @@ def test_random_blinding_still_verifies(ctx):
     assert not g.verify_proof(params.vk, proof, [7])
 
 
+@pytest.mark.parametrize("lg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 19])
+def test_h_in_evaluation_form_gives_the_coefficient_forms_proof(ctx, lg):
+    """zg_prove* takes H in evaluation form (six transforms; the h query's bases transformed once per key by a DFT over
+    the group, heval.hip); ZA_AMD_H_EVAL=0 keeps bellman's icoset_fft + coefficient-form multiexp.  Same group element,
+    so the same bytes -- and the C oracle's (which follows bellman step by step).  Covers every pass structure: one tile
+    (2^1 .. 2^10), two passes (2^11 .. 2^16), three (2^17 ..)."""
+    import os
+    import random
+    from oracle.circuits import chain_r1cs, prescribed_h_r1cs
+    from za_amd import synth
+    if lg <= 9:
+        if lg <= 6:   # every variable constrained whatever the size; H = prescribed random coefficients
+            rng = random.Random(lg)
+            r1, w = prescribed_h_r1cs(lg, [rng.randrange(bn.R) for _ in range((1 << lg) - 1)])
+        else:
+            r1, w = chain_r1cs(lg, n_inputs=2, seed=900 + lg, bit_fraction=0.5)
+        csr = co.CsrR1CS.from_r1cs(r1)
+        wb = co.witness_bytes(w)
+        sr = None
+    else:
+        sr = synth.SynthR1CS(lg, 2, 0.5, 900 + lg)
+        csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+        wb = sr.witness
+    R = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    assert R.log_m == lg
+    P, pbytes = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172)
+    r, s = 0x1234567 + lg, 0x7654321
+    got = ctx.prove(P, R, wb, r, s)            # evaluation form (the default)
+    assert ctx.prove(P, R, wb, r, s) == got
+    old = os.environ.get("ZA_AMD_H_EVAL")
+    os.environ["ZA_AMD_H_EVAL"] = "0"
+    try:
+        P0, _ = ctx.params_load(pbytes, checked=False)
+        assert ctx.prove(P0, R, wb, r, s) == got   # coefficient form
+        P0.close()
+    finally:
+        if old is None:
+            del os.environ["ZA_AMD_H_EVAL"]
+        else:
+            os.environ["ZA_AMD_H_EVAL"] = old
+    if lg <= 17:
+        assert co.prove(download_params(ctx, P), csr, wb, r, s, threads=8) == got
+    P.close(); R.close()
+    if sr is not None:
+        sr.close()
+
+
+def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx):
+    """zg_prove turns a mostly-0/1 witness into the packed form on a few host threads before the upload (3 % of the
+    bytes cross PCIe); a witness of field elements, or one with a dense stretch, is uploaded as it is.  Same proof as
+    zg_prove_dev on the raw array and as the C oracle either way."""
+    from za_amd import synth
+    for lg, bits, expect_packed in ((18, 0.97, True), (18, 0.5, False), (17, 1.0, True)):
+        sr = synth.SynthR1CS(lg, 3, bits, 0x77 + lg)
+        R = sr.load(ctx)
+        nv = sr.n_inputs + sr.n_aux
+        P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 31)
+        csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+        want = co.prove(download_params(ctx, P), csr, sr.witness, 11, 13, threads=8)
+        pin = ctx.host_alloc(32 * nv)
+        pin[:] = sr.witness
+        assert ctx.prove(P, R, pin, 11, 13) == want
+        sent = ctx.last_timings()["upload_bytes"]
+        assert (sent < 32 * nv / 4) == expect_packed, (lg, bits, sent, 32 * nv)
+        d_w = ctx.upload(sr.witness)
+        assert ctx.prove_dev(P, R, d_w, 11, 13) == want
+        ctx.free(d_w)
+        if expect_packed and bits < 1.0:
+            # one stretch of 2^16 values made dense: the packing attempt is abandoned, the proof (of a now unsatisfied
+            # system -- still a well-defined group element) equals the raw-upload one
+            w2 = np.array(sr.witness, copy=True).reshape(-1, 32)
+            rng = np.random.default_rng(5)
+            lo = 3 << 16
+            w2[lo:lo + (1 << 16), :31] = np.frombuffer(rng.bytes(31 << 16), dtype=np.uint8).reshape(-1, 31)
+            w2[lo:lo + (1 << 16), 31] = 0
+            pin[:] = w2.reshape(-1)
+            got = ctx.prove(P, R, pin, 11, 13)
+            assert ctx.last_timings()["upload_bytes"] == 32 * nv
+            d_w = ctx.upload(w2.reshape(-1))
+            assert ctx.prove_dev(P, R, d_w, 11, 13) == got
+            ctx.free(d_w)
+        ctx.host_free(pin)
+        P.close(); R.close(); sr.close()
+
+
 def test_witness_is_validated_like_a_typed_assignment(ctx):
     """bellman's `Fr` cannot hold a value >= r and its variable 0 is CS::one(): the raw 32-byte witness of zg_prove*
     is checked on the device (k_witness_classes) and refused with BadFormat instead of giving a wrong proof."""
     import za_amd
     fx = golden("proof_chain7.json")
     R, P, w, _ = _load_fixture(ctx, fx)
-    good = ctx.prove(P, R, w, 5, 7)
+    r_, s_ = int(fx["r"], 16), int(fx["s"], 16)
+    good = ctx.prove(P, R, w, r_, s_)
     assert good.hex() == fx["proof"]
     nv = len(w) // 32
     for pos in (1, nv // 2, nv - 1):
@@ -95,11 +181,11 @@ def test_witness_is_validated_like_a_typed_assignment(ctx):
             wb = bytearray(w)
             wb[32 * pos:32 * pos + 32] = bad.to_bytes(32, "little")
             with pytest.raises(za_amd.ZaAmdError) as e:
-                ctx.prove(P, R, bytes(wb), 5, 7)
+                ctx.prove(P, R, bytes(wb), r_, s_)
             assert e.value.code == za_amd.ZG_E_BAD_FORMAT and ("value %d " % pos) in str(e.value), str(e.value)
             d_w = ctx.upload(bytes(wb))
             with pytest.raises(za_amd.ZaAmdError) as e:
-                ctx.prove_dev(P, R, d_w, 5, 7)
+                ctx.prove_dev(P, R, d_w, r_, s_)
             assert e.value.code == za_amd.ZG_E_BAD_FORMAT
             # the phase API of a rank that does not evaluate the R1CS
             with pytest.raises(za_amd.ZaAmdError) as e:
@@ -109,13 +195,13 @@ def test_witness_is_validated_like_a_typed_assignment(ctx):
     # r - 1 is the largest canonical value: accepted (the proof is then simply one of an unsatisfied system)
     wb = bytearray(w)
     wb[32 * (nv - 1):32 * nv] = (bn.R - 1).to_bytes(32, "little")
-    assert len(ctx.prove(P, R, bytes(wb), 5, 7)) == 256
+    assert len(ctx.prove(P, R, bytes(wb), r_, s_)) == 256
     # variable 0 must be ONE
     for v0 in (0, 2, bn.R - 1):
         wb = bytearray(w)
         wb[0:32] = v0.to_bytes(32, "little")
         with pytest.raises(za_amd.ZaAmdError) as e:
-            ctx.prove(P, R, bytes(wb), 5, 7)
+            ctx.prove(P, R, bytes(wb), r_, s_)
         assert e.value.code == za_amd.ZG_E_BAD_FORMAT and "ONE" in str(e.value)
     # the packed form: a listed value >= r is caught by the same device pass
     classes, idx, vals = za_amd.pack_witness(w)
@@ -123,10 +209,10 @@ def test_witness_is_validated_like_a_typed_assignment(ctx):
         vb = np.array(vals, copy=True)
         vb[0:32] = np.frombuffer(bn.R.to_bytes(32, "little"), dtype=np.uint8)
         with pytest.raises(za_amd.ZaAmdError) as e:
-            ctx.prove_packed(P, R, (classes, idx, vb), 5, 7)
+            ctx.prove_packed(P, R, (classes, idx, vb), r_, s_)
         assert e.value.code == za_amd.ZG_E_BAD_FORMAT
     # and a good witness still proves to the golden bytes afterwards (no sticky state)
-    assert ctx.prove(P, R, w, 5, 7) == good
+    assert ctx.prove(P, R, w, r_, s_) == good
 
 
 def test_error_behaviour(ctx):

@@ -1,4 +1,4 @@
-"""R1CS evaluation + H pipeline (7 transforms) alone: python tools/h_bench.py [log_m]"""
+"""R1CS evaluation + H pipeline alone, both forms: python tools/h_bench.py [log_m]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import za_amd
@@ -9,9 +9,10 @@ sr = synth.SynthR1CS(lg, 2, 0.97, 0x5A)
 R = sr.load(ctx)
 d_w = ctx.upload(sr.witness)
 d_h = ctx.alloc(32 << lg)
-for _ in range(3):
-    ctx.prove_h_dev(R, d_w, d_h)
-t = time.perf_counter()
-for _ in range(20):
-    ctx.prove_h_dev(R, d_w, d_h)
-print("H pipeline: %.3f ms" % (1e3 * (time.perf_counter() - t) / 20))
+for name, fn in (("coefficient form, 7 transforms", ctx.prove_h_dev), ("evaluation form, 6 transforms", ctx.prove_h_eval_dev)) * 2:
+    for _ in range(3):
+        fn(R, d_w, d_h)
+    t = time.perf_counter()
+    for _ in range(20):
+        fn(R, d_w, d_h)
+    print("R1CS evaluation + H pipeline (%s): %.3f ms" % (name, 1e3 * (time.perf_counter() - t) / 20))

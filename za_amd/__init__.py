@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
-    "zg_prove_h_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
@@ -347,6 +347,10 @@ class Context:
     def prove_h_dev(self, r1cs, d_witness, d_h_out):
         self._check(self.lib.zg_prove_h_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
 
+    def prove_h_eval_dev(self, r1cs, d_witness, d_e_out):
+        """H in evaluation form (the scalars of the key's transformed h bases); blocking."""
+        self._check(self.lib.zg_prove_h_eval_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out)))
+
     def prove_h_enqueue_dev(self, r1cs, d_witness, d_h_out):
         """Non-blocking: queue R1CS evaluation + H; call sync() before using d_h_out."""
         self._check(self.lib.zg_prove_h_enqueue_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
@@ -379,7 +383,7 @@ class Context:
         """{kernel class: (total ms, launches, algorithmic bytes, work units)} since the last reset."""
         self.lib.zg_profile_name.restype = C.c_char_p
         out = {}
-        for i in range(7):
+        for i in range(8):
             ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
             self._check(self.lib.zg_profile_get(self.h, C.c_int(i), C.byref(ms), C.byref(n), C.byref(b)))
             u = C.c_uint64()

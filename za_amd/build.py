@@ -10,8 +10,8 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libza_amd.so")
 LIB_ZA2C = os.path.join(HERE, "libza2c.so")     # the outer drop-in boundary: za's C binding symbols (csrc/za2c.cpp)
 DRIVER = os.path.join(HERE, "za-gpu")           # `za setup|prove` shaped command-line driver (csrc/za_gpu_main.cpp)
-SOURCES = ["msm.hip", "ntt.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip", "outer.hip"]
-HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
+SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip", "outer.hip"]
+HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "nttd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc"]
 

@@ -29,6 +29,7 @@ struct Ctx {
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
+    bool ntt_attr_set = false;   // the transform kernels' dynamic-LDS attribute is set on this ctx's device
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
     struct ProveWs* prove_ws = nullptr;
     // reusable MSM scratch (one per concurrent job) and side streams, see msm.hip
@@ -54,13 +55,13 @@ int live_contexts();   // zg_ctx handles currently alive in this process (prover
 
 // kernel classes timed by the profiling facility
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,
-              PROF_R1CS_EVAL, PROF_COUNT };
+              PROF_R1CS_EVAL, PROF_MSM_ACC_G1_DENSE /* the h job: every point reaches the kernel */, PROF_COUNT };
 struct ProfScope {
     Ctx* c; int idx = -1;
     hipStream_t st;
     ProfScope(Ctx* ctx, int id, uint64_t alg_bytes, hipStream_t stream = nullptr, uint64_t units = 0)
         : c(ctx), st(stream ? stream : ctx->stream) {
-        if (ctx->prof_enabled < (id == PROF_MSM_ACC_G1 || id == PROF_MSM_ACC_G2 ? 1 : 2)) return;
+        if (ctx->prof_enabled < (id == PROF_MSM_ACC_G1 || id == PROF_MSM_ACC_G2 || id == PROF_MSM_ACC_G1_DENSE ? 1 : 2)) return;
         std::lock_guard<std::mutex> lock(ctx->prof_mu);
         Ctx::ProfPending p{id, nullptr, nullptr, alg_bytes, units};
         for (hipEvent_t* e : {&p.e0, &p.e1}) {
@@ -172,6 +173,14 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 // a,b,c: m device-form elements each in HBM, zero padded, row i at index bitrev(i); d_h_out: m plain
 // integers in natural order (coefficient m-1 is zero for a satisfied system).  a, b, c are clobbered.
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
+// H in evaluation form: d_e_out[p] = ((A B - C) / Z)(g omega^bitrev(p)) as plain integers, m of them -- the scalars of
+// a key's h_eval bases (heval.hip).  Six transforms in 4 L - 3 launches.  a, b, c as for h_poly_dev; clobbered.
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out);
+struct FrLimbs;
+int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits);
+// heval.hip: d_out[p] (m affine points, device form) = sum_i omega^(-i bitrev(p)) (g^-i / m) H_i over the first m - 1
+// points of the h query -- the bases that go with h_eval_dev's scalars.  One-time work per key.
+int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log_m, G1Affine* d_out);
 int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out);
 int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host);
 // out[row] = sum_e coeff[e] * x[idx[e]] over CSR/CSC rows; coeff pre-multiplied by 2^522, x plain integers -> M261

@@ -46,6 +46,12 @@ struct zg_params {
     };
     mutable Fbw fbw[5];
     mutable std::mutex fbw_mu;
+    // The h query in evaluation form (heval.hip): m affine points that go with h_eval_dev's scalars, built once per key
+    // (unsharded keys only) together with their own window table.  state as in Fbw.
+    mutable zg::DevBuf h_eval;
+    mutable uint32_t h_eval_log_m = 0;
+    mutable int h_eval_state = 0;
+    mutable Fbw fbw_he;
 };
 
 

@@ -992,7 +992,7 @@ struct MsmJob : MsmJobBase {
         }
         {
             if (dep && dep->ev_acc) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_acc, 0));
-            ProfScope ps(ctx, IS_G1 ? PROF_MSM_ACC_G1 : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
+            ProfScope ps(ctx, IS_G1 ? (dense ? PROF_MSM_ACC_G1_DENSE : PROF_MSM_ACC_G1) : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
                          chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
             acc_prof = ps.idx;
             hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,

@@ -33,6 +33,7 @@ struct NttTables {
     Fr minv;                            // 1/m          (M261, for kernels)
     Fr zinv;                            // 1/(g^m - 1)  (M261, for kernels)
     Fr minv_host;                       // 1/m in the host's 2^256 form
+    Fr zinv_int;                        // 1/(g^m - 1) as a plain integer (k_ntt_tail3 / k_h_quotient leave Montgomery form with it)
     int lo_bits = 0;
 };
 
@@ -122,6 +123,7 @@ static int get_tables(Ctx* ctx, uint32_t log_m, NttTables** out) {
     T->minv_host = Fr::from_u64(m).inv();
     T->minv = host_to_m261(T->minv_host);
     T->zinv = host_to_m261((g.pow_u64(m) - Fr::one()).inv());
+    T->zinv_int = (g.pow_u64(m) - Fr::one()).inv().from_mont();
     const size_t half = m > 1 ? m / 2 : 1;
     int rc = ZG_OK;
     auto A = [&](DevBuf& b, size_t n) {
@@ -184,37 +186,31 @@ struct PassFuse {
     Fr* out;                // post 3
 };
 
-template <bool DIT>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
-                                                  int k, int j, int contiguous, PassFuse fz) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* lds = reinterpret_cast<uint32_t*>(smem);   // 9 limbs per element
-    const int s_hi = s_lo + k - 1;
-    const uint32_t tile_elems = 1u << (k + j);
-    const size_t tile = blockIdx.x;
-    size_t hbase, lblock;
-    if (contiguous) {
-        hbase = tile << (k + j);
-        lblock = 0;
-    } else {
-        const size_t n_lblocks = (size_t)1 << (s_lo - j);
-        hbase = (tile / n_lblocks) << (s_hi + 1);
-        lblock = (tile % n_lblocks) << j;
-    }
-    auto gidx = [&](uint32_t li) -> size_t {
-        if (contiguous) return hbase + li;
-        return hbase | ((size_t)(li >> j) << s_lo) | lblock | (li & ((1u << j) - 1u));
-    };
-    auto lds_get = [&](uint32_t li) {
+// the LDS tile: 9 limbs per element (36-byte stride: conflict-free for unit-stride rounds)
+struct LdsTile {
+    uint32_t* lds;
+    __device__ __forceinline__ FrD get(uint32_t li) const {
         FrD v;
 #pragma unroll
         for (int q = 0; q < 9; q++) v.l[q] = lds[9 * li + q];
         return v;
-    };
-    auto lds_put = [&](uint32_t li, const FrD& v) {
+    }
+    __device__ __forceinline__ void put(uint32_t li, const FrD& v) const {
 #pragma unroll
         for (int q = 0; q < 9; q++) lds[9 * li + q] = v.l[q];
-    };
+    }
+};
+struct BlockSync {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+template <bool DIT>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
+                                                  int k, int j, int contiguous, PassFuse fz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTile T{reinterpret_cast<uint32_t*>(smem)};
+    const TileGeom G = TileGeom::make(log_m, s_lo, k, j, contiguous, blockIdx.x);
+    const uint32_t tile_elems = G.elems();
     const size_t lomask = ((size_t)1 << fz.lo_bits) - 1;
     auto ingest = [&](uint32_t li, size_t g, const Fr& raw) {
         FrD x = FrD::load_red(&raw);
@@ -224,7 +220,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
             FrD ab = x * FrD::load_red(&fz.b[g]);
             x = FrD::sub<3>(ab, FrD::load_red(&fz.c[g])) * FrD::load_canon(&fz.s);
         }
-        lds_put(li, x);
+        T.put(li, x);
     };
     if (tile_elems == 4u * NTT_THREADS) {
         // the usual case: four elements per thread.  All four 32-byte loads are issued before the first is used, so the
@@ -233,74 +229,22 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
         size_t g4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            g4[q] = gidx(threadIdx.x + q * NTT_THREADS);
+            g4[q] = G.gidx(threadIdx.x + q * NTT_THREADS);
             raw[q] = data[g4[q]];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) ingest(threadIdx.x + q * NTT_THREADS, g4[q], raw[q]);
     } else {
         for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
-            const size_t g = gidx(li);
+            const size_t g = G.gidx(li);
             ingest(li, g, data[g]);
         }
     }
     __syncthreads();
-    const int sh = contiguous ? 0 : j;  // position of the butterfly bits inside the local index
-    const uint32_t half = tile_elems >> 1;
-    // DIF: reduce the sums every 2nd stage (and after the last one); `it` counts stages in execution order
-    auto reduces = [&](int it) { return (it & 1) != 0 || it == k - 1; };
-    int it = 0;
-    if (k & 1) {   // an odd stage count: one radix-2 stage first, radix-4 pairs after it
-        const int q = DIT ? 0 : k - 1;
-        const int s = s_lo + q;          // global stage: butterfly span 2^s
-        const int bit = sh + q;
-        const bool red = reduces(0);
-        for (uint32_t b = threadIdx.x; b < half; b += blockDim.x) {
-            uint32_t i0 = ((b >> bit) << (bit + 1)) | (b & ((1u << bit) - 1u));
-            uint32_t i1 = i0 | (1u << bit);
-            size_t e0 = gidx(i0);
-            size_t texp = (e0 & (((size_t)1 << s) - 1)) << (log_m - 1 - s);
-            FrD u = lds_get(i0), v = lds_get(i1);
-            const FrD w = load_limbs(&tw[texp]);
-            if (DIT) ntt_dit2(u, v, w);          // bounds grow by at most 2 p per stage: <= 2.01 + 2k
-            else ntt_dif2(u, v, w, red);         // v <= 4.02 p on entry
-            lds_put(i0, u);
-            lds_put(i1, v);
-        }
-        __syncthreads();
-        it = 1;
-    }
-    // Two stages per LDS round trip: a thread owns the four elements that differ in local bits (bit, bit + 1) and
-    // runs the two radix-2 stages on them in registers -- the same arithmetic, element by element, as two separate
-    // stages (so the lazy bounds above still hold), with half the LDS traffic and barriers and 3 twiddle loads
-    // instead of 4: both low-stage butterflies share a twiddle, the two high-stage ones differ by omega^(m/4).
-    const uint32_t quarter = tile_elems >> 2;
-    for (; it < k; it += 2) {
-        const int qlo = DIT ? it : k - 2 - it;
-        const int s = s_lo + qlo;        // low stage: span 2^s; high stage: span 2^(s+1)
-        const int bit = sh + qlo;
-        for (uint32_t g = threadIdx.x; g < quarter; g += blockDim.x) {
-            const uint32_t i00 = ((g >> bit) << (bit + 2)) | (g & ((1u << bit) - 1u));
-            const uint32_t i01 = i00 | (1u << bit), i10 = i00 | (2u << bit), i11 = i01 | i10;
-            const size_t e00 = gidx(i00);
-            const size_t lowbits = e00 & (((size_t)1 << s) - 1);
-            const size_t t1 = lowbits << (log_m - 1 - s);          // low stage, both butterflies
-            const size_t t2 = lowbits << (log_m - 2 - s);          // high stage, butterfly (00, 10)
-            const size_t t3 = t2 + ((size_t)1 << (log_m - 2));     // high stage, butterfly (01, 11)
-            FrD x0 = lds_get(i00), x1 = lds_get(i01), x2 = lds_get(i10), x3 = lds_get(i11);
-            const FrD w1 = load_limbs(&tw[t1]), w2 = load_limbs(&tw[t2]), w3 = load_limbs(&tw[t3]);
-            if (DIT) ntt_dit4(x0, x1, x2, x3, w1, w2, w3);
-            else ntt_dif4(x0, x1, x2, x3, w1, w2, w3, reduces(it), reduces(it + 1));
-            lds_put(i00, x0);
-            lds_put(i01, x1);
-            lds_put(i10, x2);
-            lds_put(i11, x3);
-        }
-        __syncthreads();
-    }
+    ntt_tile_stages<DIT>(T, G, tw, threadIdx.x, blockDim.x, BlockSync{});
     for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
-        const size_t g = gidx(li);
-        FrD x = lds_get(li);
+        const size_t g = G.gidx(li);
+        FrD x = T.get(li);
         if (fz.post == 0) {
             x.reduce().store(&data[g]);
         } else if (fz.post == 1) {
@@ -312,6 +256,105 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
             (t * FrD::load_canon(&fz.phi[g >> fz.lo_bits])).canonical().store(&fz.out[g]);
         }
     }
+}
+
+// ---- fused passes of the evaluation-form H pipeline (h_eval_dev)
+// The LAST pass of an inverse transform (decimation in time, top stages) and the FIRST pass of the following coset
+// transform (decimation in frequency, the same top stages) work on the same strided tile: one kernel runs both with
+// the coset scaling g^i / m applied in LDS in between -- one load and one store where two passes made two of each.
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_mid(Fr* __restrict__ data, const FrLimbs* __restrict__ tw_inv,
+                                                         const FrLimbs* __restrict__ tw_fwd, int log_m, int s_lo, int k, int j,
+                                                         int contiguous, const Fr* __restrict__ hi, const Fr* __restrict__ lo,
+                                                         int lo_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTile T{reinterpret_cast<uint32_t*>(smem)};
+    const TileGeom G = TileGeom::make(log_m, s_lo, k, j, contiguous, blockIdx.x);
+    const uint32_t tile_elems = G.elems();
+    const size_t lomask = ((size_t)1 << lo_bits) - 1;
+    if (tile_elems == 4u * NTT_THREADS) {
+        Fr raw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) raw[q] = data[G.gidx(threadIdx.x + q * NTT_THREADS)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) T.put(threadIdx.x + q * NTT_THREADS, FrD::load_red(&raw[q]));
+    } else {
+        for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) T.put(li, FrD::load_red(&data[G.gidx(li)]));
+    }
+    __syncthreads();
+    ntt_tile_stages<true>(T, G, tw_inv, threadIdx.x, blockDim.x, BlockSync{});   // bounds: 2.01 + 2 k
+    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+        const size_t g = G.gidx(li);
+        const FrD sc = FrD::load_canon(&hi[g >> lo_bits]) * FrD::load_canon(&lo[g & lomask]);
+        T.put(li, T.get(li) * sc);   // a product: below 1.2 p whatever k was
+    }
+    __syncthreads();
+    ntt_tile_stages<false>(T, G, tw_fwd, threadIdx.x, blockDim.x, BlockSync{});
+    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) T.get(li).reduce().store(&data[G.gidx(li)]);
+}
+
+// The LAST pass of the three coset transforms (contiguous tiles, low stages, bit-reversed out) and the quotient
+//     e = (a b - c) / Z(g)     as a plain integer (the h multiexp's scalar)
+// in one kernel: the tiles of c, b, a go through the same LDS buffer one after the other, every thread keeps its
+// four results of c and b in registers (packed, 2 x 32) until a's are there.  full_k > 0 (domains of one tile, 2^10 and
+// below): the whole H pipeline of a tile -- inverse transform (full_k DIT stages), coset scaling, coset transform -- runs
+// in front, so such a proof's H is ONE launch.
+// A thread parks its results of c and b in its own elements of those vectors (scratch by then; the same thread reads
+// them back, so no barrier) -- holding them in registers instead was tried: 174 VGPRs, two workgroups per CU.
+__global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_tail3(const Fr* __restrict__ a, Fr* __restrict__ b,
+                                                           Fr* __restrict__ c, const FrLimbs* __restrict__ tw_fwd,
+                                                           const FrLimbs* __restrict__ tw_inv, int log_m, int k, int j, int full,
+                                                           const Fr* __restrict__ hi, const Fr* __restrict__ lo, int lo_bits,
+                                                           Fr zinv_int, Fr* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsTile T{reinterpret_cast<uint32_t*>(smem)};
+    const TileGeom G = TileGeom::make(log_m, 0, k, j, 1, blockIdx.x);
+    const uint32_t tile_elems = G.elems();
+    const size_t lomask = ((size_t)1 << lo_bits) - 1;
+#pragma unroll 1
+    for (int v = 0; v < 3; v++) {
+        const Fr* d = v == 0 ? c : v == 1 ? b : a;
+        if (tile_elems == 4u * NTT_THREADS) {
+            Fr raw[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) raw[q] = d[G.hbase + threadIdx.x + q * NTT_THREADS];
+#pragma unroll
+            for (int q = 0; q < 4; q++) T.put(threadIdx.x + q * NTT_THREADS, FrD::load_red(&raw[q]));
+        } else {
+            for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) T.put(li, FrD::load_red(&d[G.hbase + li]));
+        }
+        __syncthreads();
+        if (full) {
+            ntt_tile_stages<true>(T, G, tw_inv, threadIdx.x, blockDim.x, BlockSync{});
+            for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+                const size_t g = G.hbase + li;
+                const FrD sc = FrD::load_canon(&hi[g >> lo_bits]) * FrD::load_canon(&lo[g & lomask]);
+                T.put(li, T.get(li) * sc);
+            }
+            __syncthreads();
+        }
+        ntt_tile_stages<false>(T, G, tw_fwd, threadIdx.x, blockDim.x, BlockSync{});
+        if (v < 2) {
+            Fr* parkv = v == 0 ? c : b;
+            for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) T.get(li).reduce().store(&parkv[G.hbase + li]);
+            __syncthreads();   // the next vector's loads overwrite the tile
+        }
+    }
+    const FrD z = FrD::load_canon(&zinv_int);
+    for (uint32_t li = threadIdx.x; li < tile_elems; li += blockDim.x) {
+        const size_t g = G.hbase + li;
+        const FrD ab = T.get(li).reduce() * FrD::load_red(&b[g]);
+        // an M261 residue times a plain integer is the plain product: (a b - c) / Z leaves Montgomery form here
+        (FrD::sub<3>(ab, FrD::load_red(&c[g])) * z).canonical().store(&out[g]);
+    }
+}
+
+// e = (a b - c) / Z(g) as a plain integer, element-wise (the unfused form of k_ntt_tail3's last step)
+__global__ void __launch_bounds__(256) k_h_quotient(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
+                                                    size_t n, Fr zinv_int, Fr* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FrD ab = FrD::load_red(&a[i]) * FrD::load_red(&b[i]);
+    (FrD::sub<3>(ab, FrD::load_red(&c[i])) * FrD::load_canon(&zinv_int)).canonical().store(&out[i]);
 }
 
 __global__ void __launch_bounds__(256) k_bitrev(Fr* __restrict__ data, int log_m) {
@@ -364,19 +407,25 @@ static PassFuse no_fuse() {
     return f;
 }
 
+// The transform kernels' dynamic-LDS limit is a per-device function attribute: set once per context (a host may open
+// several devices; a process-wide flag would leave the second device without it).
+static int ntt_kernel_attributes(Ctx* ctx) {
+    if (ctx->ntt_attr_set) return ZG_OK;
+    const int bytes = 36 << NTT_LOG_TILE;
+    ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_mid, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_tail3, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->ntt_attr_set = true;
+    return ZG_OK;
+}
+
 // All passes of one transform.  DIF: natural in -> bit-reversed out (stages high -> low); DIT: bit-reversed in ->
 // natural out (stages low -> high).  `first` / `last` carry the element-wise work fused into the first pass's
 // loads / the last pass's stores.
 template <bool DIT>
 static int run_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, const PassFuse& first, const PassFuse& last) {
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-        ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        36 << NTT_LOG_TILE));
-        ZG_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        36 << NTT_LOG_TILE));
-        lds_attr_set = true;
-    }
+    ZG_TRY(ntt_kernel_attributes(ctx));
     // split the log_m stages into passes of (nearly) equal size <= NTT_KMAX
     int np = ((int)log_m + NTT_KMAX - 1) / NTT_KMAX;
     if (np < 1) np = 1;
@@ -527,6 +576,116 @@ int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out)
     post.out = d_h_out;
     if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
     ZG_TRY(run_passes<true>(ctx, d_a, T->tw_inv.as<FrLimbs>(), log_m, pre_m, post));
+    return ZG_OK;
+}
+
+// ---- H in EVALUATION form ---------------------------------------------------------------------------------------
+// bellman ends with icoset_fft and multiplies the COEFFICIENTS h_i into the h query.  The multiexp is linear, so the
+// last transform can be moved into the bases once per key (heval.hip: h_eval_i = sum_j M_ij H_j, a DFT over the group):
+//     sum_i h_i H_i  =  sum_p e[p] H_eval[p],      e[p] = ((A B - C) / Z)(g omega^bitrev(p))
+// and a proof needs six transforms instead of seven, with no pass over H's coefficients at all.  Per vector:
+//     DIT passes 0 .. L-2 | k_ntt_mid (last DIT pass + coset scaling + first DIF pass) | DIF passes L-2 .. 1
+// then ONE k_ntt_tail3 for the last DIF pass of a, b and c with the quotient in LDS: 4 L - 3 launches (13 at 2^22) where
+// the coefficient form takes 7 L (21).  Domains of one tile (2^10 and below): one launch.
+// The stage partition is listed low -> high; the top pass is the largest (k_ntt_mid runs it twice per load).
+struct StagePlan {
+    int n;
+    int k[8], s_lo[8];
+};
+static StagePlan stage_plan(uint32_t log_m) {
+    StagePlan P{};
+    P.n = ((int)log_m + NTT_KMAX - 1) / NTT_KMAX;
+    if (P.n < 1) P.n = 1;
+    int remaining = (int)log_m;
+    for (int p = P.n; p > 0; p--) {   // from the top: ceil first
+        const int k = (remaining + p - 1) / p;
+        P.k[p - 1] = k;
+        remaining -= k;
+    }
+    int s = 0;
+    for (int p = 0; p < P.n; p++) {
+        P.s_lo[p] = s;
+        s += P.k[p];
+    }
+    return P;
+}
+static void pass_geometry(uint32_t log_m, int s_lo, int k, int* j, int* contiguous) {
+    if (s_lo == 0) {
+        *contiguous = 1;
+        *j = NTT_LOG_TILE - k;
+        if (k + *j > (int)log_m) *j = (int)log_m - k;
+    } else {
+        *contiguous = 0;
+        *j = NTT_LOG_TILE - k;
+        if (*j > s_lo) *j = s_lo;
+    }
+    if (*j < 0) *j = 0;
+}
+template <bool DIT>
+static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int s_lo, int k) {
+    int j, contiguous;
+    pass_geometry(log_m, s_lo, k, &j, &contiguous);
+    const size_t tiles = ((size_t)1 << log_m) >> (k + j);
+    ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);
+    hipLaunchKernelGGL((k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
+                       (int)log_m, s_lo, k, j, contiguous, no_fuse());
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+// a, b, c: device form (M261, reduce()d), row i at index bitrev(i), zero padded; clobbered.  d_e_out: m plain integers,
+// e[p] = the quotient's value at g * omega^bitrev(p) -- the scalars that go with the key's h_eval bases.
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out) {
+    NttTables* T;
+    ZG_TRY(get_tables(ctx, log_m, &T));
+    if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
+    ZG_TRY(ntt_kernel_attributes(ctx));
+    const FrLimbs *twi = T->tw_inv.as<FrLimbs>(), *twf = T->tw_fwd.as<FrLimbs>();
+    const Fr *hi = T->g_hi_minv.as<Fr>(), *lo = T->g_lo.as<Fr>();
+    const size_t m = (size_t)1 << log_m;
+    if (log_m <= (uint32_t)NTT_LOG_TILE) {   // the whole domain is one tile
+        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)6 * 64 << log_m, nullptr, ((uint64_t)6 * log_m << log_m) >> 1);
+        hipLaunchKernelGGL(k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
+                           (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out);
+        ZG_HIP(ctx, hipGetLastError());
+        return ZG_OK;
+    }
+    const StagePlan P = stage_plan(log_m);
+    const int L = P.n;   // >= 2 here
+    Fr* v[3] = {d_a, d_b, d_c};
+    for (int q = 0; q < 3; q++) {
+        for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p]));
+        {
+            int j, contiguous;
+            pass_geometry(log_m, P.s_lo[L - 1], P.k[L - 1], &j, &contiguous);
+            const size_t tiles = m >> (P.k[L - 1] + j);
+            ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)2 * P.k[L - 1] << log_m) >> 1);
+            hipLaunchKernelGGL(k_ntt_mid, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
+                               v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits);
+            ZG_HIP(ctx, hipGetLastError());
+        }
+        for (int p = L - 2; p >= 1; p--) ZG_TRY(run_one_pass<false>(ctx, v[q], twf, log_m, P.s_lo[p], P.k[p]));
+    }
+    {
+        int j, contiguous;
+        pass_geometry(log_m, 0, P.k[0], &j, &contiguous);
+        const size_t tiles = m >> (P.k[0] + j);
+        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)4 * 32 << log_m, nullptr, ((uint64_t)3 * P.k[0] << log_m) >> 1);
+        hipLaunchKernelGGL(k_ntt_tail3, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream, d_a, d_b,
+                           d_c, twf, twi, (int)log_m, P.k[0], j, 0, hi, lo, T->lo_bits, T->zinv_int, d_e_out);
+        ZG_HIP(ctx, hipGetLastError());
+    }
+    return ZG_OK;
+}
+
+// What heval.hip needs of the tables: omega^-i in limb form (i < m/2) and the two-level tables of g^-i / m
+int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits) {
+    NttTables* T;
+    ZG_TRY(get_tables(ctx, log_m, &T));
+    *tw_inv = T->tw_inv.as<FrLimbs>();
+    *gi_lo = T->gi_lo.as<Fr>();
+    *gi_hi_int = T->gi_hi_canon.as<Fr>();
+    *lo_bits = T->lo_bits;
     return ZG_OK;
 }
 

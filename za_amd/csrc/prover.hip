@@ -7,6 +7,8 @@
 // final group arithmetic.  There is no CPU fallback: zg_init fails without a GPU.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <chrono>
 #include <thread>
 #include <memory>
@@ -172,8 +174,86 @@ __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, co
     if (!d.is_zero_mod_p()) atomicMin(first_bad, (unsigned long long)row);
 }
 
+// A few persistent host threads for the one piece of per-proof host work that is worth spreading: packing a
+// bit-heavy witness before it crosses PCIe (zg_prove).  parallel_for(n, fn) runs fn(0) .. fn(n - 1) on the workers
+// and the calling thread and returns when all are done.
+class WorkerPool {
+public:
+    explicit WorkerPool(int n_threads) {
+        for (int i = 0; i < n_threads; i++) th.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    int threads() const { return (int)th.size() + 1; }
+    void parallel_for(int n_tasks, const std::function<void(int)>& f) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            fn = &f;
+            total = n_tasks;
+            next.store(0);
+            busy = (int)th.size();
+            gen++;
+        }
+        cv.notify_all();
+        run();
+        std::unique_lock<std::mutex> lock(mu);
+        cv_done.wait(lock, [this] { return busy == 0; });
+        fn = nullptr;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= total) break;
+            (*fn)(i);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            run();
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                busy--;
+            }
+            cv_done.notify_one();
+        }
+    }
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)>* fn = nullptr;
+    int total = 0, busy = 0;
+    std::atomic<int> next{0};
+    uint64_t gen = 0;
+    bool stop = false;
+};
+
 struct ProveWs {
     DevBuf abc[3], h, wcls, w;
+    // zg_prove's host-side packing (see there): pool, per-slice lists, pinned staging of the packed form
+    std::unique_ptr<WorkerPool> pool;
+    struct PackSlice {
+        std::vector<uint32_t> idx;
+        std::vector<uint8_t> val;
+        size_t count = 0, offset = 0;
+    };
+    std::vector<PackSlice> slices;
+    uint8_t* stage = nullptr;   // pinned: [classes | other_index | others32]
+    size_t stage_bytes = 0;
     DevBuf pk_cls, pk_idx, pk_val;   // zg_prove_packed: the packed witness as uploaded
     // wcls: one class byte per witness value (k_witness_classes), shared by the evaluator and the witness multiexps.
     // wcls_for: the witness it was computed from; wcls_fresh: computed inside the current API call (the evaluator
@@ -187,6 +267,7 @@ struct ProveWs {
     hipEvent_t bad_ev = nullptr;
     bool bad_pending = false;
     ~ProveWs() {
+        if (stage) (void)hipHostFree(stage);
         if (bad_host) (void)hipHostFree(bad_host);
         if (bad_ev) (void)hipEventDestroy(bad_ev);
     }
@@ -522,7 +603,7 @@ extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) try {
 }
 extern "C" const char* zg_profile_name(int id) {
     static const char* names[] = {"msm_accumulate_g1", "msm_accumulate_g2", "msm_digit_sort", "msm_bucket_reduce",
-                                  "ntt_pass", "ntt_pointwise", "r1cs_eval"};
+                                  "ntt_pass", "ntt_pointwise", "r1cs_eval", "msm_accumulate_g1_dense"};
     return id >= 0 && id < PROF_COUNT ? names[id] : "";
 }
 
@@ -1214,7 +1295,8 @@ static int gate_events(zg_ctx* ctx) {
 }
 
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
-static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr) {
+static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr,
+                           bool eval_form = false) {
     const size_t m = (size_t)1 << r->log_m;
     ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
@@ -1224,6 +1306,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
     if (ev_eval_done) ZG_HIP(ctx, hipEventRecord(ev_eval_done, ctx->stream));
+    if (eval_form) return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
@@ -1232,6 +1315,20 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_h_out));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timings[1] = 0;
+    ctx->timings[2] = now_ms() - t0;   // R1CS evaluation + H
+    return witness_verdict(ctx);
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+
+extern "C" int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_e_out) try {
+    if (!ctx || !r || !d_e_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    double t0 = now_ms();
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_e_out, nullptr, /*eval_form=*/true));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timings[1] = 0;
     ctx->timings[2] = now_ms() - t0;   // R1CS evaluation + H
@@ -1276,12 +1373,38 @@ struct QueryUse {
     uint64_t n;
     const uint8_t* cls = nullptr;   // class bytes addressed like `scalars` (MsmDesc::cls)
 };
-static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask) {
+// The h query in evaluation form (heval.hip), built on first use: unsharded keys only (the group transform needs the
+// whole query); ZA_AMD_H_EVAL=0 keeps bellman's coefficient form (seven transforms per proof).
+static bool h_eval_allowed(const zg_params* p) {
+    const char* e = getenv("ZA_AMD_H_EVAL");   // read per key (tests switch it between key loads)
+    const bool off = e && atoi(e) == 0;
+    return !off && p->world == 1;
+}
+static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    if (p->h_eval_state == 1 && p->h_eval_log_m == log_m) return ZG_OK;
+    p->h_eval.release();
+    p->fbw_he.buf.release();
+    p->fbw_he.state = 0;
+    p->h_eval_state = -1;
+    const uint64_t m = (uint64_t)1 << log_m;
+    if (!h_eval_allowed(p) || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
+    if (p->h_eval.alloc(m * sizeof(G1Affine)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZG_OK;   // no room: the coefficient form is used
+    }
+    ZG_TRY(h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, p->h_eval.as<G1Affine>()));
+    p->h_eval_log_m = log_m;
+    p->h_eval_state = 1;
+    return ZG_OK;
+}
+
+static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask, bool h_eval_form = false) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     static const int order[5] = {4, 0, 1, 2, 3};
     for (int oi = 0; oi < 5; oi++) {
         const int k = order[oi];
-        auto& t = p->fbw[k];
+        auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
         const uint64_t n = use[k].n;
         if (!(mask & (1u << k)) || n == 0) continue;
         if (k != 0 && !use[k].scalars) continue;   // zg_params_prepare without a witness: only the h table
@@ -1387,7 +1510,7 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
 extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) try {
     if (!p || which < 0 || which > 4 || !kind || !bytes) return ZG_E_INVALID_ARG;
     std::lock_guard<std::mutex> lock(p->fbw_mu);
-    const auto& t = p->fbw[which];
+    const auto& t = which == 0 && p->fbw_he.state == 1 ? p->fbw_he : p->fbw[which];
     *kind = t.state == 1 ? (t.kind == 1 ? 2 : 1) : 0;
     *bytes = t.state == 1 ? t.buf.bytes : 0;
     return ZG_OK;
@@ -1401,13 +1524,19 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     ZG_TRY(check_query_sizes(ctx, p, r));
     QueryUse use[5];
     ZG_TRY(query_uses(ctx, p, r, d_witness, nullptr, 0x1f, use));
-    return ensure_tables(ctx, p, use, 0x1f);
+    // zg_prove* takes H in evaluation form when the key allows it: then the table that matters is the one over the
+    // transformed bases (the coefficient-form table is still built on demand by the phase API)
+    ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
+    const bool eval_form = p->h_eval_state == 1 && p->h_eval_log_m == r->log_m;
+    if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, (uint64_t)1 << r->log_m};
+    return ensure_tables(ctx, p, use, 0x1f, eval_form);
 } catch (...) {
     return zg::on_exception(ctx);
 }
 
-extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
-                                    const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
+// h_eval_form: d_h_shard holds h_eval_dev's m scalars and the h multiexp runs over the key's h_eval bases
+static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const void* d_h_shard,
+                               unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES], bool h_eval_form) {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1428,13 +1557,15 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     }
     ws.wcls_armed = false;
     ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use, (mask & 0x1eu) ? ws.wcls.as<uint8_t>() : nullptr));
+    if (h_eval_form && (mask & 1u))
+        use[0] = QueryUse{p->h_eval.p, (const uint32_t*)d_h_shard, nullptr, (uint64_t)1 << r->log_m};
     if (use[0].n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
-    ZG_TRY(ensure_tables(ctx, p, use, mask));
+    ZG_TRY(ensure_tables(ctx, p, use, mask, h_eval_form));
     MsmDesc d1[4], d2;
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
         d.cls = k == 0 ? nullptr : use[k].cls;
-        const auto& t = p->fbw[k];
+        const auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
         if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
             d.quad_table = t.buf.p;
         } else if (use[k].n && t.state == 1 && t.n == use[k].n) {
@@ -1458,6 +1589,10 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
     jac_bytes(partials + 384, b2_acc);
     ctx->timings[3] = now_ms() - t0;
     return witness_verdict(ctx);
+}
+extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
+                                    const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
+    return prove_partials_impl(ctx, p, r, d_witness, d_h_shard, mask, partials, false);
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -1556,17 +1691,20 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
         ProveWs& ws;
         ~ClassGuard() { ws.wcls_armed = ws.wcls_fresh = ws.bad_pending = false; }
     } class_guard{prove_ws(ctx)};
+    // H in evaluation form where the key has (or can get) its transformed h bases: six transforms instead of seven
+    ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
+    const bool eval_form = p->h_eval_state == 1 && p->h_eval_log_m == r->log_m;
     ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
-    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1]));
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form));
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
     ctx->ev_witness = ctx->gate_w;
     ctx->ev_h = ctx->gate_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
-    int rc_p = zg_prove_partials_dev(ctx, p, r, d_witness, dh.p, partials);
+    int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form);
     ctx->ev_witness = ctx->ev_h = nullptr;
     ctx->witness_gate_armed = false;
     ZG_TRY(rc_p);
@@ -1584,6 +1722,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     return zg::on_exception(ctx);
 }
 
+static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent);
 extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
                         const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
@@ -1598,9 +1737,12 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     ZG_HIP(ctx, dw.reserve(nv * 32));
     // (A two-part upload with the l / a / b multiexps over the first half's positions started early was built and
     // measured in round 2: slower, and eleven streams on eight hardware queues can deadlock -- DESIGN.md section 4.2.)
-    ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    bool packed = false;
+    size_t sent = nv * 32;
+    ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, &sent));   // a bit-heavy witness crosses PCIe in packed form
+    if (!packed) ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
     int rc = zg_prove_dev(ctx, p, r, dw.p, r_le, s_le, proof_out);
-    ctx->timings[0] = (double)(nv * 32);   // bytes uploaded (the copy is not timed separately: it is in [5])
+    ctx->timings[0] = (double)sent;   // bytes uploaded (the copy is not timed separately: it is in [5])
     ctx->timings[5] = now_ms() - t0;
     return rc;
 } catch (...) {
@@ -1608,6 +1750,127 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
 }
 
 // ---- packed witness (see include/za_amd.h)
+// device side: the packed form crosses PCIe, two kernels rebuild the 32-byte array in the ctx's workspace
+static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const uint32_t* other_index, const uint8_t* others32,
+                         size_t n_others) {
+    ProveWs& ws = prove_ws(ctx);
+    ZG_HIP(ctx, ws.w.reserve(nv * 32));
+    ZG_HIP(ctx, ws.pk_cls.reserve((nv + 3) / 4));
+    ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (nv + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), nv,
+                       ws.w.as<Fr>());
+    if (n_others) {
+        ZG_HIP(ctx, ws.pk_idx.reserve(n_others * 4));
+        ZG_HIP(ctx, ws.pk_val.reserve(n_others * 32));
+        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_idx.p, other_index, n_others * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_val.p, others32, n_others * 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_unpack_others, dim3((unsigned)((n_others + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ws.pk_idx.as<uint32_t>(), ws.pk_val.as<Fr>(), n_others, ws.w.as<Fr>());
+    }
+    ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+
+// zg_prove's host side for a witness that is mostly zeros and ones (a SHA-256 circuit: > 99 %; config 4: 97 %): the
+// 32 (l + v)-byte upload is the one stretch of a proof in which the GPU idles (2.3 ms of 14 at 2^22), and most of it
+// carries zeros.  A few host threads turn the array into the packed form -- 2 bits per value plus (index, value) of
+// everything else -- at memory speed, and 3 % of the bytes cross PCIe.  Returns false (nothing queued) when the witness
+// is not of that kind: then it is uploaded as it is.  ZA_AMD_PACK_THREADS sets the thread count (0 = never pack).
+static int host_pack_threads() {
+    static const int n = [] {
+        if (const char* e = getenv("ZA_AMD_PACK_THREADS")) return std::max(0, atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(16, std::max<unsigned>(1, hc / 2));
+    }();
+    return n;
+}
+static inline uint32_t value_class(const uint8_t* v) {
+    uint64_t q[4];
+    memcpy(q, v, 32);
+    return (q[1] | q[2] | q[3]) == 0 && q[0] <= 1 ? (uint32_t)q[0] : 2u;
+}
+static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {
+    *done = false;
+    const int nthreads = host_pack_threads();
+    if (nthreads <= 0 || nv < ((size_t)1 << 17)) return ZG_OK;
+    {   // a cheap look first: 1024 evenly spread values; a witness of field elements is left alone
+        size_t others = 0;
+        const size_t step = nv / 1024;
+        for (size_t k = 0; k < 1024; k++) others += value_class(witness32 + 32 * (k * step)) == 2u;
+        if (others > 128) return ZG_OK;
+    }
+    ProveWs& ws = prove_ws(ctx);
+    if (!ws.pool || ws.pool->threads() != nthreads) ws.pool.reset(new WorkerPool(nthreads - 1));
+    const size_t slice_vals = (size_t)1 << 16;   // 2 MiB of witness per task
+    const int n_slices = (int)((nv + slice_vals - 1) / slice_vals);
+    const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
+    const size_t cls_bytes = (nv + 3) / 4;
+    const size_t need = ((cls_bytes + 63) & ~(size_t)63) + max_others * 36 + 64;
+    if (ws.stage_bytes < need) {
+        if (ws.stage) (void)hipHostFree(ws.stage);
+        ws.stage = nullptr;
+        ws.stage_bytes = 0;
+        ZG_HIP(ctx, hipHostMalloc((void**)&ws.stage, need, hipHostMallocDefault));
+        ws.stage_bytes = need;
+    }
+    if ((int)ws.slices.size() < n_slices) ws.slices.resize(n_slices);
+    uint8_t* classes = ws.stage;
+    uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage + ((cls_bytes + 63) & ~(size_t)63));
+    uint8_t* val_out = reinterpret_cast<uint8_t*>(idx_out + max_others);
+    std::atomic<size_t> total{0};
+    std::atomic<bool> abort{false};
+    ws.pool->parallel_for(n_slices, [&](int si) {
+        ProveWs::PackSlice& sl = ws.slices[si];
+        sl.count = 0;
+        if (abort.load(std::memory_order_relaxed)) return;
+        const size_t lo = (size_t)si * slice_vals, hi = std::min(nv, lo + slice_vals);
+        const size_t cap = slice_vals / 4;   // a slice denser than 25 % ends the attempt
+        if (sl.idx.size() < cap) {
+            sl.idx.resize(cap);
+            sl.val.resize(cap * 32);
+        }
+        size_t k = 0;
+        for (size_t i = lo; i < hi; i += 4) {   // slice bounds are multiples of 4: one class byte per group
+            uint32_t byte = 0;
+            const size_t e = std::min(hi, i + 4);
+            for (size_t j = i; j < e; j++) {
+                const uint8_t* v = witness32 + 32 * j;
+                const uint32_t c = value_class(v);
+                byte |= c << (2 * (j - i));
+                if (c == 2u) {
+                    if (k == cap) {
+                        abort.store(true);
+                        return;
+                    }
+                    sl.idx[k] = (uint32_t)j;
+                    memcpy(&sl.val[32 * k], v, 32);
+                    k++;
+                }
+            }
+            classes[i >> 2] = (uint8_t)byte;
+        }
+        sl.count = k;
+        if (total.fetch_add(k) + k > max_others) abort.store(true);
+    });
+    if (abort.load()) return ZG_OK;
+    size_t n_others = 0;
+    for (int si = 0; si < n_slices; si++) {
+        ws.slices[si].offset = n_others;
+        n_others += ws.slices[si].count;
+    }
+    if (n_others > max_others) return ZG_OK;
+    ws.pool->parallel_for(n_slices, [&](int si) {   // the slices' lists, back to back, into the pinned staging buffer
+        const ProveWs::PackSlice& sl = ws.slices[si];
+        if (!sl.count) return;
+        memcpy(idx_out + sl.offset, sl.idx.data(), sl.count * 4);
+        memcpy(val_out + 32 * sl.offset, sl.val.data(), sl.count * 32);
+    });
+    ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
+    *done = true;
+    *bytes_sent = cls_bytes + n_others * 36;
+    return ZG_OK;
+}
+
 extern "C" int zg_witness_pack(const uint8_t* witness32, size_t n, uint8_t* classes, uint32_t* other_index,
                                uint8_t* others32, size_t cap, size_t* n_others) try {
     if (!witness32 || !classes || !n_others || (cap && (!other_index || !others32))) return ZG_E_INVALID_ARG;
@@ -1669,20 +1932,7 @@ extern "C" int zg_prove_packed(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         if ((classes[0] & 3u) != 1u) return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: variable 0 must be ONE");
     }
     ProveWs& ws = prove_ws(ctx);
-    ZG_HIP(ctx, ws.w.reserve(nv * 32));
-    ZG_HIP(ctx, ws.pk_cls.reserve((nv + 3) / 4));
-    ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (nv + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), nv,
-                       ws.w.as<Fr>());
-    if (n_others) {
-        ZG_HIP(ctx, ws.pk_idx.reserve(n_others * 4));
-        ZG_HIP(ctx, ws.pk_val.reserve(n_others * 32));
-        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_idx.p, other_index, n_others * 4, hipMemcpyHostToDevice, ctx->stream));
-        ZG_HIP(ctx, hipMemcpyAsync(ws.pk_val.p, others32, n_others * 32, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_unpack_others, dim3((unsigned)((n_others + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ws.pk_idx.as<uint32_t>(), ws.pk_val.as<Fr>(), n_others, ws.w.as<Fr>());
-    }
-    ZG_HIP(ctx, hipGetLastError());
+    ZG_TRY(upload_packed(ctx, nv, classes, other_index, others32, n_others));
     int rc = zg_prove_dev(ctx, p, r, ws.w.p, r_le, s_le, proof_out);
     ctx->timings[0] = (double)((nv + 3) / 4 + n_others * 36);   // bytes uploaded
     ctx->timings[5] = now_ms() - t0;
