@@ -125,36 +125,100 @@ def cpu_baseline(ctx, args):
                       % (threads, lg, dt, tm[0], tm[1], tm[2], ok)}
 
 
-def acc_roofline(prof, traffic=None, ipm=None):
-    """roofline object for k_accumulate<Fq> from the level-1 HIP-event profile of a timed region."""
-    acc_ms, acc_n, acc_bytes, acc_units = prof["msm_accumulate_g1"]
-    if not acc_n:
+VALU_PEAK_NOTE = ("tools/ubench_valu.hip on this chip (profiles/r02_ubench_fmul.txt): 467.5 G wave-level v_mad_u64_u32 / s "
+                  "measured; the nominal figure 1024 SIMDs x 2.4 GHz / 4 cycles = 614 G is given beside it "
+                  "(MI355X_MICROARCH.md has no integer issue rates)")
+VALU_ISSUE_NOMINAL = 1024 * 2.4e9 / 4 * 64   # lane multiply-adds / s at the nominal clock, quarter rate
+
+
+def _acc_class(prof, key):
+    ms, n, nbytes, units = prof.get(key, (0.0, 0, 0, 0))
+    if not n:
         return None
-    achieved = acc_bytes / (acc_ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "frac_of_measured_copy_ceiling": achieved / 6290.0, "traffic": traffic,
-            "launches": acc_n, "avg_launch_ms": acc_ms / acc_n, "algorithmic_bytes_per_launch": acc_bytes / acc_n}
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    mads = units * MADS_PER_MIXED_ADD
+    return {"launches": n, "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": nbytes / n,
+            "mixed_adds_per_launch": units / n, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+            "alu_frac_of_measured_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_PEAK,
+            "alu_frac_of_nominal_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_NOMINAL}
+
+
+def acc_roofline(prof, pmc=None):
+    """roofline object for k_accumulate<Fq> from the level-1 HIP-event profile of a timed region.  The kernel serves two
+    classes of job: the h multiexp (`h_dense`: every point of the launch reaches the kernel -- the honest figure, and the one
+    the top-level fields carry) and the witness queries' G1 jobs (`witness`: credited 96 B for every position of the
+    query although a zero scalar never reaches the kernel).  `blended` is round 2's single number over both.
+    pmc: {"traffic": bytes per launch, "valu_per_add": ..., "source": ...} measured for THIS workload, or None."""
+    dense, wit = _acc_class(prof, "msm_accumulate_g1_dense"), _acc_class(prof, "msm_accumulate_g1")
+    main = dense or wit
+    if not main:
+        return None
+    roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation), launches of the h multiexp" if dense
+            else "k_accumulate<Fq> (G1 bucket accumulation)",
+            "achieved": main["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": main["frac"],
+            "frac_of_measured_copy_ceiling": main["achieved"] / 6290.0,
+            "traffic": pmc["traffic"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
+            "launches": main["launches"], "avg_launch_ms": main["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": main["algorithmic_bytes_per_launch"],
+            "by_job_class": {"h_dense": dense, "witness": wit}}
+    if dense and wit:
+        ms = prof["msm_accumulate_g1_dense"][0] + prof["msm_accumulate_g1"][0]
+        nb = prof["msm_accumulate_g1_dense"][2] + prof["msm_accumulate_g1"][2]
+        nl = prof["msm_accumulate_g1_dense"][1] + prof["msm_accumulate_g1"][1]
+        roof["by_job_class"]["blended"] = {"launches": nl, "avg_launch_ms": ms / nl, "achieved": nb / (ms * 1e-3) / 1e9,
+                                           "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # secondary, integer-issue ceiling (DESIGN.md section 4): the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
-    mads = acc_units * MADS_PER_MIXED_ADD
-    roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "achieved": mads / (acc_ms * 1e-3), "peak": VALU_ISSUE_PEAK,
-                             "frac": mads / (acc_ms * 1e-3) / VALU_ISSUE_PEAK, "mixed_adds_per_launch": acc_units / acc_n}
-    if ipm:
-        roof["alu_secondary"]["valu_instructions_per_mixed_add"] = ipm
-        roof["alu_secondary"]["issue_frac"] = acc_units * ipm / (acc_ms * 1e-3) / VALU_ISSUE_PEAK
+    roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "peak_measured": VALU_ISSUE_PEAK, "peak_nominal": VALU_ISSUE_NOMINAL,
+                             "peak_source": VALU_PEAK_NOTE, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
+                             "frac_of_measured": main["alu_frac_of_measured_issue_rate"],
+                             "frac_of_nominal": main["alu_frac_of_nominal_issue_rate"]}
+    if pmc and pmc.get("valu_per_add"):
+        roof["alu_secondary"]["valu_instructions_per_mixed_add"] = pmc["valu_per_add"]
+        roof["alu_secondary"]["valu_source"] = pmc["source"]
     return roof
 
 
-def profile_json(name, key):
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))
-        if os.path.exists(path):
-            try:
-                return json.load(open(path)).get(key)
-            except Exception:
-                return None
+def host_pack_threads():
+    """zg_prove's host-side packing threads (csrc/prover.hip host_pack_threads)."""
+    if os.environ.get("ZA_AMD_PACK_THREADS"):
+        return max(0, int(os.environ["ZA_AMD_PACK_THREADS"]))
+    return min(16, max(1, (os.cpu_count() or 2) // 2))
+
+
+def pmc_for(args):
+    """PMC figures are collected in separate rocprofv3 --pmc passes (tools/pmc_*.py) and only describe the workload they
+    were taken on: the default one.  Any other workload gets None -- nothing is pasted across workloads."""
+    if not (args.workload == "synthetic" and args.log_m == 22 and abs(args.bit_fraction - 0.97) < 1e-9 and args.seed == 0x5A):
+        return None
+    for rnd in ("r03", "r02"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)))
+            vi = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_valu_instructions.json" % rnd)))
+        except Exception:
+            continue
+        t = tr.get("msm_accumulate_g1_dense_bytes_per_launch") or tr.get("msm_accumulate_g1_bytes_per_launch")
+        return {"traffic": t, "valu_per_add": vi.get("k_accumulate_g1_valu_instructions_per_wave_mixed_add"),
+                "source": "profiles/%s_pmc_traffic.json + profiles/%s_pmc_valu_instructions.json (separate rocprofv3 --pmc passes of "
+                          "this workload, 2^22 config 4; not measured in this run)" % (rnd, rnd)}
     return None
+
+
+def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live):
+    """The H pipeline against the HBM roofline: algorithmic 64 B per element per transform."""
+    n_transforms = 6
+    alg = n_transforms * 64 * m
+    out = {"bound": "hbm", "kernel": "k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form: %d transforms in %d launches)"
+           % (n_transforms, passes), "algorithmic_bytes": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "h_pipeline_ms_in_proof": h_ms_live,
+           "achieved_in_proof": alg / (h_ms_live * 1e-3) / 1e9 if h_ms_live else None,
+           "frac_in_proof": alg / (h_ms_live * 1e-3) / 1e9 / HBM_PEAK_GBS if h_ms_live else None,
+           "note": "h_pipeline_ms_in_proof = HIP-event time of the transforms inside the timed proofs (they share the GPU with "
+                   "the witness multiexps); kernel_ms = sum of the transform kernels' own event times in the instrumented proofs"}
+    if kernel_ms and launches:
+        out.update({"kernel_ms": kernel_ms, "launches": launches, "achieved": alg / (kernel_ms * 1e-3) / 1e9,
+                    "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return out
 
 
 def main():
@@ -317,14 +381,18 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_ms = []
+    h_ms_acc = []
     for _ in range(args.steps):
         ts = time.perf_counter()
         proof = step()
         step_ms.append(round(1e3 * (time.perf_counter() - ts), 3))
+        if world == 1:
+            h_ms_acc.append(ctx.last_timings()["h_ms"])   # (a ctypes read of six doubles, outside the step's clock)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     phases = ctx.last_timings()
+    h_ms_live = float(np.mean(h_ms_acc)) if h_ms_acc else None
     phase_ms = {k: v / max(args.steps, 1) for k, v in phase_acc.items()}
     elapsed = max_over_ranks(elapsed)
     dist_line = None
@@ -560,7 +628,7 @@ def main():
                     "points_per_s_scalars_resident": k_msm * n_total / el_res, "ms_per_msm_scalars_resident": 1e3 * el_res / k_msm,
                     "sharding": "%d ranks x 2^%d/%d bases" % (world, args.msm_log_n, world) if world > 1 else "single GPU",
                     "table": {"gb": binfo["table_bytes"] / 1e9, "c": binfo["c"], "digits": binfo["nwin"]},
-                    "roofline": acc_roofline(prof_msm),
+                    "roofline": acc_roofline(prof_msm),   # (no PMC passes exist for this workload: traffic = null)
                     "note": "zg_msm_resident: 2^%d G1 bases resident (device form + fixed-base window table), uniform 253-bit "
                             "scalars uploaded from pinned host memory in 4 chunks overlapped with the 4 dependent parts of the "
                             "multiexp; *_scalars_resident = zg_msm_resident_dev" % args.msm_log_n}
@@ -570,8 +638,9 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-        roof = acc_roofline(prof, traffic=profile_json("pmc_traffic", "msm_accumulate_g1_bytes_per_launch"),
-                            ipm=profile_json("pmc_valu_instructions", "k_accumulate_g1_valu_instructions_per_wave_mixed_add"))
+        roof = acc_roofline(prof, pmc=pmc_for(args))
+        ntt_ms, ntt_n = prof_all["ntt_pass"][0] / n_break, prof_all["ntt_pass"][1] / n_break
+        roof_ntt = ntt_roofline(m, int(round(ntt_n)), ntt_ms, int(round(ntt_n)), h_ms_live) if world == 1 else None
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -592,15 +661,17 @@ def main():
                                    % (100 * args.bit_fraction, args.seed, args.log_m,
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
                                       else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
-                       "step": "zg_prove: witness (%d bytes) uploaded from pinned host memory inside every step, R1CS and key resident"
-                               % witness_bytes,
+                       "step": "zg_prove: witness (%d bytes, 32 B per value) in pinned host memory, handed over inside every step; "
+                               "R1CS and key resident.  A mostly-0/1 witness is packed by %d host threads before it crosses PCIe "
+                               "(%d bytes sent in the last step); H in evaluation form (6 transforms; h bases transformed once per key)"
+                               % (witness_bytes, host_pack_threads(), int(phases.get("upload_bytes", 0))),
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
+            "roofline_ntt": roof_ntt,
             "step_ms": step_ms, "ms_median": float(np.median(step_ms)) if step_ms else None,
-            # a time without the R1CS evaluation, and the whole proof against the HBM roofline with the
-            # survey's algorithmic bytes 96(m-1) + 96 v + 96(l + d_A) + (96 + 160) d_B + 7 * 64 m
-            "prove_core_ms": (ms_per_step - phases["r1cs_eval_ms"]) if world == 1 and phases.get("r1cs_eval_ms") else None,
+            # the whole proof against the HBM roofline with the survey's algorithmic bytes
+            # 96(m-1) + 96 v + 96(l + d_A) + (96 + 160) d_B + 7 * 64 m (bellman's seven transforms)
             "prove_hbm": (lambda b: {"algorithmic_bytes": b, "achieved": b / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                      "frac": b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS})(
                 96 * (m - 1) + 96 * n_aux + 96 * n_a + 256 * n_b + 448 * m),

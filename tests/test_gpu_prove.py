@@ -699,6 +699,7 @@ def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch):
     queries pairs of opposite points in neighbouring positions (their subset sum is the identity), rows
     (x + y) * 1 = z pairs of equal points; proof against the C oracle, the plain schedule, and the pairing check."""
     import za_amd
+    monkeypatch.setenv("ZA_AMD_SMALL_LOG_N", "0")   # (jobs of this size otherwise take the small-job mode: window tables)
     rng = np.random.default_rng(7)
     w = [1, 1]                       # ONE, one public input (a constant 1)
     cons = []
@@ -829,7 +830,8 @@ def test_sha256_merkle_circuit_setup_prove_verify(ctx):
     pub = [int.from_bytes(root[:16], "big"), int.from_bytes(root[16:], "big")]
     assert za_amd.verify(pbytes, got, pub) is True
     assert za_amd.verify(pbytes, got, [pub[0], pub[1] ^ 1]) is False
-    assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [2, 2, 2, 2]     # subset-sum tables on all witness queries
+    # subset-sum tables on the l and a queries; the b queries (fewer than 2^16 positions: latency-bound jobs) take window tables
+    assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [2, 2, 1, 1]
     P.close(); R.close()
 
 

@@ -38,6 +38,16 @@
 namespace zg {
 
 static constexpr int MAXWIN = 128;
+// jobs up to this many points are latency bound: queued whole, planned from n (MsmJob::eager_small), and the key gets
+// window tables for all of its queries whatever the witness looks like (prover.hip ensure_tables)
+// (ZA_AMD_SMALL_LOG_N overrides the 2^16; 0 turns the small-job mode off.  Read per call: tests switch it.)
+size_t msm_small_n() {
+    if (const char* e = getenv("ZA_AMD_SMALL_LOG_N")) {
+        const int lg = atoi(e);
+        return lg <= 0 ? 0 : (size_t)1 << std::min(lg, 24);
+    }
+    return (size_t)1 << 16;
+}
 static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (upper limit; see item_sizes)
 
@@ -109,7 +119,33 @@ static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
 }
 // n_real scalars (neither 0 nor 1) out of n_table points.  Returns false when no table fits the budget or when
 // it would not beat the plain per-window plan by at least 8%.
-bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out) {
+// force: take the best table plan even if it does not beat the per-window plan by 8 % (small jobs: what a table buys them
+// is one bucket set and a host pass of c - 1 doublings instead of 254)
+bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force) {
+    if (force) {
+        // A small job is bound by the DEPTH of its chain of dependent additions (6 us each in G1, 19 us in G2), not by
+        // their number: about T + 1.25 mean / T in the accumulation and its bucket sums (T ~ sqrt(2 mean), see
+        // MsmJob::phase_b) plus two per reduction level, (c - 1) / 2 levels.  Wide digits win: few points per bucket.
+        double best = 1e300;
+        int bc = 0, bw = 0;
+        for (int c = 4; c <= 20; c++) {
+            const int nwin = (255 + c - 1) / c;
+            if ((double)n_table * nwin * (double)elem_bytes > (double)max_bytes) continue;
+            const double mean = (double)n_real * nwin / (double)(1u << (c - 1));
+            const double t = std::min(64.0, std::max(4.0, std::ceil(std::sqrt(2.0 * mean))));
+            const double depth = std::min(t, mean + 1.0) + 1.25 * mean / t + 2.0 * ((c - 1 + 1) / 2)
+                                 + 1e-7 * (double)(1u << (c - 1));   // ties: the smaller bucket set
+            if (depth < best) {
+                best = depth;
+                bc = c;
+                bw = nwin;
+            }
+        }
+        if (!bc) return false;
+        *c_out = bc;
+        *nwin_out = bw;
+        return true;
+    }
     double best_cost = 1e300;
     int bc = 0, bw = 0;
     for (int c = 4; c <= 23; c++) {
@@ -209,7 +245,9 @@ __global__ void __launch_bounds__(256) k_classify(const uint32_t* __restrict__ s
 //            [bin][tile] gives every tile a private output range per bin, ranks come from LDS atomics.
 //   level 2  k_part_local: one workgroup per bin sorts its segment by the low bucket bits in LDS,
 //            writes the per-bucket counts and the final (base index | sign) order.
-static constexpr int PART_TP = 4096;  // points per tile
+static constexpr int PART_TP = 4096;        // points per tile
+static constexpr int PART_TP_SMALL = 256;   // small jobs: one point per thread (a 4096-point job would otherwise be ONE
+                                            // workgroup walking 16 points x nwin digits per thread: 40 us instead of 5)
 
 __device__ __forceinline__ bool scalar_is_zero(const Scalar256& s) {
     return (s.w[0] | s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7]) == 0;
@@ -223,7 +261,7 @@ __device__ __forceinline__ bool scalar_is_one(const Scalar256& s) {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
                                               size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
-                                              int lb, uint32_t ntiles, uint32_t* __restrict__ tile_tab,
+                                              int lb, uint32_t ntiles, uint32_t tp, uint32_t* __restrict__ tile_tab,
                                               uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
                                               const uint8_t* __restrict__ wcls) {
     extern __shared__ uint32_t lds_bins[];
@@ -233,9 +271,9 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x)
         lds_bins[b] = MODE == 0 ? 0u : tile_tab[(size_t)b * ntiles + tile];
     __syncthreads();
-    const size_t base = (size_t)tile * PART_TP;
+    const size_t base = (size_t)tile * tp;
     const uint32_t lomask = (1u << lb) - 1u;
-    for (uint32_t k = threadIdx.x; k < (uint32_t)PART_TP; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < tp; k += blockDim.x) {
         const size_t i = base + k;
         const bool live = i < n;
         Scalar256 s;
@@ -495,10 +533,12 @@ __global__ void k_meta(const uint32_t* offsets, const uint32_t* item_off, uint32
 }
 
 // item -> key map for the regular keys (the ones key, last, is filled by a memset)
+// (with_last: small jobs queued without read-backs have no host-side range for that memset; their ones bucket holds
+// few items and the thread of the last key writes them)
 __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict__ item_off, uint32_t nkeys,
-                                                     uint32_t* __restrict__ item_key) {
+                                                     uint32_t* __restrict__ item_key, int with_last) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key + 1 >= nkeys) return;
+    if (key + (with_last ? 0u : 1u) >= nkeys) return;
     uint32_t lo = item_off[key], hi = item_off[key + 1];
     for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
 }
@@ -619,17 +659,23 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
 // Buckets split into more than HEAVY_ITEMS items (the top window of a small-c plan, or skewed
 // scalars) are folded by a whole workgroup first: partial[first item] receives the bucket sum, and the
 // leaf kernel reads only that.  heavy_list / heavy_cnt are filled by k_heavy_collect.
+// heavy_items: the per-job threshold (4 for throughput-bound jobs; small jobs, whose items are short, sum up to about
+// twice the mean bucket load serially, see MsmJob::phase_b).  force_key (or ~0u): a key listed whenever it holds an item --
+// the ones bucket of a job queued without read-backs, whose fold k_heavy_fold also copies to ones_out.
 static constexpr uint32_t HEAVY_ITEMS = 4;
-__global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restrict__ item_off, uint32_t nkeys_regular,
+__global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restrict__ item_off, uint32_t nkeys_listed,
+                                                       uint32_t heavy_items, uint32_t force_key,
                                                        uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= nkeys_regular) return;
-    if (item_off[key + 1] - item_off[key] > HEAVY_ITEMS) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
+    if (key >= nkeys_listed) return;
+    const uint32_t items = item_off[key + 1] - item_off[key];
+    if (items > heavy_items || (key == force_key && items > 0)) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
 }
 template <class F>
 __global__ void __launch_bounds__(128) k_heavy_fold(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
                                                     const uint32_t* __restrict__ heavy_cnt,
-                                                    const uint32_t* __restrict__ heavy_list) {
+                                                    const uint32_t* __restrict__ heavy_list, uint32_t ones_key,
+                                                    XYZZ<F>* __restrict__ ones_out) {
     using L = typename LazyOf<F>::L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_h);
@@ -648,7 +694,10 @@ __global__ void __launch_bounds__(128) k_heavy_fold(XYZZ<F>* __restrict__ partia
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) acc.store(&partial[lo]);
+        if (threadIdx.x == 0) {
+            acc.store(&partial[lo]);
+            if (key == ones_key) acc.store(ones_out);
+        }
         __syncthreads();
     }
 }
@@ -668,9 +717,9 @@ static constexpr uint32_t ROWSUM_CH = 1024;   // entries per k_rowsum block
 // one bucket's sum from its items (heavy buckets were folded into their first item)
 template <class L, class F>
 __device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
-                                               uint32_t key) {
+                                               uint32_t key, uint32_t heavy_items) {
     uint32_t lo = item_off[key], hi = item_off[key + 1];
-    if (hi - lo > HEAVY_ITEMS) hi = lo + 1;
+    if (hi - lo > heavy_items) hi = lo + 1;
     XYZZd<L> r = XYZZd<L>::inf();
     for (uint32_t i = lo; i < hi; i++) r = r.add(XYZZd<L>::load(&partial[i]));
     return r;
@@ -690,7 +739,7 @@ static constexpr uint32_t BITS_THREADS = 128;
 template <class F>
 __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
                                                              const uint32_t* __restrict__ item_off, uint32_t rows_in,
-                                                             uint32_t kw, uint32_t len_out, int f,
+                                                             uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
                                                              XYZZ<F>* __restrict__ out) {
     using L = typename LazyOf<F>::L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -705,8 +754,8 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
     const uint32_t child0 = (row * len_out + idx) << f;   // rows of len_out << f entries
     if (f == 1) {   // uniform; the last level of an odd bit count: two children, lane A does it all
         if (in_range && q == 0) {
-            XYZZd<L> c0 = in ? XYZZd<L>::load(&in[child0]) : bucket_sum<L, F>(partial, item_off, child0);
-            XYZZd<L> c1 = in ? XYZZd<L>::load(&in[child0 + 1]) : bucket_sum<L, F>(partial, item_off, child0 + 1);
+            XYZZd<L> c0 = in ? XYZZd<L>::load(&in[child0]) : bucket_sum<L, F>(partial, item_off, child0, heavy_items);
+            XYZZd<L> c1 = in ? XYZZd<L>::load(&in[child0 + 1]) : bucket_sum<L, F>(partial, item_off, child0 + 1, heavy_items);
             if (full) c1.store(outD);
             c0.add(c1).store(outS);
         }
@@ -716,8 +765,8 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
     XYZZd<L> lo = XYZZd<L>::inf(), hi = XYZZd<L>::inf();
     if (in_range) {
         const uint32_t ch = child0 + 2u * q;
-        lo = in ? XYZZd<L>::load(&in[ch]) : bucket_sum<L, F>(partial, item_off, ch);
-        hi = in ? XYZZd<L>::load(&in[ch + 1]) : bucket_sum<L, F>(partial, item_off, ch + 1);
+        lo = in ? XYZZd<L>::load(&in[ch]) : bucket_sum<L, F>(partial, item_off, ch, heavy_items);
+        hi = in ? XYZZd<L>::load(&in[ch + 1]) : bucket_sum<L, F>(partial, item_off, ch + 1, heavy_items);
     }
     XYZZd<L> r = lo.add(hi);                       // A: c0 + c1;  B: c2 + c3 (bit 1)
     (q == 0 ? hi : r).store(&lds[threadIdx.x]);    // A publishes c1, B its sum
@@ -806,12 +855,18 @@ struct MsmJob : MsmJobBase {
     size_t n;
     XYZZ<F>* out;
     bool dense = false;   // plan from n directly, no k_classify round trip
+    // A small job (see msm_batch5) is latency bound: it is planned from n as if every scalar were "real" and its whole
+    // chain is queued at once like a dense job's -- no classification or totals read-back -- but it keeps the ones
+    // bucket (a bit-heavy witness would otherwise pile its ones onto one bucket of window 0), reduced on the device
+    // by k_ones_sum from the device-side item range.
+    bool eager_small = false;
     const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
     uint32_t quad_base = 0;   // entry (relative to quad_table) of group 0's sums; 0 = n (the job covers the whole query)
     const Affine<F>* fbw_table = nullptr;   // fixed-base window table: [fbw_nwin][fbw_stride] affine points
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
     uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
+    uint32_t heavy_items = HEAVY_ITEMS;   // buckets of more items go through k_heavy_fold
     bool order_items = true;       // items sorted by length before the accumulation (not for small jobs)
     static constexpr uint32_t ITEM_ORDER_MIN = 16384;
     int acc_prof = -1;
@@ -839,7 +894,7 @@ struct MsmJob : MsmJobBase {
         if (!S.host) ZG_HIP(ctx, hipHostMalloc((void**)&S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
         grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 8);
         ZG_HIP(ctx, S.meta.reserve(64));
-        if (dense) {   // counts are taken as (0 zeros, 0 ones): the plan and the buffer bounds stay valid for any data
+        if (dense || eager_small) {   // counts are taken as (0 zeros, 0 ones): the plan and the buffer bounds stay valid for any data
             uint32_t* cls = reinterpret_cast<uint32_t*>(S.host);
             cls[0] = cls[1] = 0;
             eager = true;
@@ -879,6 +934,16 @@ struct MsmJob : MsmJobBase {
             }
             t_ones = T_ONES;
             if (n_ones / T_ONES < target / 2) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, n_ones / (target / 2)));
+            heavy_items = HEAVY_ITEMS;
+            if (eager_small || n <= msm_small_n()) {
+                // what counts for a small job is the number of dependent additions: T in a thread of k_accumulate, then
+                // up to heavy_items in bucket_sum.  T ~ sqrt(2 * mean load); buckets up to ~2.5 x the mean stay "light".
+                const double mean = (double)entries / (double)P.nkeys;
+                const uint32_t t = (uint32_t)std::min(64.0, std::max(4.0, std::ceil(std::sqrt(2.0 * mean))));
+                P.T = t;
+                heavy_items = (uint32_t)std::max(4.0, std::ceil(2.5 * mean / t));
+                if (eager_small) t_ones = 8;
+            }
             t_pack = P.T | (t_ones << 16);
         }
         ones_key = P.nkeys;  // one extra bucket after the kw * B regular ones
@@ -891,7 +956,8 @@ struct MsmJob : MsmJobBase {
         while (hb > 0 && (((size_t)P.kw << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
         const int lb = bbits - hb;
         const uint32_t nbins = ((uint32_t)P.kw << hb) + 1u;
-        const uint32_t ntiles = (uint32_t)((n + PART_TP - 1) / PART_TP);
+        const uint32_t tp = n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
+        const uint32_t ntiles = (uint32_t)((n + tp - 1) / tp);
         const size_t tab_n = (size_t)nbins * ntiles;
         const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
         // counts is indexed by key = bin << lb | low bits; the ones bin only uses low bits == 0
@@ -908,7 +974,7 @@ struct MsmJob : MsmJobBase {
         const uint32_t quad_n = quad_table && !fbw_table && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
         const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
+                           quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
                            d_cls);
         {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
@@ -921,7 +987,7 @@ struct MsmJob : MsmJobBase {
                                S.bsum.as<uint32_t>());
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
+                           quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
                            use_ones_bin, d_cls);
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
         const size_t lds2 = ((size_t)4 << lb) + 64;
@@ -942,8 +1008,9 @@ struct MsmJob : MsmJobBase {
         ZG_HIP(ctx, hipGetLastError());
         if (ev_sorted) ZG_HIP(ctx, hipEventRecord(ev_sorted, st));
         launched = true;
-        if (dense) {   // no ones bucket and a known bound on the item count: queue the rest without the read-back
-            items_bound = (uint32_t)std::min<size_t>(max_entries / P.T + nkeys, 0xffffffffu);
+        if (dense || eager_small) {   // a known bound on the item count: queue the rest without the read-back
+            // (every key's last item may be short: + nkeys; the ones bucket's items hold t_ones points)
+            items_bound = (uint32_t)std::min<size_t>(max_entries / P.T + (eager_small ? n / t_ones : 0) + nkeys, 0xffffffffu);
             chained = true;
             return phase_c();
         }
@@ -968,7 +1035,7 @@ struct MsmJob : MsmJobBase {
         {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               nkeys, S.item_key.as<uint32_t>());
+                               nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0);
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
                                               ones_hi - ones_lo, st));
@@ -1009,10 +1076,19 @@ struct MsmJob : MsmJobBase {
             ZG_HIP(ctx, S.heavy.reserve(((size_t)P.nkeys + 1) * 4));
             uint32_t* hcnt = S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES;   // zeroed with the histogram above
             uint32_t* hlist = S.heavy.as<uint32_t>();
-            hipLaunchKernelGGL(k_heavy_collect, dim3((P.nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               P.nkeys, hcnt, hlist);
+            // a job queued without read-backs folds its ones bucket here too (listed whenever it holds an item)
+            XYZZ<F>* ones_out = nullptr;
+            if (eager_small) {
+                ZG_HIP(ctx, S.ones[0].reserve(sizeof(XYZZ<F>)));
+                ones_out = S.ones[0].template as<XYZZ<F>>();
+                ZG_HIP(ctx, hipMemsetAsync(ones_out, 0, sizeof(XYZZ<F>), st));   // all zero = the identity
+            }
+            const uint32_t listed = eager_small ? nkeys : P.nkeys;
+            hipLaunchKernelGGL(k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
+                               listed, heavy_items, eager_small ? ones_key : ~0u, hcnt, hlist);
             hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
-                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist);
+                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist, eager_small ? ones_key : ~0u,
+                               ones_out);
         }
         const int bits = P.c - 1;
         red_nlev = 0;
@@ -1034,7 +1110,7 @@ struct MsmJob : MsmJobBase {
                 hipLaunchKernelGGL((k_bits_level<F>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
                                    dim3(BITS_THREADS), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
                                    S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
-                                   outp);
+                                   heavy_items, outp);
                 cur = outp;
                 red_rowbase[l] = (uint32_t)rb;   // finish(): rows of level l start here (after the kw S rows)
                 red_bitbase[l] = bb;
@@ -1047,7 +1123,9 @@ struct MsmJob : MsmJobBase {
         // cur: [kw] S, then one entry per bit-plane row, rows ordered [level][window][bit within level]
         // ---- ones bucket: its item sums form one row
         ones_ptr = nullptr;
-        if (ones_hi > ones_lo) {
+        if (eager_small) {
+            ones_ptr = S.ones[0].template as<XYZZ<F>>();   // written by k_heavy_fold above
+        } else if (ones_hi > ones_lo) {
             uint32_t cnt = ones_hi - ones_lo;
             const XYZZ<F>* in = S.partial.as<XYZZ<F>>() + ones_lo;
             int pp = 0;
@@ -1224,6 +1302,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
                                                hi - lo, out));
     j->dense = d.dense;
+    j->eager_small = !d.dense && hi - lo <= msm_small_n();
     j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
     if (d.quad_table) {
         j->quad_table = (const Affine<F>*)d.quad_table + lo;
@@ -1310,11 +1389,17 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // Priority order for the host's polling loop: the h parts (on the critical path once the NTT pipeline is done; a
     // small proof otherwise waits ~1 ms for the host to finish queueing the witness jobs' phases), then the G2 job
     // (the longest chain), then the G1 witness jobs.
+    // A small proof's jobs are all queued whole (eager): the G2 job first -- its chain of dependent additions is the
+    // longest (a G2 addition is 19 us of a wave's time) -- and the h job, which waits for the NTT pipeline anyway, last.
     MsmJobBase* jobs[16];
     int nj = 0;
-    for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
+    const bool small = g1[0].n <= msm_small_n() && g2.n <= msm_small_n();
+    if (!small)
+        for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
     jobs[nj++] = wj2.get();
     for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q].get();
+    if (small)
+        for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
     ZG_TRY(run_jobs(ctx, jobs, nj));
     G1XYZZ h = hout[0];
     for (int k = 1; k < parts; k++) h = h.add(hout[k]);

@@ -1433,7 +1433,8 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         size_t budget = (size_t)((double)avail * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
-        if (k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
+        const bool small = n <= msm_small_n();   // latency bound: always a window table (msm.hip MsmJob::eager_small)
+        if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             const size_t entries = msm_quad_entries(n);
             if (entries * elem > budget || entries >= (1ull << 31) || t.buf.alloc(entries * elem) != hipSuccess) {
@@ -1452,9 +1453,9 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         }
         // few real scalars leave few digits to save, and gathering them from an nwin-times larger table costs more
         // than that (measured at 2^22: b_g2 accumulation 1.5 -> 2.1 ms with 3% real scalars)
-        if (n_real < 64 || n_real * 2 < n) continue;
+        if (!small && (n_real < 64 || n_real * 2 < n)) continue;
         int c = 0, nwin = 0;
-        if (!msm_fbw_plan(n_real, n, budget, elem, &c, &nwin)) continue;
+        if (!msm_fbw_plan(small ? n : n_real, n, budget, elem, &c, &nwin, small)) continue;
         if (t.buf.alloc((size_t)nwin * n * elem) != hipSuccess) {
             (void)hipGetLastError();
             continue;   // no room: the plain per-window schedule is used
