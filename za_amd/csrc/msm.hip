@@ -740,7 +740,7 @@ template <class F>
 __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
                                                              const uint32_t* __restrict__ item_off, uint32_t rows_in,
                                                              uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
-                                                             XYZZ<F>* __restrict__ out) {
+                                                             uint32_t ones_row, uint32_t ones_key, XYZZ<F>* __restrict__ out) {
     using L = typename LazyOf<F>::L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per thread
@@ -752,10 +752,23 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
     XYZZ<F>* outS = out + (size_t)row * len_out + idx;
     XYZZ<F>* outD = out + ((size_t)rows_in + (size_t)row * f) * len_out + idx;   // + b * len_out for bit b
     const uint32_t child0 = (row * len_out + idx) << f;   // rows of len_out << f entries
+    // ones_row (leaf level of a small job, else ~0u): one more input row right after the S rows whose entries are the
+    // ITEM sums of the ones bucket (padded with the identity) -- a row that only needs summing, so the levels fold it
+    // along instead of a workgroup folding it on its own between the accumulation and the levels.
+    const bool ones = !in && in_range && row == ones_row;
+    const uint32_t ones_lo = ones ? item_off[ones_key] : 0u, ones_cnt = ones ? item_off[ones_key + 1] - ones_lo : 0u;
+    auto fetch = [&](uint32_t child) -> XYZZd<L> {
+        if (in) return XYZZd<L>::load(&in[child]);
+        if (ones) {
+            const uint32_t cl = child - ((row * len_out) << f);
+            return cl < ones_cnt ? XYZZd<L>::load(&partial[ones_lo + cl]) : XYZZd<L>::inf();
+        }
+        return bucket_sum<L, F>(partial, item_off, child, heavy_items);
+    };
     if (f == 1) {   // uniform; the last level of an odd bit count: two children, lane A does it all
         if (in_range && q == 0) {
-            XYZZd<L> c0 = in ? XYZZd<L>::load(&in[child0]) : bucket_sum<L, F>(partial, item_off, child0, heavy_items);
-            XYZZd<L> c1 = in ? XYZZd<L>::load(&in[child0 + 1]) : bucket_sum<L, F>(partial, item_off, child0 + 1, heavy_items);
+            XYZZd<L> c0 = fetch(child0);
+            XYZZd<L> c1 = fetch(child0 + 1);
             if (full) c1.store(outD);
             c0.add(c1).store(outS);
         }
@@ -765,8 +778,8 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
     XYZZd<L> lo = XYZZd<L>::inf(), hi = XYZZd<L>::inf();
     if (in_range) {
         const uint32_t ch = child0 + 2u * q;
-        lo = in ? XYZZd<L>::load(&in[ch]) : bucket_sum<L, F>(partial, item_off, ch, heavy_items);
-        hi = in ? XYZZd<L>::load(&in[ch + 1]) : bucket_sum<L, F>(partial, item_off, ch + 1, heavy_items);
+        lo = fetch(ch);
+        hi = fetch(ch + 1);
     }
     XYZZd<L> r = lo.add(hi);                       // A: c0 + c1;  B: c2 + c3 (bit 1)
     (q == 0 ? hi : r).store(&lds[threadIdx.x]);    // A publishes c1, B its sum
@@ -867,6 +880,7 @@ struct MsmJob : MsmJobBase {
     size_t fbw_stride = 0;
     uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
     uint32_t heavy_items = HEAVY_ITEMS;   // buckets of more items go through k_heavy_fold
+    bool ones_in_levels = false;          // small jobs: the ones bucket's item sums are a row of the reduction levels
     bool order_items = true;       // items sorted by length before the accumulation (not for small jobs)
     static constexpr uint32_t ITEM_ORDER_MIN = 16384;
     int acc_prof = -1;
@@ -1078,16 +1092,20 @@ struct MsmJob : MsmJobBase {
             uint32_t* hlist = S.heavy.as<uint32_t>();
             // a job queued without read-backs folds its ones bucket here too (listed whenever it holds an item)
             XYZZ<F>* ones_out = nullptr;
-            if (eager_small) {
+            // (a small job's ones bucket has at most n / t_ones + 1 items: if they fit a row of the leaf level they are
+            // summed there, see k_bits_level)
+            ones_in_levels = eager_small && P.c >= 2 && n / t_ones + 1 <= P.B;
+            const bool fold_ones = eager_small && !ones_in_levels;
+            if (fold_ones) {
                 ZG_HIP(ctx, S.ones[0].reserve(sizeof(XYZZ<F>)));
                 ones_out = S.ones[0].template as<XYZZ<F>>();
                 ZG_HIP(ctx, hipMemsetAsync(ones_out, 0, sizeof(XYZZ<F>), st));   // all zero = the identity
             }
-            const uint32_t listed = eager_small ? nkeys : P.nkeys;
+            const uint32_t listed = fold_ones ? nkeys : P.nkeys;
             hipLaunchKernelGGL(k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               listed, heavy_items, eager_small ? ones_key : ~0u, hcnt, hlist);
+                               listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist);
             hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
-                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist, eager_small ? ones_key : ~0u,
+                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
                                ones_out);
         }
         const int bits = P.c - 1;
@@ -1097,10 +1115,11 @@ struct MsmJob : MsmJobBase {
             left -= red_f[red_nlev++];
         }
         // levels: every row is folded 2^f : 1, S rows append their bit-plane rows (see k_bits_level)
-        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve((size_t)P.nkeys * sizeof(XYZZ<F>)));
+        const uint32_t xrow = ones_in_levels ? 1u : 0u;   // the ones row, right after the S rows
+        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve(((size_t)P.nkeys + (size_t)xrow * P.B) * sizeof(XYZZ<F>)));
         const XYZZ<F>* cur = nullptr;
         {
-            uint32_t len = P.B, rows = (uint32_t)P.kw;
+            uint32_t len = P.B, rows = (uint32_t)P.kw + xrow;
             size_t rb = 0;
             int bb = 0;
             for (int l = 0; l < red_nlev; l++) {
@@ -1110,7 +1129,7 @@ struct MsmJob : MsmJobBase {
                 hipLaunchKernelGGL((k_bits_level<F>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
                                    dim3(BITS_THREADS), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
                                    S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
-                                   heavy_items, outp);
+                                   heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
                 cur = outp;
                 red_rowbase[l] = (uint32_t)rb;   // finish(): rows of level l start here (after the kw S rows)
                 red_bitbase[l] = bb;
@@ -1123,7 +1142,9 @@ struct MsmJob : MsmJobBase {
         // cur: [kw] S, then one entry per bit-plane row, rows ordered [level][window][bit within level]
         // ---- ones bucket: its item sums form one row
         ones_ptr = nullptr;
-        if (eager_small) {
+        if (ones_in_levels) {
+            ones_ptr = cur + P.kw;                          // the ones row's sum, right after the S entries
+        } else if (eager_small) {
             ones_ptr = S.ones[0].template as<XYZZ<F>>();   // written by k_heavy_fold above
         } else if (ones_hi > ones_lo) {
             uint32_t cnt = ones_hi - ones_lo;
@@ -1146,12 +1167,14 @@ struct MsmJob : MsmJobBase {
         }
         trace_point("phase_c rowsums queued");
         // read-back layout: [kw] S, [kw * bits] T in (level, window, bit) order, [1] ones
+        // (with the ones row among the levels: [kw] S, [1] ones, [kw * bits] T -- one copy)
         const size_t n_t = (size_t)P.kw * bits;
         if (((size_t)P.kw + n_t + 1) * sizeof(XYZZ<F>) + 64 > MsmScratch::HOST_BYTES)
             return fail(ctx, ZG_E_INVALID_ARG, "msm: read-back of %zu window sums exceeds the pinned buffer", n_t);
         XYZZ<F>* hw = reinterpret_cast<XYZZ<F>*>(S.host + 64);   // the first 64 bytes keep the meta words
-        ZG_HIP(ctx, hipMemcpyAsync(hw, cur, ((size_t)P.kw + n_t) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-        if (ones_ptr) ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + n_t, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        ZG_HIP(ctx, hipMemcpyAsync(hw, cur, ((size_t)P.kw + xrow + n_t) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        if (ones_ptr && !ones_in_levels)
+            ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + n_t, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
@@ -1168,7 +1191,7 @@ struct MsmJob : MsmJobBase {
         // the device works in the 2^261 Montgomery domain; window sums come back reduce()d in that form
         // window value = S_w + sum_j 2^j T_{w,j}; one Horner pass over all bit positions
         const int bits = P.c - 1;
-        const XYZZ<F>* ht = hw + P.kw;
+        const XYZZ<F>* ht = hw + P.kw + (ones_in_levels ? 1 : 0);
         for (int w = P.kw - 1; w >= 0; w--) {
             for (int j = P.c - 1; j >= 0; j--) {
                 acc = acc.dbl();
@@ -1181,7 +1204,7 @@ struct MsmJob : MsmJobBase {
             }
             if (!hw[w].is_inf()) acc = acc.add(m261_to_host(hw[w]));
         }
-        const XYZZ<F>& ho = hw[P.kw + (size_t)P.kw * bits];
+        const XYZZ<F>& ho = ones_in_levels ? hw[P.kw] : hw[P.kw + (size_t)P.kw * bits];
         if (ones_ptr && !ho.is_inf()) acc = acc.add(m261_to_host(ho));
         *out = acc;
         done = true;
