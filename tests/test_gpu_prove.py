@@ -830,8 +830,8 @@ def test_sha256_merkle_circuit_setup_prove_verify(ctx):
     pub = [int.from_bytes(root[:16], "big"), int.from_bytes(root[16:], "big")]
     assert za_amd.verify(pbytes, got, pub) is True
     assert za_amd.verify(pbytes, got, [pub[0], pub[1] ^ 1]) is False
-    # subset-sum tables on the l and a queries; the b queries (fewer than 2^16 positions: latency-bound jobs) take window tables
-    assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [2, 2, 1, 1]
+    # queries of this size (below 2^19 positions) are latency-bound jobs: window tables, not subset sums
+    assert [P.table_info(k)[0] for k in (1, 2, 3, 4)] == [1, 1, 1, 1]
     P.close(); R.close()
 
 

@@ -40,13 +40,22 @@ namespace zg {
 static constexpr int MAXWIN = 128;
 // jobs up to this many points are latency bound: queued whole, planned from n (MsmJob::eager_small), and the key gets
 // window tables for all of its queries whatever the witness looks like (prover.hip ensure_tables)
-// (ZA_AMD_SMALL_LOG_N overrides the 2^16; 0 turns the small-job mode off.  Read per call: tests switch it.)
-size_t msm_small_n() {
-    if (const char* e = getenv("ZA_AMD_SMALL_LOG_N")) {
-        const int lg = atoi(e);
-        return lg <= 0 ? 0 : (size_t)1 << std::min(lg, 24);
-    }
-    return (size_t)1 << 16;
+// Two thresholds.  A DENSE job (the h query: every scalar a field element) stops being latency bound early -- 2^19
+// points x 13 digits is 0.5 ms of additions at full rate, and the latency-oriented plan costs more of them (h shard of an
+// 8-way 2^22 proof: 1.23 -> 1.97 ms when treated as small): 2^16.  A WITNESS job of a bit-heavy circuit has few real
+// scalars and stays a chain of short launches much longer (same shard's witness phase: 3.4 -> 1.8 ms; a 2^18 proof 3.1 ->
+// 2.6 ms; at 2^20 positions per query nothing is gained, at 2^21 it costs 0.8 ms): about 2^19.
+// (ZA_AMD_SMALL_LOG_N / ZA_AMD_SMALL_W_LOG_N override; 0 turns the mode off.  Read per call: tests switch them.)
+static size_t small_from_env(const char* name, int dflt) {
+    int lg = dflt;
+    if (const char* e = getenv(name)) lg = atoi(e);
+    return lg <= 0 ? 0 : (size_t)1 << std::min(lg, 24);
+}
+size_t msm_small_n() { return small_from_env("ZA_AMD_SMALL_LOG_N", 16); }
+size_t msm_small_witness_n() {
+    if (getenv("ZA_AMD_SMALL_LOG_N") && !getenv("ZA_AMD_SMALL_W_LOG_N") && atoi(getenv("ZA_AMD_SMALL_LOG_N")) <= 0) return 0;
+    if (!getenv("ZA_AMD_SMALL_W_LOG_N")) return 600000;   // "2^19 and a bit": a 1/8 shard of a 2^22 query is 2^19 + 8 positions
+    return small_from_env("ZA_AMD_SMALL_W_LOG_N", 19);
 }
 static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (upper limit; see item_sizes)
@@ -133,8 +142,10 @@ bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_b
             if ((double)n_table * nwin * (double)elem_bytes > (double)max_bytes) continue;
             const double mean = (double)n_real * nwin / (double)(1u << (c - 1));
             const double t = std::min(64.0, std::max(4.0, std::ceil(std::sqrt(2.0 * mean))));
+            // (+ the leaf level's pass over all 2^(c-1) buckets -- four rows of XYZZ points written and read back --
+            // in the same unit: about 1e-5 additions' time per bucket)
             const double depth = std::min(t, mean + 1.0) + 1.25 * mean / t + 2.0 * ((c - 1 + 1) / 2)
-                                 + 1e-7 * (double)(1u << (c - 1));   // ties: the smaller bucket set
+                                 + 1e-5 * (double)(1u << (c - 1));
             if (depth < best) {
                 best = depth;
                 bc = c;
@@ -1325,7 +1336,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
                                                hi - lo, out));
     j->dense = d.dense;
-    j->eager_small = !d.dense && hi - lo <= msm_small_n();
+    j->eager_small = !d.dense && hi - lo <= msm_small_witness_n();
     j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
     if (d.quad_table) {
         j->quad_table = (const Affine<F>*)d.quad_table + lo;
@@ -1416,7 +1427,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // longest (a G2 addition is 19 us of a wave's time) -- and the h job, which waits for the NTT pipeline anyway, last.
     MsmJobBase* jobs[16];
     int nj = 0;
-    const bool small = g1[0].n <= msm_small_n() && g2.n <= msm_small_n();
+    const bool small = wj2->eager_small && wj1[0]->eager_small && wj1[1]->eager_small && wj1[2]->eager_small;
     if (!small)
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
     jobs[nj++] = wj2.get();

@@ -1433,7 +1433,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         size_t budget = (size_t)((double)avail * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
-        const bool small = n <= msm_small_n();   // latency bound: always a window table (msm.hip MsmJob::eager_small)
+        const bool small = n <= (k == 0 ? msm_small_n() : msm_small_witness_n());   // latency bound: always a window table (msm.hip)
         if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             const size_t entries = msm_quad_entries(n);
