@@ -42,6 +42,7 @@ struct Ctx {
     hipEvent_t part_ev[2 * H_PARTS_MAX] = {nullptr};   // (sorted, accumulated) per part of the h job
     hipEvent_t ev_witness = nullptr, ev_h = nullptr;   // gates for the overlapped prove (prover.hip): borrowed pointers
     hipEvent_t gate_w = nullptr, gate_h = nullptr;     // the ctx's own gate events (created lazily, destroyed by zg_free)
+    hipEvent_t h_split_ev[H_PARTS_MAX] = {nullptr};    // "range k of the evaluation-form H scalars is there" (h_eval_dev)
     hipEvent_t tm_ev[3] = {nullptr, nullptr, nullptr};  // timing of the H pipeline inside zg_prove_dev: start, R1CS evaluation done, H done
     bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
@@ -149,6 +150,7 @@ struct MsmDesc {
     const void* quad_table = nullptr;
     // optional, dense jobs run in parts: part k's stream waits for part_gate[k] (e.g. "scalar chunk k has arrived")
     const hipEvent_t* part_gate = nullptr;
+    bool part_gate_only = false;   // the part gates replace the job's common gate (ev_h) instead of adding to it
     int parts = 0;   // 0 = the scheduler's choice
     // optional: one class byte per scalar position (0 = zero, 1 = one, 2 = anything else; addressed like `scalars`,
     // through `index` if there is one).  The classification and the digit sort then read 1 byte instead of 32 for
@@ -177,7 +179,7 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
 // H in evaluation form: d_e_out[p] = ((A B - C) / Z)(g omega^bitrev(p)) as plain integers, m of them -- the scalars of
 // a key's h_eval bases (heval.hip).  Six transforms in 4 L - 3 launches.  a, b, c as for h_poly_dev; clobbered.
-int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out);
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit = 0, const hipEvent_t* ev_split = nullptr);
 struct FrLimbs;
 int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits);
 // heval.hip: d_out[p] (m affine points, device form) = sum_i omega^(-i bitrev(p)) (g^-i / m) H_i over the first m - 1

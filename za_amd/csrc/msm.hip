@@ -1383,6 +1383,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     int parts = 1;
     if (g1[0].dense && g1[0].n >= ((size_t)1 << 20) && live_contexts() == 1) parts = 2;
     if (g1[0].parts > 0) parts = g1[0].parts;
+    const int gates_n = g1[0].part_gate ? std::max(g1[0].parts, 1) : 0;
     // (not when the caller gates the parts on events of its own -- zg_msm_resident's scalar chunks: its part count IS
     // the chunking, and a different split would read scalars that have not arrived yet)
     if (const char* e = getenv("ZA_AMD_H_PARTS"))
@@ -1394,6 +1395,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     for (int k = 0; k < NS; k++) {
         if (k >= 5 && k <= 7 && k - 4 >= parts) continue;
         hipEvent_t ev = is_h_slot(k) ? ev_h : ev_witness;
+        if (is_h_slot(k) && g1[0].part_gate && g1[0].part_gate_only) continue;   // gated per part below
         ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
     }
     // witness queries
@@ -1412,7 +1414,14 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
             const size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
             const int slot = k == 0 ? 0 : 4 + k;
             hp[k] = make_range_job<Fq>(ctx, slot, g1[0], lo, hi, &hout[k]);
-            if (g1[0].part_gate && g1[0].part_gate[k]) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[slot], g1[0].part_gate[k], 0));
+            if (g1[0].part_gate) {   // the caller's gates go with ITS part count; fewer parts here: wait for all of them
+                if (parts == gates_n) {
+                    if (g1[0].part_gate[k]) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[slot], g1[0].part_gate[k], 0));
+                } else {
+                    for (int g = 0; g < gates_n; g++)
+                        if (g1[0].part_gate[g]) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[slot], g1[0].part_gate[g], 0));
+                }
+            }
             if (parts > 1) {
                 hp[k]->ev_sorted = ctx->part_ev[2 * k];
                 hp[k]->ev_acc = ctx->part_ev[2 * k + 1];

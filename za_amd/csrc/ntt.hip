@@ -10,6 +10,7 @@
 // Algorithmic HBM bytes: 64 B per element per transform (one read + one write).
 // Field work uses the lazy 9x29-limb arithmetic (fd.h): HBM holds M261 residues (x*2^261) packed in
 // 8 x u32; the LDS tile holds 9 limbs per element (36-byte stride: conflict-free for ds_read_b32).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -304,10 +305,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_tail3(const Fr* __restri
                                                            Fr* __restrict__ c, const FrLimbs* __restrict__ tw_fwd,
                                                            const FrLimbs* __restrict__ tw_inv, int log_m, int k, int j, int full,
                                                            const Fr* __restrict__ hi, const Fr* __restrict__ lo, int lo_bits,
-                                                           Fr zinv_int, Fr* __restrict__ out) {
+                                                           Fr zinv_int, Fr* __restrict__ out, uint32_t tile0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
-    const TileGeom G = TileGeom::make(log_m, 0, k, j, 1, blockIdx.x);
+    const TileGeom G = TileGeom::make(log_m, 0, k, j, 1, (size_t)blockIdx.x + tile0);
     const uint32_t tile_elems = G.elems();
     const size_t lomask = ((size_t)1 << lo_bits) - 1;
 #pragma unroll 1
@@ -635,7 +636,10 @@ static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int 
 
 // a, b, c: device form (M261, reduce()d), row i at index bitrev(i), zero padded; clobbered.  d_e_out: m plain integers,
 // e[p] = the quotient's value at g * omega^bitrev(p) -- the scalars that go with the key's h_eval bases.
-int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out) {
+// nsplit > 0: the last kernel runs in nsplit launches over consecutive ranges of e -- range k covers the positions
+// below min(m, (k + 1) * ceil(m / nsplit)) -- with ev_split[k] recorded behind launch k: part k of the h multiexp starts
+// its digit sort while the rest of e is still being computed.
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit, const hipEvent_t* ev_split) {
     NttTables* T;
     ZG_TRY(get_tables(ctx, log_m, &T));
     if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
@@ -646,7 +650,8 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out)
     if (log_m <= (uint32_t)NTT_LOG_TILE) {   // the whole domain is one tile
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)6 * 64 << log_m, nullptr, ((uint64_t)6 * log_m << log_m) >> 1);
         hipLaunchKernelGGL(k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
-                           (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out);
+                           (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out, 0u);
+        for (int k = 0; k < nsplit; k++) ZG_HIP(ctx, hipEventRecord(ev_split[k], ctx->stream));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
@@ -671,8 +676,19 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out)
         pass_geometry(log_m, 0, P.k[0], &j, &contiguous);
         const size_t tiles = m >> (P.k[0] + j);
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)4 * 32 << log_m, nullptr, ((uint64_t)3 * P.k[0] << log_m) >> 1);
-        hipLaunchKernelGGL(k_ntt_tail3, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream, d_a, d_b,
-                           d_c, twf, twi, (int)log_m, P.k[0], j, 0, hi, lo, T->lo_bits, T->zinv_int, d_e_out);
+        const int ns = nsplit > 0 ? nsplit : 1;
+        const size_t chunk = (m + ns - 1) / ns, tile_elems = (size_t)1 << (P.k[0] + j);
+        size_t t0 = 0;
+        for (int q = 0; q < ns; q++) {
+            const size_t upto = std::min(m, (size_t)(q + 1) * chunk);
+            const size_t t1 = q + 1 == ns ? tiles : std::min(tiles, (upto + tile_elems - 1) / tile_elems);
+            if (t1 > t0)
+                hipLaunchKernelGGL(k_ntt_tail3, dim3((unsigned)(t1 - t0)), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream,
+                                   d_a, d_b, d_c, twf, twi, (int)log_m, P.k[0], j, 0, hi, lo, T->lo_bits, T->zinv_int, d_e_out,
+                                   (uint32_t)t0);
+            if (nsplit > 0) ZG_HIP(ctx, hipEventRecord(ev_split[q], ctx->stream));
+            t0 = std::max(t0, t1);
+        }
         ZG_HIP(ctx, hipGetLastError());
     }
     return ZG_OK;

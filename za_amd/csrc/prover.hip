@@ -467,6 +467,8 @@ extern "C" void zg_free(zg_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (auto& e : ctx->tm_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->h_split_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->gate_w) (void)hipEventDestroy(ctx->gate_w);
     if (ctx->gate_h) (void)hipEventDestroy(ctx->gate_h);
     delete ctx->prove_ws;
@@ -1291,12 +1293,14 @@ static int gate_events(zg_ctx* ctx) {
     if (!ctx->gate_h) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->gate_h, hipEventDisableTiming));
     for (auto& e : ctx->tm_ev)
         if (!e) ZG_HIP(ctx, hipEventCreate(&e));
+    for (auto& e : ctx->h_split_ev)
+        if (!e) ZG_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return ZG_OK;
 }
 
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
 static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr,
-                           bool eval_form = false) {
+                           bool eval_form = false, int h_split = 0) {
     const size_t m = (size_t)1 << r->log_m;
     ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
@@ -1306,7 +1310,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
     if (ev_eval_done) ZG_HIP(ctx, hipEventRecord(ev_eval_done, ctx->stream));
-    if (eval_form) return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
+    if (eval_form) return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out, h_split, h_split ? ctx->h_split_ev : nullptr);
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
@@ -1536,8 +1540,9 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
 }
 
 // h_eval_form: d_h_shard holds h_eval_dev's m scalars and the h multiexp runs over the key's h_eval bases
+// h_split > 0: the scalars arrive in that many ranges (ctx->h_split_ev, see h_eval_dev) and the h job runs in as many parts
 static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const void* d_h_shard,
-                               unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES], bool h_eval_form) {
+                               unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES], bool h_eval_form, int h_split = 0) {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -1566,6 +1571,11 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
         d.cls = k == 0 ? nullptr : use[k].cls;
+        if (k == 0 && h_split > 0) {
+            d.parts = h_split;
+            d.part_gate = ctx->h_split_ev;
+            d.part_gate_only = true;
+        }
         const auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
         if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
             d.quad_table = t.buf.p;
@@ -1699,13 +1709,25 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
-    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form));
+    // The h multiexp of a large proof runs in parts (msm_batch5); in evaluation form the scalars of part k are final as
+    // soon as the last transform kernel has passed them, so that kernel can be launched range by range with part k gated
+    // on its range alone (ZA_AMD_H_PIPE=1).  Measured at 2^22, A/B on one box: no difference (11.93 / 11.76 vs 11.77 /
+    // 11.83 ms) -- the first part's digit sort and the rest of the transform kernel want the same CUs -- so it is off.
+    int h_split = 0;
+    if (const char* e = getenv("ZA_AMD_H_PIPE")) {
+        if (atoi(e) != 0 && eval_form && r->log_m >= 14) {
+            h_split = r->log_m >= 20 && live_contexts() == 1 ? 2 : 0;
+            if (const char* pe = getenv("ZA_AMD_H_PARTS")) h_split = std::min(std::max(atoi(pe), 1), (int)Ctx::H_PARTS_MAX);
+            if (h_split == 1) h_split = 0;
+        }
+    }
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split));
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
     ctx->ev_witness = ctx->gate_w;
     ctx->ev_h = ctx->gate_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
-    int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form);
+    int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form, h_split);
     ctx->ev_witness = ctx->ev_h = nullptr;
     ctx->witness_gate_armed = false;
     ZG_TRY(rc_p);
