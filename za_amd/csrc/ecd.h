@@ -137,6 +137,93 @@ struct Fq2L {
     }
 };
 
+#if defined(__HIPCC__)
+// ---- Fq2 on LANE PAIRS: lane 2i holds the c0 component of every Fq2 value of a point, lane 2i + 1 the c1 component.
+// What it is for: the latency-bound G2 chains (bucket reduction levels, heavy-bucket folds, the items of a small job):
+// a G2 addition is 19 us of ONE lane's instruction stream whatever else the GPU does, and its Fq2 products are two
+// independent fused multiply-accumulates (c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0).  With the components on adjacent
+// lanes each lane runs ONE mac2 per product after an exchange of the operands (18 v_mov_dpp, quad_perm [1,0,3,2]):
+// half the instruction stream per lane, half the registers (36 instead of 72 per point), same bounds -- every
+// function below is Fq2L's, component by component, with T = one FqD per lane.
+// Control flow must be uniform across a pair: every predicate (identity, P = +-Q) is combined over both lanes.
+struct Fq2PL {
+    using T = FqD;
+    using Mem = Fq2;
+    static constexpr int MB = 3;
+    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ uint32_t swap_u32(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    }
+    static __device__ __forceinline__ T swap(const T& a) {   // the partner lane's value
+        T r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = swap_u32(a.l[i]);
+        return r;
+    }
+    static __device__ __forceinline__ T sel(bool c, const T& a, const T& b) {   // c ? a : b, limb-wise (v_cndmask)
+        T r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+        return r;
+    }
+    // a predicate over the whole Fq2 value; the exchange runs on both lanes unconditionally (no short circuit: a lane
+    // that skipped it would hand its partner a stale register)
+    static __device__ __forceinline__ bool both(bool own) {
+        const uint32_t o = own ? 1u : 0u;
+        return (o & swap_u32(o)) != 0u;
+    }
+
+    static __device__ __forceinline__ T zero() { return T::zero(); }
+    static __device__ __forceinline__ T one() { return hi() ? T::zero() : T::one(); }
+    static __device__ __forceinline__ T load_canon(const Mem* p) { return T::load_canon(hi() ? &p->c1 : &p->c0); }
+    static __device__ __forceinline__ T load_red(const Mem* p) { return T::load_red(hi() ? &p->c1 : &p->c0); }
+    static __device__ __forceinline__ void store_red(Mem* p, const T& v) { v.reduce().store(hi() ? &p->c1 : &p->c0); }
+    static __device__ __forceinline__ void store_canon(Mem* p, const T& v) { v.canonical().store(hi() ? &p->c1 : &p->c0); }
+    static __device__ __forceinline__ bool is_exact_zero(const T& a) { return both(a.is_exact_zero()); }
+    static __device__ __forceinline__ bool is_zero_mod_p(const T& a) { return both(a.is_zero_mod_p()); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return a + b; }
+    template <int K>
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return T::template sub<K>(a, b); }
+    // Fq2L::mulx: lane 0 computes a0 b0 + a1 (-b1), lane 1 computes a1 b0 + a0 b1 -- as ONE instruction stream:
+    // own a * (own b | partner b)  +  partner a * (-partner b | own b)
+    template <int KB>
+    static __device__ __forceinline__ T mulx(const T& a, const T& b) {
+        const T pa = swap(a), pb = swap(b);
+        const T npb = pb.template neg_lazy<KB, 29>();
+        const bool h = hi();
+        return T::mac2(a, sel(h, pb, b), pa, sel(h, b, npb));
+    }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return mulx<18>(a, b).reduce(); }
+    // Fq2L::sqrx: (c0 + c1)(c0 - c1) on lane 0, c0 * 2 c1 on lane 1
+    template <int K>
+    static __device__ __forceinline__ T sqrx(const T& a) {
+        const T pa = swap(a);
+        const bool h = hi();
+        const T s = T::add_lazy(a, pa), d = T::template sub<K>(a, pa), two = T::add_lazy(a, a);
+        return sel(h, pa, s) * sel(h, two, d);
+    }
+    static __device__ __forceinline__ T sqr(const T& a) { return sqrx<16>(a).reduce(); }
+    static __device__ __forceinline__ T add_lazy(const T& a, const T& b) { return T::add_lazy(a, b); }
+    template <int K, int S>
+    static __device__ __forceinline__ T sub_lazy(const T& a, const T& b) { return T::template sub_lazy<K, S>(a, b); }
+    static __device__ __forceinline__ T norm(const T& a) { return a.norm(); }
+    static __device__ __forceinline__ T neg_canon_lazy(const T& y) { return y.template neg_lazy<2, 29>(); }
+    template <int KMAX>
+    static __device__ __forceinline__ bool maybe_zero_mod_p(const T& a) { return both(a.template maybe_zero_mod_p<KMAX>()); }
+    template <int KX>
+    static __device__ __forceinline__ T mul_sub_of_diff(const T& r, const T& qq, const T& x3, const T& y, const T& w) {
+        const T t = sub<KX>(qq, x3);
+        return sub<MB>(mulx<MB + 2 * MB>(t, r), mulx<MB>(y, w));
+    }
+    static __device__ __forceinline__ T inv(const T& a) {   // (a0 - a1 u) / (a0^2 + a1^2)
+        const T sq = a.sqr();
+        const T n = (sq + swap(sq)).inv();
+        const T r = a * n;
+        return hi() ? r.template neg<2>() : r;
+    }
+};
+#endif
+
 template <class L>
 struct AffD {
     typename L::T x, y;

@@ -616,7 +616,9 @@ __global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
-template <class F>
+// L / LP: the lazy arithmetic and the lanes per point -- (Fq2PL, 2) runs a G2 point on a lane pair (ecd.h): half the
+// dependent instruction stream per addition, which is what a latency-bound job's chain is made of.
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
 __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict__ bases,
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
@@ -624,8 +626,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
                                                     const uint32_t* __restrict__ item_key,
                                                     const uint32_t* __restrict__ perm, uint32_t nkeys,
                                                     uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
-    using L = typename LazyOf<F>::L;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LP;
     if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
     if (perm) t = perm[t];              // items in order of decreasing length
     uint32_t key = item_key[t];
@@ -682,30 +683,30 @@ __global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restric
     const uint32_t items = item_off[key + 1] - item_off[key];
     if (items > heavy_items || (key == force_key && items > 0)) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
 }
-template <class F>
-__global__ void __launch_bounds__(128) k_heavy_fold(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
-                                                    const uint32_t* __restrict__ heavy_cnt,
-                                                    const uint32_t* __restrict__ heavy_list, uint32_t ones_key,
-                                                    XYZZ<F>* __restrict__ ones_out) {
-    using L = typename LazyOf<F>::L;
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+__global__ void __launch_bounds__(128 * LP) k_heavy_fold(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
+                                                         const uint32_t* __restrict__ heavy_cnt,
+                                                         const uint32_t* __restrict__ heavy_list, uint32_t ones_key,
+                                                         XYZZ<F>* __restrict__ ones_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_h);
+    const uint32_t tid = threadIdx.x / LP, bdim = blockDim.x / LP;   // points, not lanes
     const uint32_t cnt = *heavy_cnt;
     for (uint32_t slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
         const uint32_t key = heavy_list[slot];
         const uint32_t lo = item_off[key], hi = item_off[key + 1];
         XYZZd<L> acc = XYZZd<L>::inf();
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = acc.add(XYZZd<L>::load(&partial[i]));
-        acc.store(&lds[threadIdx.x]);
+        for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&partial[i]));
+        acc.store(&lds[tid]);
         __syncthreads();
-        for (uint32_t st = blockDim.x >> 1; st > 0; st >>= 1) {
-            if (threadIdx.x < st) {
-                acc = acc.add(XYZZd<L>::load(&lds[threadIdx.x + st]));
-                acc.store(&lds[threadIdx.x]);
+        for (uint32_t st = bdim >> 1; st > 0; st >>= 1) {
+            if (tid < st) {
+                acc = acc.add(XYZZd<L>::load(&lds[tid + st]));
+                acc.store(&lds[tid]);
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             acc.store(&partial[lo]);
             if (key == ones_key) acc.store(ones_out);
         }
@@ -747,15 +748,15 @@ __device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ parti
 // level with every lane busy, where one thread per group ran four (and held four points: 311 registers for G1,
 // spills for G2).
 static constexpr uint32_t BITS_THREADS = 128;
-template <class F>
-__global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
                                                              const uint32_t* __restrict__ item_off, uint32_t rows_in,
                                                              uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
                                                              uint32_t ones_row, uint32_t ones_key, XYZZ<F>* __restrict__ out) {
-    using L = typename LazyOf<F>::L;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per thread
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per point held (LP lanes each)
+    const uint32_t tid = threadIdx.x / LP;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LP;
     const uint32_t g = t >> 1, q = t & 1u;
     const bool in_range = g < rows_in * len_out;
     const uint32_t row = in_range ? g / len_out : 0u, idx = g - row * len_out;
@@ -793,11 +794,11 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
         hi = fetch(ch + 1);
     }
     XYZZd<L> r = lo.add(hi);                       // A: c0 + c1;  B: c2 + c3 (bit 1)
-    (q == 0 ? hi : r).store(&lds[threadIdx.x]);    // A publishes c1, B its sum
+    (q == 0 ? hi : r).store(&lds[tid]);            // A publishes c1, B its sum
     if (in_range && full && q == 1) r.store(outD + len_out);
     __syncthreads();
     if (in_range && (q == 0 || full)) {
-        const XYZZd<L> other = XYZZd<L>::load(&lds[threadIdx.x ^ 1u]);
+        const XYZZd<L> other = XYZZd<L>::load(&lds[tid ^ 1u]);
         (q == 0 ? r : hi).add(other).store(q == 0 ? outS : outD);   // A: group sum;  B: c3 + c1 (bit 0)
     }
 }
@@ -805,11 +806,11 @@ __global__ void __launch_bounds__(BITS_THREADS) k_bits_level(const XYZZ<F>* __re
 // One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
 // (RowMeta).  Output: one entry per block, in block order -- again rows of `chunks` entries, so the kernel is
 // applied until every row has length 1.
-template <class F>
-__global__ void __launch_bounds__(256) k_rowsum(const XYZZ<F>* __restrict__ in, RowMeta M, XYZZ<F>* __restrict__ out) {
-    using L = typename LazyOf<F>::L;
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+__global__ void __launch_bounds__(256 * LP) k_rowsum(const XYZZ<F>* __restrict__ in, RowMeta M, XYZZ<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_r);
+    const uint32_t tid = threadIdx.x / LP, bdim = blockDim.x / LP;   // points, not lanes
     int lv = 0;
     while (lv + 1 < M.nlev && blockIdx.x >= M.block_base[lv + 1]) lv++;
     const uint32_t local = blockIdx.x - M.block_base[lv];
@@ -818,23 +819,23 @@ __global__ void __launch_bounds__(256) k_rowsum(const XYZZ<F>* __restrict__ in, 
     const size_t base = (size_t)M.d_off[lv] + (size_t)row * len;
     const uint32_t lo = chunk * ROWSUM_CH, hi = lo + ROWSUM_CH < len ? lo + ROWSUM_CH : len;
     XYZZd<L> acc = XYZZd<L>::inf();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc = acc.add(XYZZd<L>::load(&in[base + i]));
-    uint32_t active = hi - lo < blockDim.x ? hi - lo : blockDim.x;   // threads holding a term
+    for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&in[base + i]));
+    uint32_t active = hi - lo < bdim ? hi - lo : bdim;   // points holding a term
     if (active > 1) {
-        acc.store(&lds[threadIdx.x]);
+        acc.store(&lds[tid]);
         __syncthreads();
         uint32_t span = 1;
         while (span < active) span <<= 1;
         for (uint32_t st = span >> 1; st > 0; st >>= 1) {
-            if (threadIdx.x < st && threadIdx.x + st < active) {
-                acc = acc.add(XYZZd<L>::load(&lds[threadIdx.x + st]));
-                acc.store(&lds[threadIdx.x]);
+            if (tid < st && tid + st < active) {
+                acc = acc.add(XYZZd<L>::load(&lds[tid + st]));
+                acc.store(&lds[tid]);
             }
             __syncthreads();
             if (active > st) active = st;
         }
     }
-    if (threadIdx.x == 0) acc.store(&out[blockIdx.x]);
+    if (tid == 0) acc.store(&out[blockIdx.x]);
 }
 
 // ZA_AMD_TRACE=2: host time stamps inside a job's phase (finds the HIP call a phase blocks in)
@@ -867,6 +868,10 @@ struct MsmJobBase {
     bool launched = false;   // phase_b has run (its events are recorded)
     bool eager = false;      // phase_a leaves nothing to wait for (dense jobs): phase_b is queued right behind it
 };
+
+// Which arithmetic the latency-bound kernels of a job run: G1 one lane per point; G2 a lane PAIR per point (ecd.h Fq2PL).
+template <class F> struct ChainCfg { using L = typename LazyOf<F>::L; static constexpr int LP = 1; };
+template <> struct ChainCfg<Fq2> { using L = Fq2PL; static constexpr int LP = 2; };
 
 template <class F>
 struct MsmJob : MsmJobBase {
@@ -1087,11 +1092,21 @@ struct MsmJob : MsmJobBase {
             ProfScope ps(ctx, IS_G1 ? (dense ? PROF_MSM_ACC_G1_DENSE : PROF_MSM_ACC_G1) : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
                          chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
             acc_prof = ps.idx;
-            hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st,
-                               fbw_table ? fbw_table : quad_table ? quad_table : d_bases,
-                               S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                               S.item_key.as<uint32_t>(), order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr, nkeys,
-                               t_pack, ones_key, S.partial.as<XYZZ<F>>());
+            using CL = typename ChainCfg<F>::L;
+            constexpr int CLP = ChainCfg<F>::LP;
+            // G2: a job of few items is a chain of dependent additions -- lane pairs halve it; a big one is bound by
+            // throughput, where one lane per point issues fewer instructions in total (no operand exchange)
+            static const long pair_max = getenv("ZA_AMD_G2_PAIR_ITEMS") ? atol(getenv("ZA_AMD_G2_PAIR_ITEMS")) : 262144;
+            const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
+            const uint32_t* acc_perm = order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr;
+            if (CLP > 1 && (long)total_items <= pair_max)
+                hipLaunchKernelGGL((k_accumulate<F, CL, CLP>), dim3((unsigned)(((size_t)total_items * CLP + 255) / 256)), dim3(256), 0, st,
+                                   acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                                   S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
+            else
+                hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, acc_bases,
+                                   S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                                   S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
         trace_point("phase_c accumulate queued");
@@ -1115,7 +1130,8 @@ struct MsmJob : MsmJobBase {
             const uint32_t listed = fold_ones ? nkeys : P.nkeys;
             hipLaunchKernelGGL(k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
                                listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist);
-            hipLaunchKernelGGL((k_heavy_fold<F>), dim3(1024), dim3(128), 128 * sizeof(XYZZ<F>), st,
+            hipLaunchKernelGGL((k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024), dim3(128 * ChainCfg<F>::LP),
+                               128 * sizeof(XYZZ<F>), st,
                                S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
                                ones_out);
         }
@@ -1137,8 +1153,9 @@ struct MsmJob : MsmJobBase {
                 len >>= red_f[l];
                 const size_t groups = (size_t)rows * len;
                 XYZZ<F>* outp = S.lvl[l & 1].template as<XYZZ<F>>();
-                hipLaunchKernelGGL((k_bits_level<F>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
-                                   dim3(BITS_THREADS), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
+                hipLaunchKernelGGL((k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
+                                   dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
+                                   dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
                                    S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
                                    heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
                 cur = outp;
@@ -1168,7 +1185,8 @@ struct MsmJob : MsmJobBase {
                 O.rows[0] = 1;
                 O.chunks[0] = (cnt + ROWSUM_CH - 1) / ROWSUM_CH;
                 ZG_HIP(ctx, S.ones[pp].reserve((size_t)O.chunks[0] * sizeof(XYZZ<F>)));
-                hipLaunchKernelGGL((k_rowsum<F>), dim3(O.chunks[0]), dim3(256), 256 * sizeof(XYZZ<F>), st, in, O,
+                hipLaunchKernelGGL((k_rowsum<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(O.chunks[0]),
+                                   dim3(256 * ChainCfg<F>::LP), 256 * sizeof(XYZZ<F>), st, in, O,
                                    S.ones[pp].as<XYZZ<F>>());
                 in = S.ones[pp].template as<XYZZ<F>>();
                 cnt = O.chunks[0];
