@@ -1094,9 +1094,11 @@ struct MsmJob : MsmJobBase {
             acc_prof = ps.idx;
             using CL = typename ChainCfg<F>::L;
             constexpr int CLP = ChainCfg<F>::LP;
-            // G2: a job of few items is a chain of dependent additions -- lane pairs halve it; a big one is bound by
-            // throughput, where one lane per point issues fewer instructions in total (no operand exchange)
-            static const long pair_max = getenv("ZA_AMD_G2_PAIR_ITEMS") ? atol(getenv("ZA_AMD_G2_PAIR_ITEMS")) : 262144;
+            // G2 runs on lane pairs at every size: a job of few items is a chain of dependent additions, which the pairs
+            // halve; a big one is bound by throughput, and there 178 registers per lane (two waves per SIMD) beat the 329
+            // of one lane per point (one wave) by more than the operand exchange costs -- dense 2^22 witness: G2
+            // accumulation 18.4 -> 15.8 ms of kernel time, proof 33.5 -> 32.9 ms.  (ZA_AMD_G2_PAIR_ITEMS: A/B switch.)
+            static const long pair_max = getenv("ZA_AMD_G2_PAIR_ITEMS") ? atol(getenv("ZA_AMD_G2_PAIR_ITEMS")) : 0x7fffffffL;
             const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
             const uint32_t* acc_perm = order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr;
             if (CLP > 1 && (long)total_items <= pair_max)
