@@ -258,6 +258,15 @@ int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witne
  * TRANSFORMED h bases (built once per key: the same linear map applied to the points), so a proof runs six transforms
  * instead of seven and gives the same group element; ZA_AMD_H_EVAL=0 keeps the coefficient form.  Blocking. */
 int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
+/* The sharded form of the same: zg_prove_h_eval_enqueue_dev is zg_prove_h_enqueue_dev for evaluation-form scalars
+ * (non-blocking; zg_sync before reading d_e_out), and zg_prove_partials_ex with ZG_MASK_H_EVAL or-ed into its mask takes
+ * d_h_shard as this rank's range of them -- positions [lo, hi) = chunk `rank` of ceil(m / world) -- and multiplies them
+ * into the key's slice of the transformed h bases.  zg_params_h_eval_info: {1 if the key has such bases, log2(m), lo, hi};
+ * a sharded key gets them in zg_params_load (when |h| = 2^k - 1, as bellman writes it), an unsharded one on first use.
+ * Every rank of a proof must use the same form: agree on min(info[0]) over the ranks first (za_amd/dist.py does). */
+#define ZG_MASK_H_EVAL 0x20u
+int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
+int zg_params_h_eval_info(const zg_params* params, uint64_t info[4]);
 int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partials_all, int world,
                      const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */

@@ -205,6 +205,74 @@ def h_coefficients(r1cs, w):
     return a[: d.m - 1]
 
 
+# ----------------------------------------------------------------------------- H in evaluation form (checker for za_amd/csrc/heval.hip)
+# bellman ends create_proof with h = icoset_fft(e), answer += multiexp(params.h, h).  icoset_fft is linear,
+# h_i = (g^-i / m) sum_j omega^(-i j) e_j, so  sum_i h_i H_i = sum_j e_j H'_j  with  H'_j = sum_i omega^(-i j) (g^-i / m) H_i :
+# the product moves the last transform from the scalars (every proof) to the bases (once per key).  The two functions
+# below restate both sides by their definitions -- no butterflies -- in the order the GPU keeps them (position p holds
+# index bitrev(p): what a decimation-in-frequency transform leaves).
+def h_eval_scalars(r1cs, w):
+    """e[p] = ((A B - C) / Z)(g omega^bitrev(p)): bellman's values just before its icoset_fft, permuted."""
+    a, b, c, *_ = eval_constraints(r1cs, w)
+    d = Domain(r1cs.domain_log())
+    a, b, c = d.pad(a), d.pad(b), d.pad(c)
+    for v in (a, b, c):
+        d.ifft(v)
+        d.coset_fft(v)
+    for i in range(d.m):
+        a[i] = (a[i] * b[i] - c[i]) % R
+    d.divide_by_z_on_coset(a)
+    return [a[bitreverse(p, d.exp)] for p in range(d.m)]
+
+
+def h_eval_bases(h_points, log_m):
+    """H'[p] = sum_(i < m-1) omega^(-i bitrev(p)) (g^-i / m) H_i, by the definition (m^2 / 2 scalar multiplications:
+    small domains only)."""
+    from .bn254 import pt_add, pt_mul
+    d = Domain(log_m)
+    m = d.m
+    assert len(h_points) >= m - 1
+    scaled, u = [], d.minv
+    for i in range(m - 1):
+        scaled.append(pt_mul(h_points[i], u))
+        u = u * d.geninv % R
+    out = []
+    for p in range(m):
+        j = bitreverse(p, log_m)
+        acc = None
+        wj = pow(d.omegainv, j, R)
+        t = 1
+        for i in range(m - 1):
+            acc = pt_add(acc, pt_mul(scaled[i], t))
+            t = t * wj % R
+        out.append(acc)
+    return out
+
+
+def h_eval_bases_fft(h_points, log_m):
+    """The same array by a decimation-in-frequency transform over the group (natural order in, bit-reversed out) -- the
+    schedule of heval.hip; tests/test_oracle_python.py checks it against h_eval_bases' definition."""
+    from .bn254 import pt_add, pt_mul, pt_neg
+    d = Domain(log_m)
+    m = d.m
+    a, u = [], d.minv
+    for i in range(m - 1):
+        a.append(pt_mul(h_points[i], u))
+        u = u * d.geninv % R
+    a.append(None)
+    for s in range(log_m - 1, -1, -1):
+        span = 1 << s
+        for t in range(m // 2):
+            low = t & (span - 1)
+            i0 = ((t >> s) << (s + 1)) | low
+            i1 = i0 | span
+            x, y = a[i0], a[i1]
+            a[i0] = pt_add(x, y)
+            dd = pt_add(x, pt_neg(y))
+            a[i1] = pt_mul(dd, pow(d.omegainv, low << (log_m - 1 - s), R)) if low else dd
+    return a
+
+
 # ----------------------------------------------------------------------------- multiexp (bellman's Pippenger)
 def multiexp_window(n):
     return 3 if n < 32 else int(math.ceil(math.log(n)))

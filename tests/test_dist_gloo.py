@@ -21,7 +21,7 @@ from tests.util import golden, r1cs_from_fixture
 class OracleEngine:
     """Same interface as za_amd.dist.GpuEngine, computed with the Python / C oracle on CPU tensors."""
 
-    def __init__(self, fx, rank, world):
+    def __init__(self, fx, rank, world, h_eval=False):
         from za_amd.dist import shard_range
         self.device = torch.device("cpu")
         self.rank, self.world = rank, world
@@ -33,11 +33,33 @@ class OracleEngine:
         self.h_chunk_entries = (self.n_h + world - 1) // world
         self.shard_range = shard_range
         _, _, _, self.ad, self.bi, self.bd = g.eval_constraints(self.r1, self.w)
+        # H in evaluation form (za_amd.dist.GpuEngine's second mode): the transformed h bases, chunked over m
+        self.h_eval = h_eval
+        self.h_mask_extra = 0
+        self._agreed = False
+
+    def agree_h_form(self, group=None):
+        """As GpuEngine.agree_h_form: evaluation form only if every rank has the transformed bases."""
+        if self._agreed:
+            return
+        t = torch.tensor([1 if self.h_eval else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        self.h_eval = bool(int(t.item()))
+        if self.h_eval:
+            self.h_chunk_entries = (self.m + self.world - 1) // self.world
+            self.h_mask_extra = 0x20
+            self.h_eval_bases = g.h_eval_bases_fft(self.params.h, self.r1.domain_log())
+        self._agreed = True
 
     def start_h(self):
         pass
 
     def finish_h(self):
+        if self.h_eval:
+            e = g.h_eval_scalars(self.r1, self.w)
+            n = self.world * self.h_chunk_entries
+            e = e + [0] * (n - len(e))
+            return torch.frombuffer(bytearray(b"".join(bn.le32(x) for x in e[:n])), dtype=torch.uint8)
         h = g.h_coefficients(self.r1, self.w) + [0]
         n = self.world * self.h_chunk_entries
         h = h + [0] * (max(n, self.m) - len(h))
@@ -56,9 +78,15 @@ class OracleEngine:
         h_acc = None
         if mask & 1:
             hs = [bn.from_le32(bytes(h_shard[32 * i:32 * i + 32].tolist())) for i in range(h_shard.numel() // 32)]
-            lo, hi = self.shard_range(self.n_h, self.rank, self.world)
-            hi = min(hi, self.m - 1)
-            h_acc = bn.msm_naive(p.h[lo:hi], hs[:max(hi - lo, 0)])
+            if mask & 0x20:
+                assert self.h_eval
+                lo, hi = self.shard_range(self.m, self.rank, self.world)
+                h_acc = bn.msm_naive(self.h_eval_bases[lo:hi], hs[:max(hi - lo, 0)])
+            else:
+                assert not self.h_eval
+                lo, hi = self.shard_range(self.n_h, self.rank, self.world)
+                hi = min(hi, self.m - 1)
+                h_acc = bn.msm_naive(p.h[lo:hi], hs[:max(hi - lo, 0)])
         if not (mask & 0x1e):
             buf = self._jac(h_acc, 32) + self._jac(None, 32) * 3 + self._jac(None, 64)
             return torch.frombuffer(bytearray(buf), dtype=torch.uint8)
@@ -96,15 +124,18 @@ class OracleEngine:
         return g.proof_bytes((A, B, Cc))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, form="coefficient"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from za_amd.dist import sharded_prove
         fx = golden("proof_chain7.json")
-        eng = OracleEngine(fx, rank, world)
+        # "evaluation": every rank has the transformed bases; "mixed": rank 1 has not -- all ranks must fall back
+        has_eval = form == "evaluation" or (form == "mixed" and rank == 0)
+        eng = OracleEngine(fx, rank, world, h_eval=has_eval)
         proof = sharded_prove(eng, int(fx["r"], 16), int(fx["s"], 16))
+        assert eng.h_eval == (form == "evaluation") if form != "coefficient" else True
         if rank == 0:
             with open(out_path, "wb") as f:
                 f.write(proof)
@@ -128,6 +159,16 @@ def test_sharded_prove_over_gloo_matches_golden(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     fx = golden("proof_chain7.json")
     assert open(out, "rb").read().hex() == fx["proof"]
+
+
+@pytest.mark.parametrize("form", ["evaluation", "mixed"])
+def test_sharded_prove_with_h_in_evaluation_form(tmp_path, form):
+    """The orchestration's second mode: rank 0 scatters the coset evaluations e in ranges of ceil(m / world), the ranks
+    multiply them into their slices of the transformed h bases (mask bit 0x20) -- same golden proof; and when one rank
+    lacks those bases, every rank agrees on the coefficient form."""
+    out = str(tmp_path / "proof.bin")
+    mp.spawn(_worker, args=(2, _free_port(), out, form), nprocs=2, join=True)
+    assert open(out, "rb").read().hex() == golden("proof_chain7.json")["proof"]
 
 
 def test_shard_ranges_partition_exactly():

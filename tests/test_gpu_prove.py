@@ -293,6 +293,66 @@ def test_sharded_phases_equal_the_unsharded_proof(ctx):
     sr.close()
 
 
+def test_sharded_phases_in_evaluation_form(ctx):
+    """The same with H in evaluation form: every shard holds its slice of the transformed h bases (cut from the full key
+    by zg_params_shard, or made by zg_params_load(rank, world) from the whole bellman key) and takes its range of the
+    scalars e; world = 3 (ranges that are no powers of two) and 8."""
+    import za_amd
+    from tests import golden_1k as k1
+    from tests.util import golden
+    from za_amd import synth
+    lg = 13
+    sr = synth.SynthR1CS(lg, 3, 0.8, 4243)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P1 = synth.synth_params(ctx, *sizes, 901)
+    d_w = ctx.upload(sr.witness)
+    r, s = 12345, 67890
+    whole = ctx.prove_dev(P1, R, d_w, r, s)
+    assert P1.h_eval_info()[:2] == (True, lg)
+    d_e = ctx.alloc(32 * m)
+    ctx.prove_h_eval_dev(R, d_w, d_e)
+    for world in (3, 8):
+        parts, covered = [], 0
+        for rank in range(world):
+            Pk = synth.params_shard(ctx, P1, rank, world)
+            ready, lgk, lo, hi = Pk.h_eval_info()
+            assert ready and lgk == lg and lo == covered
+            covered = hi
+            parts.append(ctx.prove_partials_dev(Pk, R, d_w, d_e + 32 * lo, mask=0x1f | za_amd.ZG_MASK_H_EVAL))
+            Pk.close()
+        assert covered == m
+        assert ctx.prove_combine(P1, np.concatenate(parts), world, r, s) == whole
+    # a key without the transformed bases refuses the flag instead of mixing the forms
+    Pc = synth.synth_params(ctx, *sizes, 901, rank=0, world=2)
+    assert Pc.h_eval_info()[0] is False
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.prove_partials_dev(Pc, R, d_w, d_e, mask=0x01 | za_amd.ZG_MASK_H_EVAL)
+    assert e.value.code == za_amd.ZG_E_INVALID_ARG
+    ctx.free(d_e); ctx.free(d_w)
+    sr.close()
+    # zg_params_load(rank, world) on a bellman key (|h| = 2^10 - 1): the golden 2^10 proof from three sharded loads
+    fx = golden("proof_chain10.json")
+    r1, w = k1.chain10_circuit(fx)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R2 = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    pbytes = k1.chain10_params()
+    d_w = ctx.upload(co.witness_bytes(w))
+    d_e = ctx.alloc(32 << 10)
+    ctx.prove_h_eval_dev(R2, d_w, d_e)
+    parts = []
+    for rank in range(3):
+        Pk, _ = ctx.params_load(pbytes, checked=False, rank=rank, world=3)
+        ready, lgk, lo, hi = Pk.h_eval_info()
+        assert ready and lgk == 10
+        parts.append(ctx.prove_partials_dev(Pk, R2, d_w, d_e + 32 * lo, mask=0x1f | za_amd.ZG_MASK_H_EVAL))
+        Pk.close()
+    Pf, _ = ctx.params_load(pbytes, checked=False)
+    assert ctx.prove_combine(Pf, np.concatenate(parts), 3, int(fx["r"], 16), int(fx["s"], 16)).hex() == fx["proof"]
+    ctx.free(d_e); ctx.free(d_w)
+
+
 def test_full_size_proof_matches_discrete_log_expectation(ctx):
     """2^20 constraints (config 3 size): with every base's discrete log known, the proof's three
     elements are k*G for scalars computed independently (H from the C oracle)."""

@@ -146,3 +146,30 @@ def test_workload_csr_arrays_match_the_oracle_layout():
         assert np.array_equal(rp[k], csr.row_ptr[k]) and np.array_equal(cl[k], csr.col[k]) and np.array_equal(cf[k], csr.coeff[k])
     assert wl.witness_bytes(w) == co.witness_bytes(w)
     assert wl.R == ci.R
+
+
+def test_h_in_evaluation_form_is_the_same_group_element():
+    """The identity behind za_amd/csrc/heval.hip, by definitions only (no butterfly code on either side):
+    sum_i h_i H_i (bellman: coefficients x h query) = sum_p e[p] H'[p] (coset evaluations x transformed bases)."""
+    from oracle.circuits import chain_r1cs
+    r1, w = chain_r1cs(5, n_inputs=2, seed=55, bit_fraction=0.5)
+    params, _ = g.generate_parameters(r1, 11, 12, 13, 14, 15)
+    h = g.h_coefficients(r1, w)
+    lhs = None
+    for hi, Hi in zip(h, params.h):
+        lhs = bn.pt_add(lhs, bn.pt_mul(Hi, hi))
+    e = g.h_eval_scalars(r1, w)
+    Hp = g.h_eval_bases(params.h, 5)
+    assert g.h_eval_bases_fft(params.h, 5) == Hp      # the transform schedule of heval.hip gives the defined array
+    rhs = None
+    for ep, P in zip(e, Hp):
+        rhs = bn.pt_add(rhs, bn.pt_mul(P, ep))
+    assert lhs == rhs and lhs is not None
+    # and range by range, as the ranks of a sharded proof hold them (za_amd/dist.py): three ranges of ceil(32 / 3)
+    parts = None
+    for lo in range(0, 32, 11):
+        acc = None
+        for ep, P in list(zip(e, Hp))[lo:lo + 11]:
+            acc = bn.pt_add(acc, bn.pt_mul(P, ep))
+        parts = bn.pt_add(parts, acc)
+    assert parts == lhs

@@ -30,6 +30,7 @@ ZG_E_BUFFER_TOO_SMALL = 23
 ZG_E_HIP = 30
 ZG_E_NO_DEVICE = 31
 ZG_PARTIALS_BYTES = 576
+ZG_MASK_H_EVAL = 0x20   # zg_prove_partials_ex: d_h_shard holds evaluation-form scalars
 
 # every symbol include/za_amd.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
@@ -43,7 +44,7 @@ ABI_SYMBOLS = [
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
-    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_params_h_eval_info", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
@@ -351,6 +352,10 @@ class Context:
         """H in evaluation form (the scalars of the key's transformed h bases); blocking."""
         self._check(self.lib.zg_prove_h_eval_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out)))
 
+    def prove_h_eval_enqueue_dev(self, r1cs, d_witness, d_e_out):
+        """Non-blocking zg_prove_h_eval_dev; call sync() before using d_e_out."""
+        self._check(self.lib.zg_prove_h_eval_enqueue_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out)))
+
     def prove_h_enqueue_dev(self, r1cs, d_witness, d_h_out):
         """Non-blocking: queue R1CS evaluation + H; call sync() before using d_h_out."""
         self._check(self.lib.zg_prove_h_enqueue_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_h_out)))
@@ -442,6 +447,12 @@ class Params:
     @property
     def total_h(self):
         return self.query_total(0)
+
+    def h_eval_info(self):
+        """(ready, log_m, lo, hi): this key's evaluation-form h bases (zg_params_h_eval_info)."""
+        info = (C.c_uint64 * 4)()
+        self.ctx._check(self.ctx.lib.zg_params_h_eval_info(self.h, info))
+        return bool(info[0]), int(info[1]), int(info[2]), int(info[3])
 
     def write(self):
         """Parameters::write bytes of this resident key (needs a key that carries its verifying key)."""

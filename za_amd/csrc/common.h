@@ -185,6 +185,9 @@ int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const
 // heval.hip: d_out[p] (m affine points, device form) = sum_i omega^(-i bitrev(p)) (g^-i / m) H_i over the first m - 1
 // points of the h query -- the bases that go with h_eval_dev's scalars.  One-time work per key.
 int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log_m, G1Affine* d_out);
+// prover.hip: give a SHARDED key its slice of the evaluation-form h bases from the whole query (device form, on this
+// device); no-op (state -1) when the query length is not 2^k - 1 or ZA_AMD_H_EVAL=0
+int params_h_eval_slice(Ctx* ctx, const struct ::zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full);
 int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out);
 int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host);
 // out[row] = sum_e coeff[e] * x[idx[e]] over CSR/CSC rows; coeff pre-multiplied by 2^522, x plain integers -> M261

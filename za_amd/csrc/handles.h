@@ -48,9 +48,12 @@ struct zg_params {
     mutable std::mutex fbw_mu;
     // The h query in evaluation form (heval.hip): m affine points that go with h_eval_dev's scalars, built once per key
     // (unsharded keys only) together with their own window table.  state as in Fbw.
+    // A sharded key (world > 1) holds the positions [h_eval_lo, h_eval_hi) of the m-point array -- chunk `rank` of
+    // ceil(m / world) -- made when the key is loaded or cut from a full key, while the whole query is at hand.
     mutable zg::DevBuf h_eval;
     mutable uint32_t h_eval_log_m = 0;
     mutable int h_eval_state = 0;
+    mutable uint64_t h_eval_lo = 0, h_eval_hi = 0;
     mutable Fbw fbw_he;
 };
 

@@ -1241,6 +1241,18 @@ extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t
     ZG_TRY(params_upload(ctx, p.get(), 3, pp.b_g1.data(), pp.b_g1.size(), 64));
     ZG_TRY(params_upload(ctx, p.get(), 4, pp.b_g2.data(), pp.b_g2.size(), 128));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (world > 1 && !pp.h.empty()) {
+        // a sharded key takes its slice of the evaluation-form h bases now, while the whole query is at hand (every rank
+        // parses the whole key): upload it, transform, keep [rank * ceil(m / world), ...)
+        DevBuf whole;
+        if (whole.alloc(pp.h.size() * sizeof(G1Affine)) == hipSuccess) {
+            ZG_HIP(ctx, hipMemcpyAsync(whole.p, pp.h.data(), pp.h.size() * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+            ZG_TRY(convert_mont_dev(ctx, whole.p, pp.h.size() * 2, 0, 0));
+            ZG_TRY(params_h_eval_slice(ctx, p.get(), whole.as<G1Affine>(), pp.h.size(), nullptr));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     *out = p.release();
     return ZG_OK;
 } catch (...) {
@@ -1341,6 +1353,31 @@ extern "C" int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_
     return zg::on_exception(ctx);
 }
 
+extern "C" int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_e_out) try {
+    if (!ctx || !r || !d_e_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_TRY(gate_events(ctx));
+    ZG_TRY(witness_classes(ctx, r, d_witness));   // as zg_prove_h_enqueue_dev: the witness gate sits before the pipeline
+    prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
+    ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
+    ctx->witness_gate_armed = true;
+    return prove_h_enqueue(ctx, r, d_witness, d_e_out, nullptr, /*eval_form=*/true);
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+extern "C" int zg_params_h_eval_info(const zg_params* p, uint64_t info[4]) try {
+    if (!p || !info) return ZG_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    info[0] = p->h_eval_state == 1 ? 1 : 0;
+    info[1] = p->h_eval_log_m;
+    info[2] = p->h_eval_lo;
+    info[3] = p->h_eval_hi;
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
+
 extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
                                      const void* d_h_shard, uint8_t partials[ZG_PARTIALS_BYTES]) try {
     return zg_prove_partials_ex(ctx, p, r, d_witness, d_h_shard, 0x1f, partials);
@@ -1379,12 +1416,45 @@ struct QueryUse {
 };
 // The h query in evaluation form (heval.hip), built on first use: unsharded keys only (the group transform needs the
 // whole query); ZA_AMD_H_EVAL=0 keeps bellman's coefficient form (seven transforms per proof).
-static bool h_eval_allowed(const zg_params* p) {
+static bool h_eval_allowed() {
     const char* e = getenv("ZA_AMD_H_EVAL");   // read per key (tests switch it between key loads)
-    const bool off = e && atoi(e) == 0;
-    return !off && p->world == 1;
+    return !(e && atoi(e) == 0);
+}
+// A sharded key's slice: positions [rank * ceil(m / world), ...) of the m-point evaluation-form array.  The group
+// transform needs the whole query, so this runs where it is at hand: zg_params_load (every rank parses the whole key),
+// zg_params_shard (cut from a full resident key; d_h_eval_full = its transformed array if it has one).
+int zg::params_h_eval_slice(Ctx* ctx, const zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full) {
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    p->h_eval.release();
+    p->h_eval_state = -1;
+    uint32_t log_m = 0;
+    while (((uint64_t)1 << log_m) < n_h + 1) log_m++;
+    if (!h_eval_allowed() || log_m == 0 || log_m >= 28 || ((uint64_t)1 << log_m) != n_h + 1) return ZG_OK;   // bellman: |h| = m - 1
+    const uint64_t m = (uint64_t)1 << log_m, chunk = (m + p->world - 1) / p->world;
+    const uint64_t lo = std::min<uint64_t>(m, (uint64_t)p->rank * chunk), hi = std::min<uint64_t>(m, lo + chunk);
+    DevBuf full;
+    if (!d_h_eval_full) {
+        if (full.alloc(m * sizeof(G1Affine)) != hipSuccess) {
+            (void)hipGetLastError();
+            return ZG_OK;
+        }
+        ZG_TRY(h_eval_bases_build(ctx, d_h_full, n_h, log_m, full.as<G1Affine>()));
+        d_h_eval_full = full.as<G1Affine>();
+    }
+    if (p->h_eval.alloc(std::max<uint64_t>(hi - lo, 1) * sizeof(G1Affine)) != hipSuccess) {
+        (void)hipGetLastError();
+        return ZG_OK;
+    }
+    if (hi > lo) ZG_HIP(ctx, hipMemcpyAsync(p->h_eval.p, d_h_eval_full + lo, (hi - lo) * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->h_eval_log_m = log_m;
+    p->h_eval_lo = lo;
+    p->h_eval_hi = hi;
+    p->h_eval_state = 1;
+    return ZG_OK;
 }
 static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
+    if (p->world != 1) return ZG_OK;   // a sharded key has its slice from the start, or never (params_h_eval_slice)
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     if (p->h_eval_state == 1 && p->h_eval_log_m == log_m) return ZG_OK;
     p->h_eval.release();
@@ -1392,13 +1462,15 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
     p->fbw_he.state = 0;
     p->h_eval_state = -1;
     const uint64_t m = (uint64_t)1 << log_m;
-    if (!h_eval_allowed(p) || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
+    if (!h_eval_allowed() || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
     if (p->h_eval.alloc(m * sizeof(G1Affine)) != hipSuccess) {
         (void)hipGetLastError();
         return ZG_OK;   // no room: the coefficient form is used
     }
     ZG_TRY(h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, p->h_eval.as<G1Affine>()));
     p->h_eval_log_m = log_m;
+    p->h_eval_lo = 0;
+    p->h_eval_hi = m;
     p->h_eval_state = 1;
     return ZG_OK;
 }
@@ -1563,8 +1635,11 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     }
     ws.wcls_armed = false;
     ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use, (mask & 0x1eu) ? ws.wcls.as<uint8_t>() : nullptr));
-    if (h_eval_form && (mask & 1u))
-        use[0] = QueryUse{p->h_eval.p, (const uint32_t*)d_h_shard, nullptr, (uint64_t)1 << r->log_m};
+    if (h_eval_form && (mask & 1u)) {
+        if (!(p->h_eval_state == 1 && p->h_eval_log_m == r->log_m))
+            return fail(ctx, ZG_E_INVALID_ARG, "this key has no evaluation-form h bases for a 2^%u domain", r->log_m);
+        use[0] = QueryUse{p->h_eval.p, (const uint32_t*)d_h_shard, nullptr, p->h_eval_hi - p->h_eval_lo};
+    }
     if (use[0].n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
     ZG_TRY(ensure_tables(ctx, p, use, mask, h_eval_form));
     MsmDesc d1[4], d2;
@@ -1603,7 +1678,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
 }
 extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
                                     const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
-    return prove_partials_impl(ctx, p, r, d_witness, d_h_shard, mask, partials, false);
+    return prove_partials_impl(ctx, p, r, d_witness, d_h_shard, mask & 0x1fu, partials, (mask & ZG_MASK_H_EVAL) != 0);
 } catch (...) {
     return zg::on_exception(ctx);
 }

@@ -47,6 +47,8 @@ def sharded_prove(engine, r, s, group=None, timings=None):
     """
     import time
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if hasattr(engine, "agree_h_form"):
+        engine.agree_h_form(group)      # evaluation or coefficient form of H: the same on every rank (once per engine)
     nbytes = engine.h_chunk_entries * 32
     tm = {}
     t0 = time.perf_counter()
@@ -81,7 +83,7 @@ def sharded_prove(engine, r, s, group=None, timings=None):
         mine = scatter_list[0]
     t3 = time.perf_counter()
     tm["scatter"] = 1e3 * (t3 - t2)
-    part = _merge_partials(engine.partials(mine, H_MASK), w_part)
+    part = _merge_partials(engine.partials(mine, H_MASK | getattr(engine, "h_mask_extra", 0)), w_part)
     t4 = time.perf_counter()
     tm["h_msm"] = 1e3 * (t4 - t3)
     if world > 1:
@@ -104,6 +106,11 @@ def sharded_prove(engine, r, s, group=None, timings=None):
     return proof
 
 
+def za_amd_mask_h_eval():
+    from . import ZG_MASK_H_EVAL
+    return ZG_MASK_H_EVAL
+
+
 class GpuEngine:
     """Per-rank compute on one MI355X through the C ABI phase entry points."""
 
@@ -117,6 +124,31 @@ class GpuEngine:
         self.h_chunk_entries = (self.n_h_total + world - 1) // world
         self.m = m
         self._h_all = None
+        # H in evaluation form (six transforms on rank 0 instead of seven) when this rank's key has its slice of the
+        # transformed h bases; agree_h_form() makes it the decision of ALL ranks
+        ready, lg, lo_e, hi_e = params.h_eval_info()
+        self.h_eval = bool(ready and lg == r1cs.log_m)
+        self._agreed = False
+        self._set_form()
+
+    def _set_form(self):
+        if self.h_eval:
+            self.h_chunk_entries = (self.m + self.world - 1) // self.world
+            self.h_mask_extra = za_amd_mask_h_eval()
+        else:
+            self.h_chunk_entries = (self.n_h_total + self.world - 1) // self.world
+            self.h_mask_extra = 0
+
+    def agree_h_form(self, group=None):
+        if self._agreed:
+            return
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            t = torch.tensor([1 if self.h_eval else 0], dtype=torch.int32,
+                             device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            self.h_eval = bool(int(t.item()))
+            self._set_form()
+        self._agreed = True
 
     def _total_h(self):
         # all ranks hold the same total; recover it from this rank's shard bounds is not enough, so the
@@ -129,7 +161,10 @@ class GpuEngine:
         if self._h_all is None or self._h_all.numel() != need * 32:
             self._h_all = torch.zeros(need * 32, dtype=torch.uint8, device=self.device)
             torch.cuda.current_stream(self.device).synchronize()
-        self.ctx.prove_h_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
+        if self.h_eval:
+            self.ctx.prove_h_eval_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
+        else:
+            self.ctx.prove_h_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
 
     def finish_h(self):
         self.ctx.sync()
