@@ -252,6 +252,7 @@ _RUST_TO_C = {
 def _c_prototypes():
     text = open(os.path.join(ROOT, "include", "za_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^[ \t]*#.*$", "", text, flags=re.M)    # preprocessor lines
     protos = {}
     for ret, name, args in re.findall(r"([A-Za-z_][\w\s\*]*?)\b(zg_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         args = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
