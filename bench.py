@@ -404,7 +404,9 @@ def main():
                      "witness_msm_ms_rank0_beside_ntt": phase_ms.get("witness_msm"),
                      "h_ntt_ms": phase_ms.get("h_total"), "scatter_ms": phase_ms.get("scatter"),
                      "gather_ms": phase_ms.get("gather"), "combine_ms": phase_ms.get("combine"),
-                     "note": "host wall times per proof; h_ntt_ms = rank 0's R1CS evaluation + 7 NTTs from start to "
+                     "h_form": "evaluation (6 transforms, transformed h bases)" if getattr(engine, "h_eval", False)
+                               else "coefficient (7 transforms)",
+                     "note": "host wall times per proof; h_ntt_ms = rank 0's R1CS evaluation + H transforms from start to "
                              "finish (its witness MSMs run beside them); msm_phase_ms = max over ranks of witness MSMs + "
                              "h MSM of the rank's 1/%d shard" % world}
 

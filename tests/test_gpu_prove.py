@@ -317,6 +317,8 @@ def test_sharded_phases_in_evaluation_form(ctx):
         parts, covered = [], 0
         for rank in range(world):
             Pk = synth.params_shard(ctx, P1, rank, world)
+            if rank == 1:
+                Pk.prepare(R, d_w)       # tables up front, as bench.py does for its shard (the slice, not m points)
             ready, lgk, lo, hi = Pk.h_eval_info()
             assert ready and lgk == lg and lo == covered
             covered = hi

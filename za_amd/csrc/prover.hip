@@ -1605,7 +1605,7 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     // transformed bases (the coefficient-form table is still built on demand by the phase API)
     ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
     const bool eval_form = p->h_eval_state == 1 && p->h_eval_log_m == r->log_m;
-    if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, (uint64_t)1 << r->log_m};
+    if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, p->h_eval_hi - p->h_eval_lo};   // (a sharded key: its slice)
     return ensure_tables(ctx, p, use, 0x1f, eval_form);
 } catch (...) {
     return zg::on_exception(ctx);
