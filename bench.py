@@ -497,16 +497,20 @@ def main():
         Pk = synth.params_shard(ctx, full_key, 0, W)
         Pk.prepare(r1, d_w)
         d_h = ctx.alloc(32 * (m + W))
-        ctx.prove_h_dev(r1, d_w, d_h)
+        # the form a sharded run takes (za_amd/dist.py): evaluation form when the shard has its slice of the transformed h bases
+        ev = Pk.h_eval_info()[0] and full_key.h_eval_info()[0]
+        h_fn = ctx.prove_h_eval_dev if ev else ctx.prove_h_dev
+        h_mask = 0x01 | (za_amd.ZG_MASK_H_EVAL if ev else 0)
+        h_fn(r1, d_w, d_h)
         ts = []
         for _ in range(4):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            ctx.prove_h_dev(r1, d_w, d_h)
+            h_fn(r1, d_w, d_h)
             t2 = time.perf_counter()
             ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x1e)
             t3 = time.perf_counter()
-            ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x01)
+            ctx.prove_partials_dev(Pk, r1, d_w, d_h, h_mask)      # rank 0's range starts at position 0
             t4 = time.perf_counter()
             ts.append((t2 - t1, t3 - t2, t4 - t3))
         ts = np.array(ts[1:]) * 1e3
@@ -515,10 +519,10 @@ def main():
             t1 = time.perf_counter()
             ctx.prove_partials_dev(full_key, r1, d_w, d_h, 0x1e)
             t2 = time.perf_counter()
-            ctx.prove_partials_dev(full_key, r1, d_w, d_h, 0x01)
+            ctx.prove_partials_dev(full_key, r1, d_w, d_h, h_mask)
             full_w.append((t2 - t1, time.perf_counter() - t2))
         full_w = np.array(full_w[1:]) * 1e3
-        shard_line = {"world": W, "h_ntt_ms": float(ts[:, 0].mean()), "witness_msm_ms": float(ts[:, 1].mean()),
+        shard_line = {"world": W, "h_form": "evaluation" if ev else "coefficient", "h_ntt_ms": float(ts[:, 0].mean()), "witness_msm_ms": float(ts[:, 1].mean()),
                       "h_msm_ms": float(ts[:, 2].mean()), "msm_phase_ms": float(ts[:, 1:].sum(axis=1).mean()),
                       "unsharded_msm_phase_ms": float(full_w.sum(axis=1).mean()),
                       "msm_scaling_model": float(full_w.sum(axis=1).mean() / ts[:, 1:].sum(axis=1).mean()),

@@ -13,21 +13,22 @@ R = sr.load(ctx)
 m = 1 << lg
 P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 7000)
 d_w = ctx.upload(sr.witness)
+P.prepare(R, d_w)                      # tables and the evaluation-form h bases of the full key
 Pk = synth.params_shard(ctx, P, 0, W)
 Pk.prepare(R, d_w)
 d_h = ctx.alloc(32 << lg)
-ctx.prove_h_dev(R, d_w, d_h)
+ctx.prove_h_eval_dev(R, d_w, d_h)
 ts = []
 for _ in range(6):
-    t1 = time.perf_counter(); ctx.prove_h_dev(R, d_w, d_h)
+    t1 = time.perf_counter(); ctx.prove_h_eval_dev(R, d_w, d_h)
     t2 = time.perf_counter(); ctx.prove_partials_dev(Pk, R, d_w, d_h, 0x1e)
-    t3 = time.perf_counter(); ctx.prove_partials_dev(Pk, R, d_w, d_h, 0x01)
+    t3 = time.perf_counter(); ctx.prove_partials_dev(Pk, R, d_w, d_h, 0x21)
     t4 = time.perf_counter(); ts.append((t2 - t1, t3 - t2, t4 - t3))
 ts = np.array(ts[2:]) * 1e3
 full = []
 for _ in range(5):
     t1 = time.perf_counter(); ctx.prove_partials_dev(P, R, d_w, d_h, 0x1e)
-    t2 = time.perf_counter(); ctx.prove_partials_dev(P, R, d_w, d_h, 0x01)
+    t2 = time.perf_counter(); ctx.prove_partials_dev(P, R, d_w, d_h, 0x21)
     full.append((t2 - t1, time.perf_counter() - t2))
 full = np.array(full[2:]) * 1e3
 print("W=%d shard: h_ntt %.3f witness %.3f h_msm %.3f | unsharded witness %.3f h_msm %.3f | msm scaling %.2fx; tables %s"
