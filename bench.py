@@ -183,7 +183,8 @@ def host_pack_threads():
     """zg_prove's host-side packing threads (csrc/prover.hip host_pack_threads)."""
     if os.environ.get("ZA_AMD_PACK_THREADS"):
         return max(0, int(os.environ["ZA_AMD_PACK_THREADS"]))
-    return min(16, max(1, (os.cpu_count() or 2) // 2))
+    hc = os.cpu_count() or 1
+    return 0 if hc < 8 else min(32, max(4, hc // 4))
 
 
 def pmc_for(args):
