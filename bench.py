@@ -184,7 +184,7 @@ def host_pack_threads():
     if os.environ.get("ZA_AMD_PACK_THREADS"):
         return max(0, int(os.environ["ZA_AMD_PACK_THREADS"]))
     hc = os.cpu_count() or 1
-    return 0 if hc < 8 else min(32, max(4, hc // 4))
+    return 0 if hc < 8 else min(8, hc // 2)
 
 
 def pmc_for(args):

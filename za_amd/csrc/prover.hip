@@ -1874,16 +1874,18 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
 // carries zeros.  A few host threads turn the array into the packed form -- 2 bits per value plus (index, value) of
 // everything else -- at memory speed, and 3 % of the bytes cross PCIe.  Returns false (nothing queued) when the witness
 // is not of that kind: then it is uploaded as it is.  ZA_AMD_PACK_THREADS sets the thread count (0 = never pack).
-// Host time at 2^22 with 32 threads: 0.40 ms scan + 0.12 ms to put the lists back to back + 0.04 ms of queueing.
+// Host time at 2^22 with 8 threads: 0.73 ms scan + 0.07 ms to put the lists back to back + 0.03 ms of queueing.
 static int host_pack_threads() {
     static const int n = [] {
         if (const char* e = getenv("ZA_AMD_PACK_THREADS")) return std::max(0, atoi(e));
-        // measured on the GPU box (256 hardware threads, 134 MB witness): 4 threads 1.37 ms, 8: 0.82, 16: 0.73, 32: 0.56,
-        // 64: 1.0 -- against 2.34 ms for the plain upload.  A quarter of the host's threads, between 4 and 32; a host with
-        // fewer than 8 hardware threads uploads the array as it is.
+        // Measured on the GPU box (256 hardware threads, shared with other jobs; 134 MB witness).  Alone, the pass takes
+        // 1.37 ms with 4 threads, 0.82 with 8, 0.73 with 16, 0.56 with 32, 1.0 with 64 (the plain upload: 2.34 ms).  Inside
+        // the benchmark loop on a loaded host the order flips -- every thread is one more chance of a late wake-up:
+        // 11.76 ms per proof with 8 threads, 11.81 / 12.06 with 16, 12.19 / 12.31 with 32 (and a 20 ms outlier).  So: 8,
+        // or half of a small host's threads; a host with fewer than 8 hardware threads uploads the array as it is.
         const unsigned hc = std::thread::hardware_concurrency();
         if (hc < 8) return 0;
-        return (int)std::min<unsigned>(32, std::max<unsigned>(4, hc / 4));
+        return (int)std::min<unsigned>(8, hc / 2);
     }();
     return n;
 }
@@ -1909,7 +1911,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     };
     ProveWs& ws = prove_ws(ctx);
     if (!ws.pool || ws.pool->threads() != nthreads) ws.pool.reset(new WorkerPool(nthreads - 1));
-    const size_t slice_vals = (size_t)1 << 16;   // 2 MiB of witness per task
+    const size_t slice_vals = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
     const int n_slices = (int)((nv + slice_vals - 1) / slice_vals);
     const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
     const size_t cls_bytes = (nv + 3) / 4;
@@ -1932,7 +1934,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         sl.count = 0;
         if (abort.load(std::memory_order_relaxed)) return;
         const size_t lo = (size_t)si * slice_vals, hi = std::min(nv, lo + slice_vals);
-        const size_t cap = slice_vals / 4;   // a slice denser than 25 % ends the attempt
+        const size_t cap = slice_vals / 2;   // a slice denser than 50 % ends the attempt
         if (sl.idx.size() < cap) {
             sl.idx.resize(cap);
             sl.val.resize(cap * 32);
