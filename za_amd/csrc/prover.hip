@@ -1505,6 +1505,10 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         size_t reserve = 0;
         for (int q = 0; q < 5; q++) reserve += (size_t)use[q].n * 16 * 12;
         reserve += (size_t)use[0].n * 32 * 8;
+        // ... and a sixteenth of the device on top: at 2^26 with a dense witness the estimate above is met to within a
+        // few GB (round 3: the evaluation-form h bases and their build buffer were enough to make the first proof of
+        // `bench.py --log-m 26 --bit-fraction 0` run out of memory in a sort buffer)
+        reserve += total_b / 16;
         const size_t avail = free_b > reserve ? free_b - reserve : 0;
         size_t budget = (size_t)((double)avail * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
@@ -1930,6 +1934,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     std::atomic<size_t> total{0};
     std::atomic<bool> abort{false};
     ws.pool->parallel_for(n_slices, [&](int si) {
+      try {   // (a worker thread must not let an exception escape: std::bad_alloc from the slice's lists ends the attempt)
         ProveWs::PackSlice& sl = ws.slices[si];
         sl.count = 0;
         if (abort.load(std::memory_order_relaxed)) return;
@@ -1961,6 +1966,9 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         }
         sl.count = k;
         if (total.fetch_add(k) + k > max_others) abort.store(true);
+      } catch (...) {
+        abort.store(true);
+      }
     });
     stamp("scan");
     if (abort.load()) return ZG_OK;
