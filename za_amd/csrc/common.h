@@ -156,6 +156,8 @@ struct MsmDesc {
     // through `index` if there is one).  The classification and the digit sort then read 1 byte instead of 32 for
     // every 0 / 1 scalar -- a witness query of the SHA-like workload is 97 % of those, and each job makes three passes.
     const uint8_t* cls = nullptr;
+    // small-job mode (msm.hip): 1 / 0 = decided with the key's table for this query, -1 = by the job's size
+    int small_hint = -1;
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);

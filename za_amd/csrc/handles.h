@@ -43,6 +43,8 @@ struct zg_params {
         int kind = 0;    // 0 = window table, 1 = subset-sum ("quad") table
         uint64_t n = 0;
         int state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit / does not pay
+        bool small = false;   // planned for a latency-bound job (msm.hip small-job mode): decided with the table, when the
+                              // number of "real" scalars of the query is known
     };
     mutable Fbw fbw[5];
     mutable std::mutex fbw_mu;

@@ -1356,7 +1356,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
                                                hi - lo, out));
     j->dense = d.dense;
-    j->eager_small = !d.dense && hi - lo <= msm_small_witness_n();
+    j->eager_small = !d.dense && (d.small_hint >= 0 ? d.small_hint != 0 : hi - lo <= msm_small_n());
     j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
     if (d.quad_table) {
         j->quad_table = (const Affine<F>*)d.quad_table + lo;

@@ -1513,7 +1513,12 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         size_t budget = (size_t)((double)avail * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
-        const bool small = n <= (k == 0 ? msm_small_n() : msm_small_witness_n());   // latency bound: always a window table (msm.hip)
+        // latency bound (msm.hip small-job mode: always a window table): a dense query up to 2^16 points; a witness query up
+        // to ~2^19 positions IF few of its scalars are "real" (a bit-heavy circuit: shard of a 2^22 proof, 3 % of 2^19) --
+        // with 183 k field elements (the b queries of the 2^20 Poseidon chain) the mode's short items and wide digits cost
+        // throughput: G2 accumulation 1.8 -> 2.6 ms of kernel time, the proof 8.3 -> 8.8 ms
+        const bool small = n <= msm_small_n() || (k != 0 && n <= msm_small_witness_n() && n_real <= msm_small_n());
+        t.small = small;
         if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             const size_t entries = msm_quad_entries(n);
@@ -1650,6 +1655,10 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
         d.cls = k == 0 ? nullptr : use[k].cls;
+        if (k != 0) {
+            const auto& tk = p->fbw[k];
+            if (tk.state == 1 && tk.n == use[k].n) d.small_hint = tk.small ? 1 : 0;
+        }
         if (k == 0 && h_split > 0) {
             d.parts = h_split;
             d.part_gate = ctx->h_split_ev;
