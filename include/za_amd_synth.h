@@ -55,6 +55,12 @@ int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b
 int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
 /* out = k*p (+ q when q != NULL) with the host curve code; group 1 = G1 (64 B affine), 2 = G2 (128 B). */
 int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out);
+/* zg_prove's host-side packer (csrc/prover.hip HostPacker) on plain memory, no GPU: `threads` host threads turn n
+ * 32-byte values into class bytes ((n + 3) / 4) and the other values' (index, bytes) back to back (room for n / 8).
+ * *n_others = their number, or SIZE_MAX when the witness is not of the kind that packs (more than 12.5 % other values
+ * over all, or one 2^14-value stretch more than half of them) -- then zg_prove uploads the array as it is. */
+int zg_selftest_pack_mt(const uint8_t* witness32, size_t n, int threads, uint8_t* classes, uint32_t* other_index,
+                        uint8_t* others32, size_t* n_others);
 /* Parse + validate a bellman Parameters body on the host (no GPU) and check write(read(x)) == x.
  * counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, bytes consumed. */
 int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap);

@@ -304,3 +304,50 @@ def test_integration_md_ffi_block_matches_the_header():
     # the entry points a za maintainer cannot do without are in the block
     for must in ("zg_init", "zg_params_load", "zg_r1cs_load", "zg_prove", "zg_prove_random", "zg_proof_json", "zg_verify"):
         assert must in [f[0] for f in fns]
+
+
+def test_host_packer_matches_the_single_threaded_pack(lib_built):
+    """zg_prove's multi-threaded host packer (no GPU involved) against zg_witness_pack: same class bytes, same list of
+    other values; sizes that are no multiples of the task size or of 4; witnesses that must be refused (too dense over
+    all, or one dense stretch)."""
+    import za_amd
+    rng = np.random.default_rng(11)
+    SIZE_MAX = (1 << 64) - 1
+
+    def witness(n, frac_other):
+        w = np.zeros((n, 32), dtype=np.uint8)
+        w[:, 0] = rng.integers(0, 2, n)
+        k = int(n * frac_other)
+        pos = rng.choice(n, k, replace=False)
+        w[pos, :31] = rng.integers(0, 256, (k, 31), dtype=np.uint8)
+        w[pos, 1] |= 1            # not 0 / 1
+        return w
+
+    def pack_mt(w, threads):
+        n = w.shape[0]
+        cls = np.zeros((n + 3) // 4, dtype=np.uint8)
+        idx = np.zeros(max(n // 8, 1), dtype=np.uint32)
+        vals = np.zeros(max(n // 8, 1) * 32, dtype=np.uint8)
+        k = C.c_size_t()
+        rc = lib_built.zg_selftest_pack_mt(w.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_int(threads),
+                                           cls.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
+                                           vals.ctypes.data_as(C.c_void_p), C.byref(k))
+        assert rc == 0
+        return cls, idx, vals, k.value
+
+    for n, threads in ((1 << 17, 4), ((1 << 17) + 4099, 3), (70001, 1), ((1 << 16) + 2, 8)):
+        w = witness(n, 0.03)
+        cls, idx, vals, k = pack_mt(w, threads)
+        c1, i1, v1 = za_amd.pack_witness(w.reshape(-1))
+        assert k == i1.size and k != SIZE_MAX
+        assert bytes(cls) == bytes(c1) and bytes(idx[:k]) == bytes(i1) and bytes(vals[:32 * k]) == bytes(v1)
+    # more than an eighth of the values are field elements: not packed
+    assert pack_mt(witness(1 << 17, 0.2), 4)[3] == SIZE_MAX
+    # one stretch of 2^14 values more than half dense (2 % over all): not packed either
+    w = witness(1 << 18, 0.0)
+    w[5 << 14:(5 << 14) + 9000, 3] = 7
+    assert pack_mt(w, 4)[3] == SIZE_MAX
+    # ... but a dense stretch below that limit is
+    w = witness(1 << 18, 0.0)
+    w[5 << 14:(5 << 14) + 8000, 3] = 7
+    assert pack_mt(w, 4)[3] == 8000

@@ -242,16 +242,94 @@ private:
     bool stop = false;
 };
 
-struct ProveWs {
-    DevBuf abc[3], h, wcls, w;
-    // zg_prove's host-side packing (see there): pool, per-slice lists, pinned staging of the packed form
+static inline uint32_t value_class(const uint8_t* v) {
+    uint64_t q[4];
+    memcpy(q, v, 32);
+    return (q[1] | q[2] | q[3]) == 0 && q[0] <= 1 ? (uint32_t)q[0] : 2u;
+}
+
+// The host part alone (no GPU call): classes -> `classes` ((nv + 3) / 4 bytes), the other values' positions and bytes
+// back to back -> idx_out / val_out (room for nv / 8 of them).  *n_others_out = their number, or SIZE_MAX when the
+// witness is not the kind that packs (too dense over all, or one 2^14-value stretch more than half dense).
+struct HostPacker {
     std::unique_ptr<WorkerPool> pool;
-    struct PackSlice {
+    struct Slice {
         std::vector<uint32_t> idx;
         std::vector<uint8_t> val;
         size_t count = 0, offset = 0;
     };
-    std::vector<PackSlice> slices;
+    std::vector<Slice> slices;
+    static constexpr size_t SLICE_VALS = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
+
+    void run(const uint8_t* witness32, size_t nv, int nthreads, uint8_t* classes, uint32_t* idx_out, uint8_t* val_out,
+             size_t* n_others_out, const std::function<void(const char*)>& stamp) {
+        *n_others_out = SIZE_MAX;
+        if (!pool || pool->threads() != nthreads) pool.reset(new WorkerPool(nthreads - 1));
+        const int n_slices = (int)((nv + SLICE_VALS - 1) / SLICE_VALS);
+        const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
+        if ((int)slices.size() < n_slices) slices.resize(n_slices);
+        std::atomic<size_t> total{0};
+        std::atomic<bool> abort{false};
+        pool->parallel_for(n_slices, [&](int si) {
+            try {   // (a worker thread must not let an exception escape: std::bad_alloc from the slice's lists ends the attempt)
+                Slice& sl = slices[si];
+                sl.count = 0;
+                if (abort.load(std::memory_order_relaxed)) return;
+                const size_t lo = (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
+                const size_t cap = SLICE_VALS / 2;   // a slice denser than 50 % ends the attempt
+                if (sl.idx.size() < cap) {
+                    sl.idx.resize(cap);
+                    sl.val.resize(cap * 32);
+                }
+                size_t k = 0;
+                for (size_t i = lo; i < hi; i += 4) {   // slice bounds are multiples of 4: one class byte per group
+                    uint32_t byte = 0;
+                    const size_t e = std::min(hi, i + 4);
+                    for (size_t j = i; j < e; j++) {
+                        const uint8_t* v = witness32 + 32 * j;
+                        const uint32_t c = value_class(v);
+                        byte |= c << (2 * (j - i));
+                        if (c == 2u) {
+                            if (k == cap) {
+                                abort.store(true);
+                                return;
+                            }
+                            sl.idx[k] = (uint32_t)j;
+                            memcpy(&sl.val[32 * k], v, 32);
+                            k++;
+                        }
+                    }
+                    classes[i >> 2] = (uint8_t)byte;
+                }
+                sl.count = k;
+                if (total.fetch_add(k) + k > max_others) abort.store(true);
+            } catch (...) {
+                abort.store(true);
+            }
+        });
+        stamp("scan");
+        if (abort.load()) return;
+        size_t n_others = 0;
+        for (int si = 0; si < n_slices; si++) {
+            slices[si].offset = n_others;
+            n_others += slices[si].count;
+        }
+        if (n_others > max_others) return;
+        pool->parallel_for(n_slices, [&](int si) {   // the slices' lists, back to back, into the (pinned) staging buffer
+            const Slice& sl = slices[si];
+            if (!sl.count) return;
+            memcpy(idx_out + sl.offset, sl.idx.data(), sl.count * 4);
+            memcpy(val_out + 32 * sl.offset, sl.val.data(), sl.count * 32);
+        });
+        stamp("gather");
+        *n_others_out = n_others;
+    }
+};
+
+struct ProveWs {
+    DevBuf abc[3], h, wcls, w;
+    // zg_prove's host-side packing (see there): the packer (pool + per-slice lists) and the pinned staging of the packed form
+    std::unique_ptr<HostPacker> packer;
     uint8_t* stage = nullptr;   // pinned: [classes | other_index | others32]
     size_t stage_bytes = 0;
     DevBuf pk_cls, pk_idx, pk_val;   // zg_prove_packed: the packed witness as uploaded
@@ -1902,11 +1980,17 @@ static int host_pack_threads() {
     }();
     return n;
 }
-static inline uint32_t value_class(const uint8_t* v) {
-    uint64_t q[4];
-    memcpy(q, v, 32);
-    return (q[1] | q[2] | q[3]) == 0 && q[0] <= 1 ? (uint32_t)q[0] : 2u;
+// test hook (include/za_amd_synth.h): the host packer on plain memory, no GPU
+extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
+                                   uint8_t* others32, size_t* n_others) try {
+    if (!witness32 || !classes || !other_index || !others32 || !n_others || threads < 1) return ZG_E_INVALID_ARG;
+    HostPacker hp;
+    hp.run(witness32, nv, threads, classes, other_index, others32, n_others, [](const char*) {});
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
+
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {
     *done = false;
     const int nthreads = host_pack_threads();
@@ -1923,10 +2007,8 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         if (trace) fprintf(stderr, "[za_amd trace] pack %-14s +%.3f ms\n", what, now_ms() - t_begin);
     };
     ProveWs& ws = prove_ws(ctx);
-    if (!ws.pool || ws.pool->threads() != nthreads) ws.pool.reset(new WorkerPool(nthreads - 1));
-    const size_t slice_vals = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
-    const int n_slices = (int)((nv + slice_vals - 1) / slice_vals);
-    const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
+    if (!ws.packer) ws.packer.reset(new HostPacker());
+    const size_t max_others = nv / 8;
     const size_t cls_bytes = (nv + 3) / 4;
     const size_t need = ((cls_bytes + 63) & ~(size_t)63) + max_others * 36 + 64;
     if (ws.stage_bytes < need) {
@@ -1936,64 +2018,12 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         ZG_HIP(ctx, hipHostMalloc((void**)&ws.stage, need, hipHostMallocDefault));
         ws.stage_bytes = need;
     }
-    if ((int)ws.slices.size() < n_slices) ws.slices.resize(n_slices);
     uint8_t* classes = ws.stage;
     uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage + ((cls_bytes + 63) & ~(size_t)63));
     uint8_t* val_out = reinterpret_cast<uint8_t*>(idx_out + max_others);
-    std::atomic<size_t> total{0};
-    std::atomic<bool> abort{false};
-    ws.pool->parallel_for(n_slices, [&](int si) {
-      try {   // (a worker thread must not let an exception escape: std::bad_alloc from the slice's lists ends the attempt)
-        ProveWs::PackSlice& sl = ws.slices[si];
-        sl.count = 0;
-        if (abort.load(std::memory_order_relaxed)) return;
-        const size_t lo = (size_t)si * slice_vals, hi = std::min(nv, lo + slice_vals);
-        const size_t cap = slice_vals / 2;   // a slice denser than 50 % ends the attempt
-        if (sl.idx.size() < cap) {
-            sl.idx.resize(cap);
-            sl.val.resize(cap * 32);
-        }
-        size_t k = 0;
-        for (size_t i = lo; i < hi; i += 4) {   // slice bounds are multiples of 4: one class byte per group
-            uint32_t byte = 0;
-            const size_t e = std::min(hi, i + 4);
-            for (size_t j = i; j < e; j++) {
-                const uint8_t* v = witness32 + 32 * j;
-                const uint32_t c = value_class(v);
-                byte |= c << (2 * (j - i));
-                if (c == 2u) {
-                    if (k == cap) {
-                        abort.store(true);
-                        return;
-                    }
-                    sl.idx[k] = (uint32_t)j;
-                    memcpy(&sl.val[32 * k], v, 32);
-                    k++;
-                }
-            }
-            classes[i >> 2] = (uint8_t)byte;
-        }
-        sl.count = k;
-        if (total.fetch_add(k) + k > max_others) abort.store(true);
-      } catch (...) {
-        abort.store(true);
-      }
-    });
-    stamp("scan");
-    if (abort.load()) return ZG_OK;
-    size_t n_others = 0;
-    for (int si = 0; si < n_slices; si++) {
-        ws.slices[si].offset = n_others;
-        n_others += ws.slices[si].count;
-    }
-    if (n_others > max_others) return ZG_OK;
-    ws.pool->parallel_for(n_slices, [&](int si) {   // the slices' lists, back to back, into the pinned staging buffer
-        const ProveWs::PackSlice& sl = ws.slices[si];
-        if (!sl.count) return;
-        memcpy(idx_out + sl.offset, sl.idx.data(), sl.count * 4);
-        memcpy(val_out + 32 * sl.offset, sl.val.data(), sl.count * 32);
-    });
-    stamp("gather");
+    size_t n_others = SIZE_MAX;
+    ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp);
+    if (n_others == SIZE_MAX) return ZG_OK;
     ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
     stamp("queued");
     *done = true;
