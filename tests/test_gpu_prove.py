@@ -750,6 +750,10 @@ def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts):
     want = ctx.prove(P, R, sr.witness, 21, 22)
     monkeypatch.setenv("ZA_AMD_H_PARTS", parts)
     assert ctx.prove(P, R, sr.witness, 21, 22) == want
+    # the same with the last transform kernel launched range by range and every part gated on its own range
+    monkeypatch.setenv("ZA_AMD_H_PIPE", "1")
+    assert ctx.prove(P, R, sr.witness, 21, 22) == want
+    monkeypatch.delenv("ZA_AMD_H_PIPE")
     monkeypatch.setenv("ZA_AMD_FBW", "0")
     P2 = synth.synth_params(ctx, *sizes, 23)
     assert ctx.prove(P2, R, sr.witness, 21, 22) == want
