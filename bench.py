@@ -3,15 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W [--log-m 22]
 
-A "step" is one create_proof -- zg_prove: the witness comes from (pinned) HOST memory, its upload is part of the
-step, as SURVEY 8(d) defines the metric -- of the synthetic 2^log_m R1CS of config 4 (SHA256-Merkle-like witness:
-97 % bits, SplitMix64 seed 0x5A) with the R1CS and the proving key resident in HBM; r, s are fixed.  N > 1 is launched
-by torch.distributed.run, one rank per GPU: the MSMs shard by base chunk, the NTT stays on rank 0 (za_amd/dist.py).
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (G1 bucket accumulation) from HIP-event timings
-taken inside the timed region; `cpu_baseline` times the oracle (a port of bellman's CPU algorithm) on the same
-workload on this box's host cores.  Secondary keys: prove_dev_ms (witness already in HBM), g1_msm (the metric's second
-half: 2^26 resident G1 bases, scalars uploaded), dense_witness (same size, no 0/1 shortcuts), shard_model (the
-per-rank phases of an 8-way sharded proof measured on this one GPU), concurrent_provers.
+A "step" is one create_proof -- zg_prove: the witness comes from (pinned) HOST memory and its hand-over is part of the
+step, as SURVEY 8(d) defines the metric (a mostly-0/1 witness is packed by a few host threads before it crosses PCIe) --
+of the synthetic 2^log_m R1CS of config 4 (SHA256-Merkle-like witness: 97 % bits, SplitMix64 seed 0x5A) with the R1CS and
+the proving key resident in HBM; r, s are fixed.  N > 1 is launched by torch.distributed.run, one rank per GPU: the MSMs
+shard by base chunk, the NTT stays on rank 0 (za_amd/dist.py).  Rank 0 prints ONE JSON line.
+`roofline` is for the dominant kernel, the G1 bucket accumulation, as launched by the h multiexp (every point of such a
+launch reaches the kernel), from HIP events inside the timed region; `roofline.by_job_class` also carries the witness
+jobs' launches and the blend of both (the figure a rocprofv3 --stats summary shows: one kernel name); `traffic` is filled
+only for the workload the PMC passes in profiles/ were taken on.  `roofline_ntt` is the H pipeline against the same
+roofline.  `cpu_baseline` times the oracle (a port of bellman's CPU algorithm) on the same workload on this box's host
+cores.  Secondary keys: prove_dev_ms (witness already in HBM), prove_packed (the caller hands over the packed form),
+g1_msm (the metric's second half: 2^26 resident G1 bases, scalars uploaded), dense_witness (same size, no 0/1 shortcuts),
+sha256_merkle, shard_model (the per-rank phases of an 8-way sharded proof measured on this one GPU), concurrent_provers.
 """
 import argparse
 import json

@@ -62,6 +62,12 @@ const char* zg_strerror(int code);
 const char* zg_last_error(const zg_ctx* ctx);
 /* Use an existing HIP stream (hipStream_t cast to void*) for every launch; NULL = the ctx's own. */
 int zg_set_stream(zg_ctx* ctx, void* hip_stream);
+/* Options of a context.  ZG_OPT_ONE_SHOT (value != 0): this context proves once per key (za's `prove` command: read the
+ * key, prove, exit), so the per-key precomputation that only pays over several proofs is skipped -- the h query's
+ * evaluation-form bases (2 s at 2^22) and the window / subset-sum tables (0.3 s) -- and the proof takes bellman's own
+ * schedule of seven transforms.  Same proof bytes either way. */
+#define ZG_OPT_ONE_SHOT 1
+int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
 /* ---- device memory plumbing ---------------------------------------------------------------- */

@@ -243,7 +243,7 @@ def test_witness_pack_is_a_host_function(lib_built):
 
 # ---- INTEGRATION.md's Rust FFI block vs include/za_amd.h (no Rust toolchain here: keep the paper binding honest)
 _RUST_TO_C = {
-    "i32": {"int"}, "u32": {"uint32_t", "unsigned", "unsigned int"}, "u64": {"uint64_t"}, "usize": {"size_t"},
+    "i32": {"int"}, "i64": {"int64_t"}, "u32": {"uint32_t", "unsigned", "unsigned int"}, "u64": {"uint64_t"}, "usize": {"size_t"},
     "f64": {"double"}, "u8": {"uint8_t"}, "libc::c_char": {"char"}, "libc::c_void": {"void"},
     "ZgCtx": {"zg_ctx"}, "ZgParams": {"zg_params"}, "ZgR1cs": {"zg_r1cs"}, "ZgMsmBases": {"zg_msm_bases"},
 }

@@ -166,6 +166,28 @@ def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx):
         P.close(); R.close(); sr.close()
 
 
+def test_one_shot_context_skips_the_per_key_precomputation(lib_built):
+    """ZG_OPT_ONE_SHOT (za's `prove` command: read the key, prove once, exit): no evaluation-form h bases, no tables --
+    bellman's own schedule -- and the same proof bytes as a context that builds them."""
+    import za_amd
+    from za_amd import synth
+    lg = 15
+    sr = synth.SynthR1CS(lg, 2, 0.9, 1515)
+    c1 = za_amd.Context(0)
+    c1.set_one_shot()
+    R = sr.load(c1)
+    sizes = ((1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P = synth.synth_params(c1, *sizes, 77)
+    a = c1.prove(P, R, sr.witness, 31, 32)
+    assert [P.table_info(k)[0] for k in range(5)] == [0] * 5 and P.h_eval_info()[0] is False
+    c2 = za_amd.Context(0)
+    R2 = sr.load(c2)
+    assert c2.prove(P, R2, sr.witness, 31, 32) == a            # the same key in an ordinary context: tables appear
+    assert P.table_info(0)[0] == 1 and P.h_eval_info()[0] is True
+    assert c1.prove(P, R, sr.witness, 31, 32) == a             # ... and the one-shot context uses what is there
+    P.close(); R.close(); R2.close(); sr.close(); c1.close(); c2.close()
+
+
 def test_witness_is_validated_like_a_typed_assignment(ctx):
     """bellman's `Fr` cannot hold a value >= r and its variable 0 is CS::one(): the raw 32-byte witness of zg_prove*
     is checked on the device (k_witness_classes) and refused with BadFormat instead of giving a wrong proof."""

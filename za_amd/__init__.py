@@ -34,7 +34,7 @@ ZG_MASK_H_EVAL = 0x20   # zg_prove_partials_ex: d_h_shard holds evaluation-form 
 
 # every symbol include/za_amd.h declares (tests/test_abi.py checks the library exports them all)
 ABI_SYMBOLS = [
-    "zg_init", "zg_free", "zg_strerror", "zg_last_error", "zg_set_stream", "zg_sync",
+    "zg_init", "zg_free", "zg_strerror", "zg_last_error", "zg_set_stream", "zg_set_option", "zg_sync",
     "zg_dev_alloc", "zg_dev_free", "zg_h2d", "zg_d2h",
     "zg_msm_g1", "zg_msm_g2", "zg_msm_g1_dev", "zg_msm_g2_dev",
     "zg_msm_bases_g1", "zg_msm_bases_g1_dev", "zg_msm_bases_g2", "zg_msm_bases_free", "zg_msm_bases_info",
@@ -136,6 +136,10 @@ class Context:
     # ---- plumbing
     def set_stream(self, stream_handle):
         self._check(self.lib.zg_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_one_shot(self, on=True):
+        """ZG_OPT_ONE_SHOT: no per-key precomputation (a key used for one proof)."""
+        self._check(self.lib.zg_set_option(self.h, C.c_int(1), C.c_int64(1 if on else 0)))
 
     def sync(self):
         self._check(self.lib.zg_sync(self.h))

@@ -29,6 +29,7 @@ struct Ctx {
     struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
+    bool one_shot = false;       // zg_set_option(ZG_OPT_ONE_SHOT): no per-key precomputation
     bool ntt_attr_set = false;   // the transform kernels' dynamic-LDS attribute is set on this ctx's device
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
     struct ProveWs* prove_ws = nullptr;

@@ -77,40 +77,6 @@ static ZG_HD void ntt_dif2(FrD& u, FrD& v, const FrD& w, bool red) {
     u = red ? sm.reduce() : sm;
 }
 
-// ---- stage 0 (span 1) has the twiddle omega^0 = 1 in every butterfly: the variants below leave those multiplications
-// out -- one stage's worth per transform (of log2 m).  (Stages 1 and 2 are half / a quarter trivial, but lane by lane.)
-// DIT, stages (0, 1) on fresh values (below 2.01 p): the low stage is (u, v) -> (u + v, u - v).
-static ZG_HD void ntt_dit4_s0(FrD& x0, FrD& x1, FrD& x2, FrD& x3, const FrD& w2, const FrD& w3) {
-    const FrD a0 = FrD::add_lazy(x0, x1), a1 = FrD::sub_lazy<3, 29>(x0, x1);    // <= 4.02 p, 5.01 p
-    const FrD a2 = FrD::add_lazy(x2, x3), a3 = FrD::sub_lazy<3, 29>(x2, x3);
-    const FrD tc = a2 * w2, td = a3 * w3;
-    x0 = FrD::add_lazy(a0, tc).norm();
-    x2 = FrD::sub_lazy<2, 29>(a0, tc).norm();
-    x1 = FrD::add_lazy(a1, td).norm();
-    x3 = FrD::sub_lazy<2, 29>(a1, td).norm();
-}
-static ZG_HD void ntt_dit2_s0(FrD& u, FrD& v) {
-    const FrD d = FrD::sub<3>(u, v);
-    u = u + v;
-    v = d;
-}
-// DIF, stages (1, 0) -- the LAST round of a transform (the caller reduce()s what it stores): the low stage is
-// (u, v) -> (u + v, u - v).  In: normalised values below 4.02 p.  Out: normalised, below 26 p.
-static ZG_HD void ntt_dif4_s0(FrD& x0, FrD& x1, FrD& x2, FrD& x3, const FrD& w2, const FrD& w3) {
-    const FrD b0 = FrD::add_lazy(x0, x2), b1 = FrD::add_lazy(x1, x3);           // < 8.04 p, limbs < 2^30
-    const FrD b2 = FrD::sub_lazy<5, 29>(x0, x2) * w2;
-    const FrD b3 = FrD::sub_lazy<5, 29>(x1, x3) * w3;
-    x0 = FrD::add_lazy(b0, b1).norm();
-    x1 = FrD::sub_lazy<9, 30>(b0, b1).norm();
-    x2 = FrD::add_lazy(b2, b3).norm();
-    x3 = FrD::sub_lazy<2, 29>(b2, b3).norm();
-}
-static ZG_HD void ntt_dif2_s0(FrD& u, FrD& v) {
-    const FrD d = FrD::sub<5>(u, v);
-    u = u + v;
-    v = d;
-}
-
 // ---- one LDS tile's worth of butterfly stages, shared by every transform kernel of ntt.hip and by the host bound
 // checker (tests/cpp/test_fd.cpp runs the same function with one "thread" and bound tracking).
 // A tile holds 2^(k+j) elements of a 2^log_m vector: stages s_lo .. s_lo+k-1.  "Strided" form (s_lo >= j): 2^k rows
@@ -169,14 +135,9 @@ static ZG_HD void ntt_tile_stages(Tile& t, const TileGeom& G, const FrLimbs* __r
             const size_t e0 = G.gidx(i0);
             const size_t texp = (e0 & (((size_t)1 << s) - 1)) << (log_m - 1 - s);
             FrD u = t.get(i0), v = t.get(i1);
-            if (s == 0) {   // uniform: every twiddle of stage 0 is 1
-                if (DIT) ntt_dit2_s0(u, v);
-                else ntt_dif2_s0(u, v);
-            } else {
-                const FrD w = load_limbs(&tw[texp]);
-                if (DIT) ntt_dit2(u, v, w);
-                else ntt_dif2(u, v, w, red);
-            }
+            const FrD w = load_limbs(&tw[texp]);
+            if (DIT) ntt_dit2(u, v, w);
+            else ntt_dif2(u, v, w, red);
             t.put(i0, u);
             t.put(i1, v);
         }
@@ -196,15 +157,9 @@ static ZG_HD void ntt_tile_stages(Tile& t, const TileGeom& G, const FrLimbs* __r
             const size_t t2 = lowbits << (log_m - 2 - s);          // high stage, butterfly (00, 10)
             const size_t t3 = t2 + ((size_t)1 << (log_m - 2));     // high stage, butterfly (01, 11)
             FrD x0 = t.get(i00), x1 = t.get(i01), x2 = t.get(i10), x3 = t.get(i11);
-            const FrD w2 = load_limbs(&tw[t2]), w3 = load_limbs(&tw[t3]);
-            if (s == 0) {   // uniform: the low stage of this round is stage 0 (DIT: the first round, DIF: the last)
-                if (DIT) ntt_dit4_s0(x0, x1, x2, x3, w2, w3);
-                else ntt_dif4_s0(x0, x1, x2, x3, w2, w3);
-            } else {
-                const FrD w1 = load_limbs(&tw[t1]);
-                if (DIT) ntt_dit4(x0, x1, x2, x3, w1, w2, w3);
-                else ntt_dif4(x0, x1, x2, x3, w1, w2, w3, reduces(it), reduces(it + 1));
-            }
+            const FrD w1 = load_limbs(&tw[t1]), w2 = load_limbs(&tw[t2]), w3 = load_limbs(&tw[t3]);
+            if (DIT) ntt_dit4(x0, x1, x2, x3, w1, w2, w3);
+            else ntt_dif4(x0, x1, x2, x3, w1, w2, w3, reduces(it), reduces(it + 1));
             t.put(i00, x0);
             t.put(i01, x1);
             t.put(i10, x2);

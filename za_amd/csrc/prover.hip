@@ -584,6 +584,15 @@ extern "C" int zg_set_stream(zg_ctx* ctx, void* hip_stream) try {
 } catch (...) {
     return zg::on_exception(ctx);
 }
+extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
+    if (!ctx) return ZG_E_INVALID_ARG;
+    switch (option) {
+        case ZG_OPT_ONE_SHOT: ctx->one_shot = value != 0; return ZG_OK;
+        default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
+    }
+} catch (...) {
+    return zg::on_exception(ctx);
+}
 extern "C" int zg_sync(zg_ctx* ctx) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1535,6 +1544,7 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
     if (p->world != 1) return ZG_OK;   // a sharded key has its slice from the start, or never (params_h_eval_slice)
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     if (p->h_eval_state == 1 && p->h_eval_log_m == log_m) return ZG_OK;
+    if (ctx->one_shot) return ZG_OK;   // (the state stays as it is: another context may still build the bases)
     p->h_eval.release();
     p->fbw_he.buf.release();
     p->fbw_he.state = 0;
@@ -1563,6 +1573,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (!(mask & (1u << k)) || n == 0) continue;
         if (k != 0 && !use[k].scalars) continue;   // zg_params_prepare without a witness: only the h table
         if ((t.state == 1 && t.n == n) || t.state == -1) continue;
+        if (ctx->one_shot) continue;   // no tables for a key that is used once (their state stays "not tried")
         t.buf.release();
         t.state = -1;
         const char* off = getenv("ZA_AMD_FBW");   // "0" = no tables, otherwise a bit mask over (h, l, a, b_g1, b_g2)
@@ -1583,10 +1594,6 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         size_t reserve = 0;
         for (int q = 0; q < 5; q++) reserve += (size_t)use[q].n * 16 * 12;
         reserve += (size_t)use[0].n * 32 * 8;
-        // ... and a sixteenth of the device on top: at 2^26 with a dense witness the estimate above is met to within a
-        // few GB (round 3: the evaluation-form h bases and their build buffer were enough to make the first proof of
-        // `bench.py --log-m 26 --bit-fraction 0` run out of memory in a sort buffer)
-        reserve += total_b / 16;
         const size_t avail = free_b > reserve ? free_b - reserve : 0;
         size_t budget = (size_t)((double)avail * 0.6);
         if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));

@@ -271,6 +271,7 @@ static int prove_impl(const char* pk_path, const char* inputs, char* proof_buffe
     Handles h;
     int rc = zg_init(0, &h.ctx);
     if (rc) return return_string(err_text(nullptr, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
+    zg_set_option(h.ctx, ZG_OPT_ONE_SHOT, 1);   // read the key, prove once, return: no per-key tables
     double t0 = now_s();
     rc = zg_pk_load(h.ctx, pk.data(), pk.size(), /*checked=*/1, 0, 1, &h.r1cs, &h.params);   // read_pk: Parameters::read(pk, true)
     if (rc) return return_string(err_text(h.ctx, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
