@@ -128,11 +128,12 @@ def test_h_in_evaluation_form_gives_the_coefficient_forms_proof(ctx, lg):
         sr.close()
 
 
-def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx):
+def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx, monkeypatch):
     """zg_prove turns a mostly-0/1 witness into the packed form on a few host threads before the upload (3 % of the
     bytes cross PCIe); a witness of field elements, or one with a dense stretch, is uploaded as it is.  Same proof as
     zg_prove_dev on the raw array and as the C oracle either way."""
     from za_amd import synth
+    monkeypatch.setenv("ZA_AMD_PACK_MIN_LOG_N", "16")    # (by default only witnesses of 2^20 values and more are packed)
     for lg, bits, expect_packed in ((18, 0.97, True), (18, 0.5, False), (17, 1.0, True)):
         sr = synth.SynthR1CS(lg, 3, bits, 0x77 + lg)
         R = sr.load(ctx)

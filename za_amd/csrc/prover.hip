@@ -198,10 +198,17 @@ public:
             total = n_tasks;
             next.store(0);
             busy = (int)th.size();
+            busy_relaxed.store(busy, std::memory_order_release);
             gen++;
         }
         cv.notify_all();
         run();
+        // the workers are done within microseconds of this thread: spin briefly before sleeping on the condition variable
+        for (int spin = 0; spin < 20000 && busy_relaxed.load(std::memory_order_acquire) != 0; spin++) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
         std::unique_lock<std::mutex> lock(mu);
         cv_done.wait(lock, [this] { return busy == 0; });
         fn = nullptr;
@@ -228,6 +235,7 @@ private:
             {
                 std::lock_guard<std::mutex> lock(mu);
                 busy--;
+                busy_relaxed.store(busy, std::memory_order_release);
             }
             cv_done.notify_one();
         }
@@ -238,6 +246,7 @@ private:
     const std::function<void(int)>* fn = nullptr;
     int total = 0, busy = 0;
     std::atomic<int> next{0};
+    std::atomic<int> busy_relaxed{0};   // mirror of `busy` for the caller's spin
     uint64_t gen = 0;
     bool stop = false;
 };
@@ -330,6 +339,8 @@ struct ProveWs {
     DevBuf abc[3], h, wcls, w;
     // zg_prove's host-side packing (see there): the packer (pool + per-slice lists) and the pinned staging of the packed form
     std::unique_ptr<HostPacker> packer;
+    double pack_ema_ms = 0;   // running average of the packing pass's host time
+    int pack_skip = 0;        // proofs left to hand over unpacked after the pass turned out slower than the plain upload
     uint8_t* stage = nullptr;   // pinned: [classes | other_index | others32]
     size_t stage_bytes = 0;
     DevBuf pk_cls, pk_idx, pk_val;   // zg_prove_packed: the packed witness as uploaded
@@ -2001,7 +2012,11 @@ extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int thre
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {
     *done = false;
     const int nthreads = host_pack_threads();
-    if (nthreads <= 0 || nv < ((size_t)1 << 17)) return ZG_OK;
+    // below ~2^20 values (32 MB, 0.6 ms of PCIe) waking the threads costs what the pass saves
+    // (ZA_AMD_PACK_MIN_LOG_N: the tests lower it)
+    int min_log = 20;
+    if (const char* e = getenv("ZA_AMD_PACK_MIN_LOG_N")) min_log = std::min(std::max(atoi(e), 10), 30);
+    if (nthreads <= 0 || nv < ((size_t)1 << min_log)) return ZG_OK;
     {   // a cheap look first: 1024 evenly spread values; a witness of field elements is left alone
         size_t others = 0;
         const size_t step = nv / 1024;
@@ -2014,6 +2029,11 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         if (trace) fprintf(stderr, "[za_amd trace] pack %-14s +%.3f ms\n", what, now_ms() - t_begin);
     };
     ProveWs& ws = prove_ws(ctx);
+    if (ws.pack_skip > 0) {   // see below: the host is too busy for the pass to pay
+        ws.pack_skip--;
+        return ZG_OK;
+    }
+    const double t_pack0 = now_ms();
     if (!ws.packer) ws.packer.reset(new HostPacker());
     const size_t max_others = nv / 8;
     const size_t cls_bytes = (nv + 3) / 4;
@@ -2033,6 +2053,16 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     if (n_others == SIZE_MAX) return ZG_OK;
     ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
     stamp("queued");
+    {   // The pass competes with whatever else runs on the host (on a shared 256-thread host with a load average of 30 it
+        // has been seen to take 2.7 ms instead of 0.8): when its running average exceeds what the plain upload costs
+        // (32 B per value at ~55 GB/s), the next 32 proofs go over PCIe unpacked, then it is tried again.
+        const double t = now_ms() - t_pack0, plain_ms = (double)nv * 32.0 / 55e6;
+        ws.pack_ema_ms = ws.pack_ema_ms > 0 ? 0.7 * ws.pack_ema_ms + 0.3 * t : t;
+        if (nv >= ((size_t)1 << 20) && ws.pack_ema_ms > 0.9 * plain_ms) {
+            ws.pack_skip = 32;
+            ws.pack_ema_ms = 0;
+        }
+    }
     *done = true;
     *bytes_sent = cls_bytes + n_others * 36;
     return ZG_OK;
