@@ -340,6 +340,7 @@ struct ProveWs {
     // zg_prove's host-side packing (see there): the packer (pool + per-slice lists) and the pinned staging of the packed form
     std::unique_ptr<HostPacker> packer;
     double pack_ema_ms = 0;   // running average of the packing pass's host time
+    int pack_slow = 0;        // consecutive passes slower than the plain upload
     int pack_skip = 0;        // proofs left to hand over unpacked after the pass turned out slower than the plain upload
     uint8_t* stage = nullptr;   // pinned: [classes | other_index | others32]
     size_t stage_bytes = 0;
@@ -2034,10 +2035,12 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         return ZG_OK;
     }
     const double t_pack0 = now_ms();
-    if (!ws.packer) ws.packer.reset(new HostPacker());
     const size_t max_others = nv / 8;
     const size_t cls_bytes = (nv + 3) / 4;
     const size_t need = ((cls_bytes + 63) & ~(size_t)63) + max_others * 36 + 64;
+    // a pass that first allocates (worker threads, per-slice lists, the pinned stage) says nothing about the host's load
+    const bool cold = !ws.packer || ws.stage_bytes < need;
+    if (!ws.packer) ws.packer.reset(new HostPacker());
     if (ws.stage_bytes < need) {
         if (ws.stage) (void)hipHostFree(ws.stage);
         ws.stage = nullptr;
@@ -2057,10 +2060,14 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         // has been seen to take 2.7 ms instead of 0.8): when its running average exceeds what the plain upload costs
         // (32 B per value at ~55 GB/s), the next 32 proofs go over PCIe unpacked, then it is tried again.
         const double t = now_ms() - t_pack0, plain_ms = (double)nv * 32.0 / 55e6;
-        ws.pack_ema_ms = ws.pack_ema_ms > 0 ? 0.7 * ws.pack_ema_ms + 0.3 * t : t;
-        if (nv >= ((size_t)1 << 20) && ws.pack_ema_ms > 0.9 * plain_ms) {
-            ws.pack_skip = 32;
-            ws.pack_ema_ms = 0;
+        if (!cold) {
+            ws.pack_ema_ms = ws.pack_ema_ms > 0 ? 0.7 * ws.pack_ema_ms + 0.3 * t : t;
+            ws.pack_slow = t > 0.9 * plain_ms ? ws.pack_slow + 1 : 0;
+            if (ws.pack_slow >= 2 && ws.pack_ema_ms > 0.9 * plain_ms) {   // two slow passes in a row, not one late wake-up
+                ws.pack_skip = 32;
+                ws.pack_ema_ms = 0;
+                ws.pack_slow = 0;
+            }
         }
     }
     *done = true;
