@@ -27,11 +27,11 @@ else:
 P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
 pin = ctx.host_alloc(len(wb)); pin[:] = wb
 print("log_m", R.log_m, "tables", [P.table_info(k) for k in range(5)])
-ts = []
+ts, proofs = [], set()
 for i in range(n):
     if i == n - 1:
         sys.stderr.write("=== traced proof\n"); sys.stderr.flush()
     t0 = time.perf_counter()
-    ctx.prove(P, R, pin, 5, 7)
+    proofs.add(bytes(ctx.prove(P, R, pin, 5, 7)))
     ts.append(1e3 * (time.perf_counter() - t0))
-print("ms per proof:", np.round(ts, 3), "median %.3f" % np.median(ts[3:]), ctx.last_timings())
+print("ms per proof:", np.round(ts, 3), "median %.3f" % np.median(ts[3:]), ctx.last_timings(), "distinct proofs:", len(proofs))

@@ -501,6 +501,64 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_xscan_final(uint32_t* __restri
     }
 }
 
+// ---- the same two scans as ONE single-block launch each, for tables of at most SCAN_ONE_MAX entries: a small job is a
+// chain of dependent launches (~5 us each whatever they do), and three launches to scan 2000 words are two too many
+static constexpr size_t SCAN_ONE_MAX = 4 * (size_t)SCAN_TILE;
+__global__ void __launch_bounds__(SCAN_THREADS) k_xscan_one(uint32_t* __restrict__ v, size_t n) {
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (size_t t0 = 0; t0 <= n; t0 += SCAN_TILE) {   // v has n + 1 entries
+        const size_t base = t0 + (size_t)threadIdx.x * SCAN_PER_THREAD;
+        uint32_t x[SCAN_PER_THREAD];
+        uint32_t sc = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; k++) {
+            x[k] = base + k < n ? v[base + k] : 0u;
+            sc += x[k];
+        }
+        uint32_t tot;
+        uint32_t e = block_excl_scan(sc, lds, tot) + carry;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; k++) {
+            if (base + k <= n) v[base + k] = e;
+            e += x[k];
+        }
+        carry += tot;
+    }
+}
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_one(const uint32_t* __restrict__ counts, uint32_t nkeys, uint32_t T,
+                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ item_off) {
+    __shared__ uint32_t lds[8];
+    uint32_t cc = 0, ci = 0;
+    for (uint32_t t0 = 0; t0 <= nkeys; t0 += SCAN_TILE) {   // entry nkeys holds the totals
+        const uint32_t base = t0 + threadIdx.x * SCAN_PER_THREAD;
+        uint32_t cnt[SCAN_PER_THREAD];
+        uint32_t sc = 0, si = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; k++) {
+            const uint32_t idx = base + k;
+            cnt[k] = idx < nkeys ? counts[idx] : 0;
+            sc += cnt[k];
+            si += items_of(cnt[k], T, idx, nkeys);
+        }
+        uint32_t tc, ti;
+        uint32_t ec = block_excl_scan(sc, lds, tc) + cc;
+        uint32_t ei = block_excl_scan(si, lds, ti) + ci;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; k++) {
+            const uint32_t idx = base + k;
+            if (idx <= nkeys) {
+                offsets[idx] = ec;
+                item_off[idx] = ei;
+            }
+            ec += cnt[k];
+            ei += items_of(cnt[k], T, idx, nkeys);
+        }
+        cc += tc;
+        ci += ti;
+    }
+}
+
 // level 2: one workgroup per bin; segment [tile_off[bin*ntiles], tile_off[(bin+1)*ntiles]) of A
 __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
                                                     uint32_t ntiles, uint32_t nbins, int lb,
@@ -554,12 +612,19 @@ __global__ void k_meta(const uint32_t* offsets, const uint32_t* item_off, uint32
 }
 
 // item -> key map for the regular keys (the ones key, last, is filled by a memset)
-// (with_last: small jobs queued without read-backs have no host-side range for that memset; their ones bucket holds
-// few items and the thread of the last key writes them)
+// (with_last: small jobs queued without read-backs have no host-side range for that memset: the grid writes the ones
+// bucket's items too)
 __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict__ item_off, uint32_t nkeys,
-                                                     uint32_t* __restrict__ item_key, int with_last) {
+                                                     uint32_t* __restrict__ item_key, int with_last,
+                                                     uint32_t* __restrict__ zeroed, uint32_t nzero) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key + (with_last ? 0u : 1u) >= nkeys) return;
+    // (also clears the words the kernels after this one count in: item-size histogram, its scan, heavy-bucket counter)
+    for (uint32_t i = key; i < nzero; i += gridDim.x * blockDim.x) zeroed[i] = 0;
+    if (with_last) {   // all threads share the ones bucket's items (a bit-heavy witness: tens of thousands of them)
+        const uint32_t lo = item_off[nkeys - 1], hi = item_off[nkeys];
+        for (uint32_t t = lo + key; t < hi; t += gridDim.x * blockDim.x) item_key[t] = nkeys - 1;
+    }
+    if (key + 1u >= nkeys) return;
     uint32_t lo = item_off[key], hi = item_off[key + 1];
     for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
 }
@@ -1020,11 +1085,15 @@ struct MsmJob : MsmJobBase {
             const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
             const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
             ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>((size_t)nbx, (size_t)2 * nbk) * 4));
-            hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
-                               S.bsum.as<uint32_t>());
-            hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
-            hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
-                               S.bsum.as<uint32_t>());
+            if (tab_n + 1 <= SCAN_ONE_MAX) {
+                hipLaunchKernelGGL(k_xscan_one, dim3(1), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n);
+            } else {
+                hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
+                                   S.bsum.as<uint32_t>());
+                hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
+                hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
+                                   S.bsum.as<uint32_t>());
+            }
         }
         hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
@@ -1036,15 +1105,24 @@ struct MsmJob : MsmJobBase {
                            S.sorted.as<uint32_t>());
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
-                           S.bsum.as<uint32_t>(), nb);
-        hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
-                           S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                           (uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
-                           S.meta.as<uint32_t>());
-        ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
+        if ((size_t)nkeys + 1 <= SCAN_ONE_MAX) {
+            hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+                               S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+                               S.bsum.as<uint32_t>(), nb);
+            hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
+            hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+                               S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                               (uint32_t*)nullptr);
+        }
+        // the totals come back to the host for the jobs that plan their last phase from them -- a job queued whole only
+        // needs them for the profile's unit count
+        if (!(dense || eager_small) || ctx->prof_enabled) {
+            hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
+                               S.meta.as<uint32_t>());
+            ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
+        }
         ZG_HIP(ctx, hipGetLastError());
         if (ev_sorted) ZG_HIP(ctx, hipEventRecord(ev_sorted, st));
         launched = true;
@@ -1074,18 +1152,20 @@ struct MsmJob : MsmJobBase {
         trace_point("phase_c reserved items");
         {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
+            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] its scan, [1] the heavy-bucket counter
+            ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
+            uint32_t* hist = S.ihist.as<uint32_t>();
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0);
+                               nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0, hist, 2 * ITEM_CLASSES + 1);
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
                                               ones_hi - ones_lo, st));
             // order the items by length -- not for a small job: three launches and a memset cost more than the lanes of
             // its few hundred waves waiting for their longest item (it is launch and latency bound, not throughput bound)
-            order_items = total_items >= ITEM_ORDER_MIN;
-            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] its scan, [1] the heavy-bucket counter
-            ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
-            uint32_t* hist = S.ihist.as<uint32_t>();
-            ZG_HIP(ctx, hipMemsetAsync(hist, 0, (2 * ITEM_CLASSES + 1) * 4, st));
+            {
+                static const long omin = getenv("ZA_AMD_ORDER_MIN") ? atol(getenv("ZA_AMD_ORDER_MIN")) : (long)ITEM_ORDER_MIN;
+                order_items = (long)total_items >= omin;
+            }
             if (order_items) {
                 ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
                 const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
@@ -1271,6 +1351,14 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
         fprintf(stderr, "[za_amd trace] job %d %-8s host %.3f -> %.3f ms\n", j, what, t_begin, now);
     };
     auto tnow = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
+    // (trace only) GPU-side begin / end of every job queued whole, relative to the end of what the main stream holds on entry
+    hipEvent_t tev[16][2] = {{nullptr}}, tbase = nullptr;
+    if (trace) {
+        (void)hipEventCreate(&tbase);
+        (void)hipEventRecord(tbase, ctx->stream);
+        for (int j = 0; j < njobs; j++)
+            for (int k = 0; k < 2; k++) (void)hipEventCreate(&tev[j][k]);
+    }
     while (remaining > 0) {
         bool progressed = false;
         // launches first: a job's host-side finish() (a few hundred point operations) must not delay another
@@ -1290,7 +1378,9 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
                 // proof waited 0.9 ms here while the host was queueing the witness jobs' phases).
                 if (jobs[j]->eager && (!jobs[j]->dep || jobs[j]->dep->launched)) {
                     const double tb2 = tnow();
+                    if (trace) (void)hipEventRecord(tev[j][0], jobs[j]->st);
                     ZG_TRY(jobs[j]->phase_b());
+                    if (trace) (void)hipEventRecord(tev[j][1], jobs[j]->st);
                     stamp(j, "phase_b+c", tb2);
                     state[j] = jobs[j]->chained ? 3 : 2;
                 }
@@ -1327,6 +1417,16 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
             break;   // rescan from the front: the jobs are listed by priority (the h parts first)
         }
         if (!progressed) std::this_thread::yield();
+    }
+    if (trace) {
+        for (int j = 0; j < njobs; j++) {
+            float a = -1, b = -1;
+            if (hipEventElapsedTime(&a, tbase, tev[j][0]) == hipSuccess && hipEventElapsedTime(&b, tbase, tev[j][1]) == hipSuccess)
+                fprintf(stderr, "[za_amd trace] job %d on the GPU %.3f -> %.3f ms\n", j, a, b);
+            for (int k = 0; k < 2; k++) (void)hipEventDestroy(tev[j][k]);
+        }
+        (void)hipGetLastError();
+        (void)hipEventDestroy(tbase);
     }
     int rc = ZG_OK;
     for (auto& f : finishing) {
