@@ -689,9 +689,13 @@ def main():
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
                                       else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
                        "step": "zg_prove: witness (%d bytes, 32 B per value) in pinned host memory, handed over inside every step; "
-                               "R1CS and key resident.  A mostly-0/1 witness is packed by %d host threads before it crosses PCIe "
-                               "(%d bytes sent in the last step); H in evaluation form (6 transforms; h bases transformed once per key)"
-                               % (witness_bytes, host_pack_threads(), int(phases.get("upload_bytes", 0))),
+                               "R1CS and key resident.  %s; H in evaluation form (6 transforms; h bases transformed once per key)"
+                               % (witness_bytes,
+                                  "packed by %d host threads before it crossed PCIe (%d bytes sent in the last step)"
+                                  % (host_pack_threads(), int(phases.get("upload_bytes", 0)))
+                                  if 0 < int(phases.get("upload_bytes", 0)) < witness_bytes else
+                                  "sent over PCIe as it is in the last step (packing applies from 2^20 values, to a mostly-0/1 "
+                                  "witness, on a host where the pass is faster than the plain copy)"),
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
