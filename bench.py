@@ -173,7 +173,7 @@ def acc_roofline(prof, pmc=None):
                                            "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "both classes are ONE kernel name: this average is the one a rocprofv3 --stats "
                                                    "summary of the same command shows for k_accumulate<Fq> (profiles/r03_m_*: "
-                                                   "1153.9 us in the csv, 1167.6 us here in the same run)"}
+                                                   "1172.7 us in the csv, 1194.3 us here in the same run)"}
     # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
     roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "peak_measured": VALU_ISSUE_PEAK, "peak_nominal": VALU_ISSUE_NOMINAL,
@@ -367,9 +367,13 @@ def main():
     if world > 1:
         from za_amd.dist import GpuEngine, sharded_prove
         engine = GpuEngine(ctx, P, r1, d_w, world)
+        upload_sent = [0]
 
         def step():
-            ctx.h2d(d_w, w_host)       # every rank's copy of the witness arrives over its own PCIe link, inside the step
+            # every rank's copy of the witness arrives over its own PCIe link, inside the step, the way zg_prove hands it
+            # over (packed by host threads when it is mostly 0 / 1)
+            engine.d_witness, sent = ctx.witness_to_device(w_host)
+            upload_sent[0] = sent
             tm = {}
             out = sharded_prove(engine, r_blind, s_blind, timings=tm)
             for k, v in tm.items():
@@ -406,6 +410,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
     phases = ctx.last_timings()
+    if world > 1:
+        phases = dict(phases, upload_bytes=float(upload_sent[0]))
     h_ms_live = float(np.mean(h_ms_acc)) if h_ms_acc else None
     phase_ms = {k: v / max(args.steps, 1) for k, v in phase_acc.items()}
     elapsed = max_over_ranks(elapsed)
@@ -688,9 +694,10 @@ def main():
                                    % (100 * args.bit_fraction, args.seed, args.log_m,
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
                                       else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
-                       "step": "zg_prove: witness (%d bytes, 32 B per value) in pinned host memory, handed over inside every step; "
+                       "step": "%s: witness (%d bytes, 32 B per value) in pinned host memory, handed over inside every step; "
                                "R1CS and key resident.  %s; H in evaluation form (6 transforms; h bases transformed once per key)"
-                               % (witness_bytes,
+                               % ("zg_prove" if world == 1 else "sharded proof (za_amd/dist.py), every rank takes the whole witness",
+                                  witness_bytes,
                                   "packed by %d host threads before it crossed PCIe (%d bytes sent in the last step)"
                                   % (host_pack_threads(), int(phases.get("upload_bytes", 0)))
                                   if 0 < int(phases.get("upload_bytes", 0)) < witness_bytes else

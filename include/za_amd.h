@@ -273,6 +273,12 @@ int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness,
 #define ZG_MASK_H_EVAL 0x20u
 int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
 int zg_params_h_eval_info(const zg_params* params, uint64_t info[4]);
+/* zg_prove's hand-over of a HOST witness on its own, for callers that drive the phases themselves (every rank of a sharded
+ * proof needs the witness): n = n_inputs + n_aux canonical-LE scalars, copied -- in packed form by a few host threads
+ * when they are mostly zeros and ones -- into the context's own buffer; *d_witness receives its device
+ * address, valid until the context's next hand-over (this call or zg_prove) or zg_free; *bytes_sent (may be NULL) what
+ * crossed PCIe.  Queued on the context's stream, not waited for: the phase entry points order themselves behind it. */
+int zg_witness_to_device(zg_ctx* ctx, const uint8_t* witness32, size_t n, void** d_witness, size_t* bytes_sent);
 int zg_prove_combine(zg_ctx* ctx, const zg_params* params, const uint8_t* partials_all, int world,
                      const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[256]);
 /* [lo, hi) of query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) held by this params handle. */

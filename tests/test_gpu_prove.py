@@ -167,6 +167,56 @@ def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx, monkeypatch):
         P.close(); R.close(); sr.close()
 
 
+def test_witness_to_device_hands_over_like_zg_prove(ctx, monkeypatch):
+    """zg_witness_to_device (the hand-over of zg_prove on its own, for sharded callers): the context's buffer holds the
+    witness byte for byte whether it crossed PCIe packed or as it is, and the phase entry points prove from it."""
+    from za_amd import synth
+    monkeypatch.setenv("ZA_AMD_PACK_MIN_LOG_N", "16")
+    for lg, bits in ((17, 0.97), (17, 0.3)):
+        sr = synth.SynthR1CS(lg, 2, bits, 0x31)
+        R = sr.load(ctx)
+        nv = sr.n_inputs + sr.n_aux
+        P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 5)
+        pin = ctx.host_alloc(32 * nv)
+        pin[:] = sr.witness
+        want = ctx.prove(P, R, pin, 9, 10)
+        d_w, sent = ctx.witness_to_device(pin)
+        assert (sent < 32 * nv // 4) == (bits > 0.9), (bits, sent)
+        assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(sr.witness)
+        assert ctx.prove_dev(P, R, d_w, 9, 10) == want
+        ctx.host_free(pin)
+        P.close(); R.close(); sr.close()
+    with pytest.raises(Exception):
+        ctx.witness_to_device(np.zeros(0, dtype=np.uint8))
+
+
+def test_zg_prove_falls_back_to_the_plain_upload_while_packing_is_slow(lib_built, monkeypatch):
+    """The packing pass competes with whatever else runs on the host: two passes in a row slower than their budget (here:
+    a budget of zero) and the next proofs hand the witness over unpacked.  Same proof bytes either way; the first pass of
+    a context (it allocates) is not judged."""
+    import za_amd
+    from za_amd import synth
+    monkeypatch.setenv("ZA_AMD_PACK_BUDGET", "0")
+    ctx = za_amd.Context(0)
+    lg = 20
+    sr = synth.SynthR1CS(lg, 2, 0.97, 0x99)
+    R = sr.load(ctx)
+    nv = sr.n_inputs + sr.n_aux
+    P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 77)
+    pin = ctx.host_alloc(32 * nv)
+    pin[:] = sr.witness
+    proofs, sent = [], []
+    for _ in range(5):
+        proofs.append(bytes(ctx.prove(P, R, pin, 3, 4)))
+        sent.append(int(ctx.last_timings()["upload_bytes"]))
+    assert len(set(proofs)) == 1
+    assert all(b < 32 * nv // 4 for b in sent[:3]) and sent[3] == sent[4] == 32 * nv, sent
+    d_w = ctx.upload(sr.witness)
+    assert bytes(ctx.prove_dev(P, R, d_w, 3, 4)) == proofs[0]
+    ctx.free(d_w); ctx.host_free(pin)
+    P.close(); R.close(); sr.close(); ctx.close()
+
+
 def test_one_shot_context_skips_the_per_key_precomputation(lib_built):
     """ZG_OPT_ONE_SHOT (za's `prove` command: read the key, prove once, exit): no evaluation-form h bases, no tables --
     bellman's own schedule -- and the same proof bytes as a context that builds them."""

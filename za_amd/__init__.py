@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
-    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_params_h_eval_info", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_params_h_eval_info", "zg_witness_to_device", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
@@ -355,6 +355,16 @@ class Context:
     def prove_h_eval_dev(self, r1cs, d_witness, d_e_out):
         """H in evaluation form (the scalars of the key's transformed h bases); blocking."""
         self._check(self.lib.zg_prove_h_eval_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out)))
+
+    def witness_to_device(self, witness):
+        """zg_prove's hand-over of a host witness on its own (packed by host threads when it is mostly 0 / 1): returns
+        (device address inside the context's buffer, bytes that crossed PCIe).  Queued, not waited for."""
+        w = _u8(witness)
+        if w.size % 32:
+            raise ValueError("witness must be 32 bytes per value")
+        d, sent = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.zg_witness_to_device(self.h, _ptr(w), C.c_size_t(w.size // 32), C.byref(d), C.byref(sent)))
+        return d.value, sent.value
 
     def prove_h_eval_enqueue_dev(self, r1cs, d_witness, d_e_out):
         """Non-blocking zg_prove_h_eval_dev; call sync() before using d_e_out."""

@@ -1931,6 +1931,22 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
 }
 
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent);
+// The device copy of the witness lives in the ctx's workspace (no allocation per proof) and the upload is simply
+// queued in front of the proof's work: everything after it is gated by stream order / the witness event.  From
+// pinned memory (zg_host_alloc) the copy runs at PCIe speed, 32 (l + v) bytes: 134 MB = 2.4 ms at 2^22 -- unless the
+// witness is mostly zeros and ones, which cross PCIe in packed form (pack_and_upload).
+// (A two-part upload with the l / a / b multiexps over the first half's positions started early was built and
+// measured in round 2: slower, and eleven streams on eight hardware queues can deadlock -- DESIGN.md section 4.2.)
+static int witness_handover(zg_ctx* ctx, const uint8_t* witness32, size_t nv, void** d_w, size_t* sent) {
+    DevBuf& dw = prove_ws(ctx).w;
+    ZG_HIP(ctx, dw.reserve(nv * 32));
+    bool packed = false;
+    *sent = nv * 32;
+    ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, sent));
+    if (!packed) ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    *d_w = dw.p;
+    return ZG_OK;
+}
 extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
                         const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
     if (!ctx || !p || !r) return ZG_E_INVALID_ARG;
@@ -1938,21 +1954,27 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
-    // The device copy of the witness lives in the ctx's workspace (no allocation per proof) and the upload is simply
-    // queued in front of the proof's work: everything after it is gated by stream order / the witness event.  From
-    // pinned memory (zg_host_alloc) the copy runs at PCIe speed, 32 (l + v) bytes: 134 MB = 2.4 ms at 2^22.
-    DevBuf& dw = prove_ws(ctx).w;
-    ZG_HIP(ctx, dw.reserve(nv * 32));
-    // (A two-part upload with the l / a / b multiexps over the first half's positions started early was built and
-    // measured in round 2: slower, and eleven streams on eight hardware queues can deadlock -- DESIGN.md section 4.2.)
-    bool packed = false;
-    size_t sent = nv * 32;
-    ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, &sent));   // a bit-heavy witness crosses PCIe in packed form
-    if (!packed) ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
-    int rc = zg_prove_dev(ctx, p, r, dw.p, r_le, s_le, proof_out);
+    void* d_w = nullptr;
+    size_t sent = 0;
+    ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
+    int rc = zg_prove_dev(ctx, p, r, d_w, r_le, s_le, proof_out);
     ctx->timings[0] = (double)sent;   // bytes uploaded (the copy is not timed separately: it is in [5])
     ctx->timings[5] = now_ms() - t0;
     return rc;
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+// The same hand-over for callers that drive the phases themselves (a rank of a sharded proof, za_amd/dist.py): queued on
+// the context's stream, not waited for.
+extern "C" int zg_witness_to_device(zg_ctx* ctx, const uint8_t* witness32, size_t n, void** d_witness, size_t* bytes_sent) try {
+    if (!ctx || !d_witness) return ZG_E_INVALID_ARG;
+    if (!witness32 || n == 0) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL or empty");
+    if (n >= ((size_t)1 << 32)) return fail(ctx, ZG_E_INVALID_ARG, "witness of %zu values", n);
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    size_t sent = 0;
+    ZG_TRY(witness_handover(ctx, witness32, n, d_witness, &sent));
+    if (bytes_sent) *bytes_sent = sent;
+    return ZG_OK;
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -2059,8 +2081,12 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     {   // The pass competes with whatever else runs on the host (on a shared 256-thread host with a load average of 30 it
         // has been seen to take 2.7 ms instead of 0.8): when its running average exceeds what the plain upload costs
         // (32 B per value at ~55 GB/s), the next 32 proofs go over PCIe unpacked, then it is tried again.
-        const double t = now_ms() - t_pack0, plain_ms = (double)nv * 32.0 / 55e6;
-        if (!cold) {
+        // (ZA_AMD_PACK_BUDGET: the fraction of the plain upload's time the pass may take, default 0.9; the tests set 0 to
+        // walk through the fallback)
+        double budget = 0.9;
+        if (const char* e = getenv("ZA_AMD_PACK_BUDGET")) budget = atof(e);
+        const double t = now_ms() - t_pack0, plain_ms = (double)nv * 32.0 / 55e6 * budget / 0.9;
+        if (!cold && nv >= ((size_t)1 << 20)) {
             ws.pack_ema_ms = ws.pack_ema_ms > 0 ? 0.7 * ws.pack_ema_ms + 0.3 * t : t;
             ws.pack_slow = t > 0.9 * plain_ms ? ws.pack_slow + 1 : 0;
             if (ws.pack_slow >= 2 && ws.pack_ema_ms > 0.9 * plain_ms) {   // two slow passes in a row, not one late wake-up
