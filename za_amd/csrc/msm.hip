@@ -560,10 +560,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_one(const uint32_t* __res
 }
 
 // level 2: one workgroup per bin; segment [tile_off[bin*ntiles], tile_off[(bin+1)*ntiles]) of A
+// A long segment (a 2^26-point job: ~10^5 entries per bin) is scattered TILE entries at a time through LDS: the tile is
+// counting-sorted there and leaves as runs of consecutive words per bucket.  Writing sorted[cursor++] entry by entry, as
+// the short-segment path does, fills every 64-byte line of a 400 KB output region over the workgroup's whole lifetime --
+// 200 MB of half-written lines in flight across the chip, far beyond the L2s: 20.5 ms for the 403 M entries of one part of
+// a 2^26-point multiexp (19.7 G entries/s against 117 G/s on the 6.6 K-entry segments of a 2^22 proof, whose 218 MB of
+// entries also still sit in the 256 MB Infinity Cache when this kernel reads them).  Staged, with the counting pass's loads
+// eight deep and the next tile prefetched: 7.5 ms (counting 1.8, tiles 3.7, writes 2.0); the multiexp 103 -> 86 ms.
+static constexpr uint32_t PART_STAGE_TILE = 8192;
 __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
-                                                    uint32_t ntiles, uint32_t nbins, int lb,
+                                                    uint32_t ntiles, uint32_t nbins, int lb, uint32_t stage_min,
                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted) {
-    extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, then 8 words of scan scratch
+    extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, 16 words of scan scratch; staged: see below
     const uint32_t bin = blockIdx.x;
     const int bits = bin + 1 == nbins ? 0 : lb;   // the ones bin is a single bucket
     const uint32_t nl = 1u << bits;
@@ -576,7 +584,18 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
     }
     for (uint32_t b = threadIdx.x; b < nl; b += blockDim.x) lds_l[b] = 0;
     __syncthreads();
-    for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) atomicAdd(&lds_l[A[i].y], 1u);
+    {   // (eight loads in flight per thread: a long segment is otherwise a chain of 96 load -> atomic round trips)
+        constexpr uint32_t U = 8;
+        uint32_t i = start + threadIdx.x;
+        for (; i + (U - 1) * blockDim.x < end; i += U * blockDim.x) {
+            uint32_t y[U];
+#pragma unroll
+            for (uint32_t k = 0; k < U; k++) y[k] = A[i + k * blockDim.x].y;
+#pragma unroll
+            for (uint32_t k = 0; k < U; k++) atomicAdd(&lds_l[y[k]], 1u);
+        }
+        for (; i < end; i += blockDim.x) atomicAdd(&lds_l[A[i].y], 1u);
+    }
     __syncthreads();
     // exclusive prefix over the nl local buckets: each thread owns a run of consecutive buckets
     const uint32_t per = (nl + blockDim.x - 1) / blockDim.x;
@@ -595,9 +614,66 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
         }
     }
     __syncthreads();
-    for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) {
-        uint2 e = A[i];
-        sorted[atomicAdd(&lds_l[e.y], 1u)] = e.x;
+    if (end - start < stage_min || nl > blockDim.x) {
+        for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) {
+            uint2 e = A[i];
+            sorted[atomicAdd(&lds_l[e.y], 1u)] = e.x;
+        }
+        return;
+    }
+    // staged: [2^lb] cursors | 16 scratch | [2^lb] tile counts | [2^lb] tile offsets | [TILE] values | [TILE] buckets (u16)
+    constexpr uint32_t TILE = PART_STAGE_TILE, PER = TILE / 1024;
+    uint32_t* cur = lds_l;
+    uint32_t* th = scratch + 16;
+    uint32_t* toff = th + (1u << lb);
+    uint32_t* stage_v = toff + (1u << lb);
+    uint16_t* stage_b = reinterpret_cast<uint16_t*>(stage_v + TILE);
+    if (threadIdx.x < nl) th[threadIdx.x] = 0;
+    __syncthreads();
+    // (the next tile's entries are loaded while this one goes through LDS: a tile is otherwise one memory round trip with
+    // nothing to overlap it -- the barriers keep the workgroup's waves in step)
+    uint2 e[PER], nx[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = start + k * 1024 + threadIdx.x;
+        nx[k] = i < end ? A[i] : make_uint2(0u, 0u);
+    }
+    for (uint32_t t0 = start; t0 < end; t0 += TILE) {
+        const uint32_t n_t = end - t0 < TILE ? end - t0 : TILE;
+        uint32_t rk[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            e[k] = nx[k];
+            const uint32_t i = t0 + TILE + k * 1024 + threadIdx.x;
+            if (i < end) nx[k] = A[i];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++)
+            if (k * 1024 + threadIdx.x < n_t) rk[k] = atomicAdd(&th[e[k].y], 1u);
+        __syncthreads();
+        uint32_t tot_t;
+        const uint32_t ex_t = block_excl_scan(threadIdx.x < nl ? th[threadIdx.x] : 0u, scratch, tot_t);
+        if (threadIdx.x < nl) toff[threadIdx.x] = ex_t;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (k * 1024 + threadIdx.x < n_t) {
+                const uint32_t pos = toff[e[k].y] + rk[k];
+                stage_v[pos] = e[k].x;
+                stage_b[pos] = (uint16_t)e[k].y;
+            }
+        }
+        __syncthreads();
+        for (uint32_t pos = threadIdx.x; pos < n_t; pos += 1024) {
+            const uint32_t b = stage_b[pos];
+            sorted[cur[b] + (pos - toff[b])] = stage_v[pos];
+        }
+        __syncthreads();
+        if (threadIdx.x < nl) {
+            cur[threadIdx.x] += th[threadIdx.x];
+            th[threadIdx.x] = 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -1099,9 +1175,14 @@ struct MsmJob : MsmJobBase {
                            quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
                            use_ones_bin, d_cls);
         // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
-        const size_t lds2 = ((size_t)4 << lb) + 64;
+        // (long segments go through an LDS stage, see k_part_local; ZA_AMD_PART_STAGE_MIN: the tests force it for all)
+        uint32_t stage_min = 2 * PART_STAGE_TILE;
+        if (const char* e = getenv("ZA_AMD_PART_STAGE_MIN")) stage_min = (uint32_t)atol(e);
+        const bool may_stage = max_entries / nbins * 2 >= stage_min && lb <= 10;   // mean segment within 2x of the threshold
+        if (!may_stage) stage_min = 0xffffffffu;
+        const size_t lds2 = ((size_t)4 << lb) + 64 + (may_stage ? ((size_t)8 << lb) + PART_STAGE_TILE * 6 : 0);
         hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
-                           S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, S.counts.as<uint32_t>(),
+                           S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
                            S.sorted.as<uint32_t>());
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
