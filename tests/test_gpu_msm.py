@@ -87,6 +87,30 @@ def test_g1_against_c_oracle(ctx, n, pattern):
     ctx.free(d)
 
 
+@pytest.mark.parametrize("pattern", ["uniform", "bits97", "all_equal"])
+def test_g1_with_every_sort_segment_through_the_lds_stage(ctx, pattern, monkeypatch):
+    """k_part_local's staged scatter (normally for segments of 16 K entries and more: 2^24 points and up, where it is
+    covered by the full-size tests) forced onto every segment: plain windows, window table and resident bases."""
+    monkeypatch.setenv("ZA_AMD_PART_STAGE_MIN", "0")
+    n = (1 << 15) + 77
+    rng = np.random.default_rng(77)
+    d, host = _bases_from_gpu(ctx, n, 4242)
+    v = int.from_bytes(rng.bytes(32), "little") % bn.R
+    if pattern == "uniform":
+        sc = [int.from_bytes(rng.bytes(32), "little") % bn.R for _ in range(n)]
+    elif pattern == "bits97":
+        sc = [int(rng.integers(0, 2)) if rng.random() < 0.97 else int.from_bytes(rng.bytes(32), "little") % bn.R for _ in range(n)]
+    else:
+        sc = [v] * n          # one bucket per window takes everything: segments of very different lengths
+    sb = co.witness_bytes(sc)
+    exp = co.msm_g1(host, sb, threads=8)
+    assert jac_to_affine_bytes(ctx.msm_g1(host, sb), 32) == exp
+    H = ctx.msm_bases_g1_dev(d, n, table_budget_gb=1.0)
+    assert jac_to_affine_bytes(ctx.msm_resident(H, np.frombuffer(sb, dtype=np.uint8), n, dense_hint=(pattern == "uniform")), 32) == exp
+    ctx.msm_bases_free(H)
+    ctx.free(d)
+
+
 @pytest.mark.parametrize("n", [1000, 1 << 13])
 def test_g2_against_c_oracle_with_density(ctx, n):
     rng = np.random.default_rng(n)
