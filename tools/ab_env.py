@@ -1,5 +1,5 @@
 """A/B of an environment switch the library reads per call, inside ONE process (boxes and host loads differ too much for
-runs of separate processes to be compared):  python tools/ab_env.py NAME v1,v2,... [log_m] [rounds] [proofs]
+runs of separate processes to be compared):  python tools/ab_env.py NAME v1,v2,... [log_m] [rounds] [proofs] [bit_fraction]
 Alternates the values round by round; prints the median / min of zg_prove_dev and zg_prove per value."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +11,13 @@ lg = int(sys.argv[3]) if len(sys.argv) > 3 else 22
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 proofs = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 ctx = za_amd.Context(0)
-sr = synth.SynthR1CS(lg, 2, 0.97, 0x5A)
+bits = float(sys.argv[6]) if len(sys.argv) > 6 else 0.97
+sr = synth.SynthR1CS(lg, 2, bits, 0x5A if bits > 0 else 0x26)
 R = sr.load(ctx)
-P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+if lg >= 24:     # bases with known discrete logs instead of a trapdoor set-up
+    P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 7000)
+else:
+    P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
 pin = ctx.host_alloc(len(sr.witness)); pin[:] = sr.witness
 d_w = ctx.upload(sr.witness)
 ref = None
