@@ -23,6 +23,7 @@ struct FqL {
     using T = FqD;
     using Mem = Fq;
     static constexpr int MB = 2;
+    static constexpr bool QUAD = false;   // (FqQL below: one addition spread over four lanes)
     static ZG_HD T zero() { return T::zero(); }
     static ZG_HD T one() { return T::one(); }
     static ZG_HD T load_canon(const Mem* p) { return T::load_canon(p); }
@@ -68,6 +69,7 @@ struct Fq2D {
 struct Fq2L {
     using T = Fq2D;
     using Mem = Fq2;
+    static constexpr bool QUAD = false;
     static constexpr int MB = 3;  // components of a product are reduce()d: < 2.01 p
     static ZG_HD T zero() { return T{FqD::zero(), FqD::zero()}; }
     static ZG_HD T one() { return T{FqD::one(), FqD::zero()}; }
@@ -150,6 +152,7 @@ struct Fq2PL {
     using T = FqD;
     using Mem = Fq2;
     static constexpr int MB = 3;
+    static constexpr bool QUAD = false;
     static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
     static __device__ __forceinline__ uint32_t swap_u32(uint32_t v) {
         return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -220,6 +223,39 @@ struct Fq2PL {
         const T n = (sq + swap(sq)).inv();
         const T r = a * n;
         return hi() ? r.template neg<2>() : r;
+    }
+};
+
+// ---- one G1 addition on FOUR lanes.  The latency-bound kernels (the small levels of the bucket reduction, heavy-bucket
+// folds) run chains of dependent additions, and one addition is fourteen field multiplications issued one after the other
+// by a single wave (~7 us) although at most four of them depend on each other.  Here the four lanes of a quad hold COPIES
+// of both operands and each computes one product per round -- u1, u2, s1, s2 | pp, r^2, zz zz', zzz zzz' | ppp, qq, zz3 |
+// r (qq - x3), s1 ppp, zzz3 -- with the results broadcast inside the quad by DPP (quad_perm [k,k,k,k]): four rounds
+// instead of fourteen products, the same operations with the same bounds as XYZZd::add.  Costs 4 lanes' worth of issue
+// slots for ~2.2x the speed: only where lanes are idle anyway (MsmJob picks it per launch).  Memory: loads are
+// replicated (same address on the four lanes), stores are the first lane's.
+struct FqQL : FqL {
+    static constexpr bool QUAD = true;
+    static __device__ __forceinline__ uint32_t role() { return threadIdx.x & 3u; }
+    static __device__ __forceinline__ void store_red(Mem* p, const T& v) {
+        if (role() == 0) v.reduce().store(p);
+    }
+    static __device__ __forceinline__ T sel4(const T& a0, const T& a1, const T& a2, const T& a3) {
+        const uint32_t k = role();
+        T r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const uint32_t lo = k & 1u ? a1.l[i] : a0.l[i], hi = k & 1u ? a3.l[i] : a2.l[i];
+            r.l[i] = k & 2u ? hi : lo;
+        }
+        return r;
+    }
+    template <int K>
+    static __device__ __forceinline__ T bcast(const T& a) {   // lane K's value on all four lanes
+        T r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], K * 0x55, 0xF, 0xF, true);
+        return r;
     }
 };
 #endif
@@ -334,7 +370,33 @@ struct XYZZd {
         T y3 = L::template mul_sub_of_diff<BX>(r, qq, x3, y, ppp);                                            // <= 2 MB = BY
         return XYZZd{x3, y3, L::template mulx<2 * MB + 2>(zz, pp), L::template mulx<MB>(zzz, ppp)};
     }
+#if defined(__HIPCC__)
+    // add() with the products of each dependency level on the four lanes of a quad (FqQL)
+    __device__ __forceinline__ XYZZd add_quad(const XYZZd& o) const {
+        if (o.is_inf()) return *this;
+        if (is_inf()) return o;
+        const T m1 = L::mul(L::sel4(x, o.x, y, o.y), L::sel4(o.zz, zz, o.zzz, zzz));
+        const T u1 = L::template bcast<0>(m1), u2 = L::template bcast<1>(m1), s1 = L::template bcast<2>(m1), s2 = L::template bcast<3>(m1);
+        const T p = L::template sub<MB>(u2, u1);
+        const T r = L::template sub<MB>(s2, s1);
+        if (L::is_zero_mod_p(p)) {
+            if (L::is_zero_mod_p(r)) return dbl();
+            return inf();
+        }
+        const T m2 = L::mul(L::sel4(p, r, zz, zzz), L::sel4(p, r, o.zz, o.zzz));
+        const T pp = L::template bcast<0>(m2), rr = L::template bcast<1>(m2), zzo = L::template bcast<2>(m2), zzzo = L::template bcast<3>(m2);
+        const T m3 = L::mul(L::sel4(p, u1, zzo, zzo), pp);
+        const T ppp = L::template bcast<0>(m3), qq = L::template bcast<1>(m3), zz3 = L::template bcast<2>(m3);
+        const T x3 = L::template sub<3 * MB>(rr, L::add(ppp, L::add(qq, qq)));
+        const T m4 = L::mul(L::sel4(r, s1, zzzo, zzzo), L::sel4(L::template sub<BX>(qq, x3), ppp, ppp, ppp));
+        const T t0 = L::template bcast<0>(m4), t1 = L::template bcast<1>(m4), zzz3 = L::template bcast<2>(m4);
+        return XYZZd{x3, L::template sub<MB>(t0, t1), zz3, zzz3};
+    }
+#endif
     ZG_HD XYZZd add(const XYZZd& o) const {
+#if defined(__HIPCC__)
+        if constexpr (L::QUAD) return add_quad(o);
+#endif
         if (o.is_inf()) return *this;
         if (is_inf()) return o;
         T u1 = L::mul(x, o.zz);

@@ -1326,11 +1326,27 @@ struct MsmJob : MsmJobBase {
                 len >>= red_f[l];
                 const size_t groups = (size_t)rows * len;
                 XYZZ<F>* outp = S.lvl[l & 1].template as<XYZZ<F>>();
-                hipLaunchKernelGGL((k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
-                                   dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
-                                   dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
-                                   S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
-                                   heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
+                // a level of few groups is a chain of dependent additions with most of the GPU idle: G1 then runs every
+                // addition on four lanes (ecd.h FqQL; ZA_AMD_QUAD_LANES: largest such level in logical lanes, 0 = off).
+                // (The same on four lane pairs for G2 -- eight lanes, ds_swizzle broadcasts -- was measured: no gain.)
+                bool quad = false;
+                if constexpr (IS_G1) {
+                    const long qmax = getenv("ZA_AMD_QUAD_LANES") ? atol(getenv("ZA_AMD_QUAD_LANES")) : 32768;
+                    quad = (long)(groups * 2) <= qmax;
+                }
+                if (quad) {
+                    if constexpr (IS_G1)
+                        hipLaunchKernelGGL((k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
+                                           dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, cur, S.partial.as<XYZZ<F>>(),
+                                           S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l], heavy_items,
+                                           l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
+                } else {
+                    hipLaunchKernelGGL((k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
+                                       dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
+                                       dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
+                                       S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
+                                       heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
+                }
                 cur = outp;
                 red_rowbase[l] = (uint32_t)rb;   // finish(): rows of level l start here (after the kw S rows)
                 red_bitbase[l] = bb;
