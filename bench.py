@@ -173,7 +173,7 @@ def acc_roofline(prof, pmc=None):
                                            "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "both classes are ONE kernel name: this average is the one a rocprofv3 --stats "
                                                    "summary of the same command shows for k_accumulate<Fq> (profiles/r03_m_*: "
-                                                   "1081.4 us in the csv, 1111.9 us here in the same run)"}
+                                                   "1082.7 us in the csv, 1111.1 us here in the same run)"}
     # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
     roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "peak_measured": VALU_ISSUE_PEAK, "peak_nominal": VALU_ISSUE_NOMINAL,
