@@ -1,7 +1,7 @@
 """Host packing pass vs NUMA placement: pins the process to one node while the witness is allocated and to another
 while proving (argv: alloc_node run_node).  ZA_AMD_TRACE=1 prints the pass's stamps."""
 import os, sys, time, glob
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 nodes = sorted(glob.glob("/sys/devices/system/node/node[0-9]*"))
 def cpus(n):
     out = []
