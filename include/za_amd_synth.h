@@ -55,6 +55,14 @@ int zg_selftest_field_host(int which, int op, const uint8_t* a, const uint8_t* b
 int zg_selftest_field_dev(zg_ctx* ctx, int which, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
 /* out = k*p (+ q when q != NULL) with the host curve code; group 1 = G1 (64 B affine), 2 = G2 (128 B). */
 int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t* k32, const uint8_t* q, uint8_t* out);
+/* The DEVICE point arithmetic (csrc/ecd.h) operation by operation over n operand pairs.  group 1 = G1, 2 = G2.
+ * lanes: 1 = one lane per point; 2 = G2 on lane pairs (Fq2PL); 4 = G1 on four lanes (FqQL).
+ * p, q: affine points (64 / 128 B, Montgomery LE, all zero = identity); zp, zq: non-zero field elements (32 / 64 B) that
+ * choose the XYZZ representation (x z^2, y z^3, z^2, z^3) the operands are given to the operation in.
+ * op: 0 P + Q (XYZZ + XYZZ), 1 P + Q (XYZZ + affine), 2 P - Q (XYZZ + affine with y negated lazily), 3 2P,
+ *     4 (P + Q) + Q (mixed, chained), 5 (P + Q) + P (full, chained).   out: the result, affine. */
+int zg_selftest_curve_dev(zg_ctx* ctx, int group, int lanes, int op, const uint8_t* p, const uint8_t* zp,
+                          const uint8_t* q, const uint8_t* zq, uint8_t* out, size_t n);
 /* zg_prove's host-side packer (csrc/prover.hip HostPacker) on plain memory, no GPU: `threads` host threads turn n
  * 32-byte values into class bytes ((n + 3) / 4) and the other values' (index, bytes) back to back (room for n / 8).
  * *n_others = their number, or SIZE_MAX when the witness is not of the kind that packs (more than 12.5 % other values

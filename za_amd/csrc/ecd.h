@@ -344,6 +344,9 @@ struct XYZZd {
     // products shares one Montgomery reduction over Fq, and the doubling / inverse test starts with a one-multiply
     // filter.  All four outputs are normalised: X <= BX, Y <= BY, ZZ, ZZZ <= MB.
     ZG_HD XYZZd add_mixed(const AffD<L>& q) const {
+#if defined(__HIPCC__)
+        if constexpr (L::QUAD) return add_mixed_quad(q);
+#endif
         if (q.inf) return *this;
         if (is_inf()) return from_affine(q.y_canonical());
         T u2 = L::template mulx<MB>(q.x, zz);
@@ -389,6 +392,31 @@ struct XYZZd {
         const T ppp = L::template bcast<0>(m3), qq = L::template bcast<1>(m3), zz3 = L::template bcast<2>(m3);
         const T x3 = L::template sub<3 * MB>(rr, L::add(ppp, L::add(qq, qq)));
         const T m4 = L::mul(L::sel4(r, s1, zzzo, zzzo), L::sel4(L::template sub<BX>(qq, x3), ppp, ppp, ppp));
+        const T t0 = L::template bcast<0>(m4), t1 = L::template bcast<1>(m4), zzz3 = L::template bcast<2>(m4);
+        return XYZZd{x3, L::template sub<MB>(t0, t1), zz3, zzz3};
+    }
+    // add_mixed() the same way: u2, s2 | pp, r^2 | ppp, qq, zz3 | r (qq - x3), y ppp, zzz3 -- four rounds instead of ten
+    // serial products.  The operations are add_mixed()'s with add_quad()'s plain (reduced) products: p <= MB + BX and
+    // r <= MB + BY feed multiplications only, x3 <= MB + 3 MB = BX, y3 <= 2 MB = BY.  q.y may be a lazily negated
+    // canonical value (2p - y limb-wise): it is only ever a factor (round one) -- the identity and doubling branches
+    // normalise it first, as add_mixed() does.
+    __device__ __forceinline__ XYZZd add_mixed_quad(const AffD<L>& q) const {
+        if (q.inf) return *this;
+        if (is_inf()) return from_affine(q.y_canonical());
+        const T m1 = L::mul(L::sel4(q.x, q.y, q.x, q.y), L::sel4(zz, zzz, zz, zzz));
+        const T u2 = L::template bcast<0>(m1), s2 = L::template bcast<1>(m1);
+        const T p = L::template sub<BX>(u2, x);
+        const T r = L::template sub<BY>(s2, y);
+        if (L::is_zero_mod_p(p)) {
+            if (L::is_zero_mod_p(r)) return dbl_affine(q.y_canonical());
+            return inf();
+        }
+        const T m2 = L::sqr(L::sel4(p, r, p, r));
+        const T pp = L::template bcast<0>(m2), rr = L::template bcast<1>(m2);
+        const T m3 = L::mul(L::sel4(p, x, zz, zz), pp);
+        const T ppp = L::template bcast<0>(m3), qq = L::template bcast<1>(m3), zz3 = L::template bcast<2>(m3);
+        const T x3 = L::template sub<3 * MB>(rr, L::add(ppp, L::add(qq, qq)));
+        const T m4 = L::mul(L::sel4(r, y, zzz, zzz), L::sel4(L::template sub<BX>(qq, x3), ppp, ppp, ppp));
         const T t0 = L::template bcast<0>(m4), t1 = L::template bcast<1>(m4), zzz3 = L::template bcast<2>(m4);
         return XYZZd{x3, L::template sub<MB>(t0, t1), zz3, zzz3};
     }

@@ -62,6 +62,7 @@ static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (u
 
 struct MsmScratch {
     DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], ones[2], bsum, meta, heavy;
+    DevBuf abuf2, tab2, p2m;   // staged partition: level-2 output, its [segment][sub-bin][chunk] table, its plan
     static constexpr size_t HOST_BYTES = 256 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
 };
@@ -350,6 +351,289 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
     }
 }
 
+// ------------------------------------------------------------------------------------------------ staged partition
+// Large jobs (MsmJob::phase_b picks per job): every level of the partition leaves a workgroup as RUNS of consecutive
+// entries per bin.  The unstaged k_part<1> above writes each 8-byte entry where its LDS-atomic rank says: with 4097 bins a
+// tile's entries for one bin are a dozen, written one at a time by different waves, and the lines reach HBM partly
+// filled -- 275 MB written for 89 MB of entries at 2^22, 11.5 GB for 3.2 GB at 2^26 (profiles/r03_pmc_traffic*.json).
+// Here the key (bucket index, c - 1 bits, times the window when windows are not folded) is split three ways:
+//   level 1  k_part<0> counts as before, with FEW bins (2^7 or so); k_part_staged scatters: a tile's points are taken in
+//            rounds of at most PS_CAP entries, counting-sorted by bin in LDS and written out bin by bin -- a round's run
+//            for one bin is ~32 consecutive entries (256 B);
+//   level 2  k_p2<0/1>: every level-1 segment is cut into chunks of P2_CHUNK entries; per chunk a histogram over the
+//            next key bits, one exclusive scan over [segment][sub-bin][chunk] (which IS the sorted order), then the same
+//            LDS-staged scatter.  Skipped when the key space is small enough for two levels;
+//   level 3  k_part_local as before: one workgroup per (level-1 bin, level-2 sub-bin) segment, at most 2^7 buckets.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total);   // (with the scans below)
+static constexpr uint32_t PS_CAP = 4096;      // staged entries per round (8 bytes of LDS each)
+static constexpr uint32_t P2_CHUNK = 4096;    // entries per level-2 chunk (16 per thread)
+
+// (key, value) of every entry of point i -- the one place the digit walk of k_part lives for the staged kernel
+template <class Emit>
+__device__ __forceinline__ void walk_digits(Scalar256 s, uint32_t i, int c, int nwin, uint32_t wsel, uint32_t vstride, int hb,
+                                            int lb, uint32_t lomask, Emit&& emit) {
+    uint32_t carry = 0;
+    for (int w = 0; w < nwin; w++) {
+        const int32_t d = next_digit(s, c, carry);
+        if (d == 0) continue;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1u;
+        emit((((uint32_t)w & wsel) << hb) | (mag >> lb), (i + (uint32_t)w * vstride) | (d < 0 ? 0x80000000u : 0u), mag & lomask);
+    }
+}
+
+// level-1 scatter.  Same arguments and bins as k_part<1>; tile_tab holds the exclusive scan of k_part<0>'s table.
+__global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
+                                                     size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
+                                                     int lb, uint32_t ntiles, uint32_t tp, const uint32_t* __restrict__ tile_tab,
+                                                     uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
+                                                     const uint8_t* __restrict__ wcls) {
+    extern __shared__ uint32_t lds_s[];
+    const uint32_t nbins = ((uint32_t)kw << hb) + 1u;   // last bin: scalars == 1 (final order, goes to `sorted`)
+    uint32_t* hist = lds_s;                  // [nbins] the round's counts
+    uint32_t* lscan = hist + nbins;          // [nbins] their exclusive scan
+    uint32_t* cursor = lscan + nbins;        // [nbins] placement cursors
+    uint32_t* gbase = cursor + nbins;        // [nbins] where the tile's next entry of a bin goes in A / sorted
+    uint32_t* scratch = gbase + nbins;       // [16]
+    uint32_t* pfx = scratch + 16;            // [tp + 1] class << 30 | exclusive prefix of the points' entry bounds
+    uint32_t* st_v = pfx + tp + 1;           // [PS_CAP]
+    uint16_t* st_l = reinterpret_cast<uint16_t*>(st_v + PS_CAP);   // [PS_CAP] low key bits
+    uint16_t* st_b = st_l + PS_CAP;                                  // [PS_CAP] bin
+    const uint32_t wsel = kw == 1 ? 0u : ~0u;
+    const uint32_t tile = blockIdx.x;
+    const size_t base = (size_t)tile * tp;
+    const uint32_t lomask = (1u << lb) - 1u;
+    for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) gbase[b] = tile_tab[(size_t)b * ntiles + tile];
+    // ---- entry bound of every point (0, 1 or nwin) and its class, prefix-summed over the tile
+    {
+        const uint32_t per = tp / blockDim.x;   // tp is a multiple of 256
+        const uint32_t k0 = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; j++) {
+            const size_t i = base + k0 + j;
+            uint32_t cls = 0;
+            if (i < n) cls = wcls ? wcls[index ? (size_t)index[i] : i] : 2u;
+            const uint32_t ub = cls == 0 ? 0u : (cls == 1 && use_ones_bin) ? 1u : (uint32_t)nwin;
+            pfx[k0 + j] = (cls << 30) | ub;   // (the bound; replaced by the prefix below)
+            sum += ub;
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, scratch, tot);
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t v = pfx[k0 + j];
+            pfx[k0 + j] = (v & 0xC0000000u) | ex;
+            ex += v & 0x3FFFFFFFu;
+        }
+        if (threadIdx.x == blockDim.x - 1) pfx[tp] = ex;
+    }
+    __syncthreads();
+    // one point: class / scalar / subset-sum vote exactly as in k_part, entries handed to emit(bin, value, low)
+    auto point = [&](uint32_t k, bool in_round, auto&& emit) {
+        const size_t i = base + k;
+        const bool live = in_round && i < n;
+        Scalar256 s;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s.w[q] = 0;
+        bool one, zero;
+        if (wcls) {
+            const uint32_t cl = live ? pfx[k] >> 30 : 0u;
+            zero = cl == 0;
+            one = use_ones_bin && cl == 1;
+            if (cl == 2 || (cl == 1 && !use_ones_bin)) s = load_scalar(scalars, index ? (size_t)index[i] : i);
+        } else {
+            if (live) s = load_scalar(scalars, index ? (size_t)index[i] : i);
+            one = use_ones_bin && live && scalar_is_one(s);
+            zero = !live || scalar_is_zero(s);
+        }
+        if (quad_n) {
+            const uint64_t mo = __ballot(one), mr = __ballot(!one && !zero);
+            const uint32_t qb = lane_id() & ~3u;
+            const uint32_t q_ones = (uint32_t)(mo >> qb) & 15u, q_real = (uint32_t)(mr >> qb) & 15u;
+            if (q_real == 0) {
+                if (one && (lane_id() & 3u) == (uint32_t)__builtin_ctz(q_ones))
+                    emit(nbins - 1, quad_n + 15u * (uint32_t)(i >> 2) + q_ones - 1u, 0u);
+                return;
+            }
+        }
+        if (zero) return;
+        if (one) {
+            emit(nbins - 1, (uint32_t)i, 0u);
+            return;
+        }
+        walk_digits(s, (uint32_t)i, c, nwin, wsel, vstride, hb, lb, lomask, emit);
+    };
+    // ---- rounds: points [k_lo, k_hi), both multiples of four (a subset-sum group never straddles a round), whose
+    // entry bounds sum to at most PS_CAP
+    for (uint32_t k_lo = 0; k_lo < tp;) {
+        const uint32_t p_lo = pfx[k_lo] & 0x3FFFFFFFu;
+        uint32_t lo = k_lo / 4 + 1, hi = tp / 4;   // group indices; the answer is the largest g with pfx[4 g] - p_lo <= PS_CAP
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) / 2;
+            if ((pfx[4 * mid] & 0x3FFFFFFFu) - p_lo <= PS_CAP) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t k_hi = 4 * lo;
+        const uint32_t bound = (pfx[k_hi] & 0x3FFFFFFFu) - p_lo;
+        if (bound == 0) {   // nothing but zeros up to k_hi (uniform: every thread reads the same words)
+            k_lo = k_hi;
+            continue;
+        }
+        for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        const uint32_t j_lo = k_lo / blockDim.x, j_hi = (k_hi + blockDim.x - 1) / blockDim.x;
+        for (uint32_t j = j_lo; j < j_hi; j++) {
+            const uint32_t k = j * blockDim.x + threadIdx.x;
+            point(k, k >= k_lo && k < k_hi, [&](uint32_t bin, uint32_t, uint32_t) { atomicAdd(&hist[bin], 1u); });
+        }
+        __syncthreads();
+        uint32_t n_round;
+        {   // exclusive scan of the round's counts
+            const uint32_t per = (nbins + blockDim.x - 1) / blockDim.x, b0 = threadIdx.x * per;
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q < per; q++) sum += b0 + q < nbins ? hist[b0 + q] : 0u;
+            uint32_t ex = block_excl_scan(sum, scratch, n_round);
+            for (uint32_t q = 0; q < per; q++) {
+                if (b0 + q < nbins) {
+                    lscan[b0 + q] = ex;
+                    cursor[b0 + q] = ex;
+                    ex += hist[b0 + q];
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = j_lo; j < j_hi; j++) {
+            const uint32_t k = j * blockDim.x + threadIdx.x;
+            point(k, k >= k_lo && k < k_hi, [&](uint32_t bin, uint32_t val, uint32_t low) {
+                const uint32_t pos = atomicAdd(&cursor[bin], 1u);
+                st_v[pos] = val;
+                st_l[pos] = (uint16_t)low;
+                st_b[pos] = (uint16_t)bin;
+            });
+        }
+        __syncthreads();
+        for (uint32_t pos = threadIdx.x; pos < n_round; pos += blockDim.x) {
+            const uint32_t b = st_b[pos];
+            const uint32_t g = gbase[b] + (pos - lscan[b]);
+            if (b == nbins - 1) sorted[g] = st_v[pos];
+            else A[g] = make_uint2(st_v[pos], st_l[pos]);
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) gbase[b] += hist[b];
+        k_lo = k_hi;
+    }
+}
+
+// level-2 plan (one workgroup): p2m = [nb1 + 2] segment starts (regular bins, the ones bin, the total) | [nb1 + 1]
+// exclusive prefix of the segments' chunk counts
+__global__ void __launch_bounds__(256) k_p2_plan(const uint32_t* __restrict__ tile_tab, uint32_t ntiles, uint32_t nb1,
+                                                 uint32_t* __restrict__ p2m) {
+    __shared__ uint32_t lds[16];
+    uint32_t* seg_off = p2m;
+    uint32_t* cb = p2m + nb1 + 2;
+    for (uint32_t s = threadIdx.x; s < nb1 + 2; s += blockDim.x) seg_off[s] = tile_tab[(size_t)s * ntiles];
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 <= nb1; s0 += blockDim.x) {
+        const uint32_t sg = s0 + threadIdx.x;
+        const uint32_t len = sg < nb1 ? seg_off[sg + 1] - seg_off[sg] : 0u;
+        const uint32_t nch = (len + P2_CHUNK - 1) / P2_CHUNK;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(nch, lds, tot);
+        if (sg <= nb1) cb[sg] = carry + ex;
+        carry += tot;
+    }
+}
+// this workgroup's (segment, chunk): binary search in the chunk prefix
+__device__ __forceinline__ bool p2_locate(const uint32_t* __restrict__ p2m, uint32_t nb1, uint32_t* sg, uint32_t* chunk,
+                                          uint32_t* nch, uint32_t* start, uint32_t* end, uint32_t* cbase) {
+    const uint32_t* seg_off = p2m;
+    const uint32_t* cb = p2m + nb1 + 2;
+    if (blockIdx.x >= cb[nb1]) return false;
+    uint32_t lo = 0, hi = nb1 - 1;   // largest s with cb[s] <= blockIdx.x (empty segments share a value: the search lands
+    while (lo < hi) {                // on the last of them, which is the one that owns the chunk)
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if (cb[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    *sg = lo;
+    *cbase = cb[lo];
+    *chunk = blockIdx.x - cb[lo];
+    *nch = cb[lo + 1] - cb[lo];
+    *start = seg_off[lo] + *chunk * P2_CHUNK;
+    const uint32_t e = seg_off[lo + 1];
+    *end = e - *start < P2_CHUNK ? e : *start + P2_CHUNK;
+    return true;
+}
+// MODE 0: tab2[nsub * cb[seg] + sub * nch[seg] + chunk] = the chunk's entries with sub-bin `sub` (bits [b3, b3 + b2) of
+// the low key); MODE 1: tab2 scanned; the chunk is counting-sorted by sub-bin in LDS and written to `out` as runs,
+// the low key cut down to its b3 bits
+template <int MODE>
+__global__ void __launch_bounds__(256) k_p2(const uint2* __restrict__ in, const uint32_t* __restrict__ p2m, uint32_t nb1,
+                                            int b2, int b3, uint32_t* __restrict__ tab2, uint2* __restrict__ out) {
+    __shared__ uint32_t hist[128], lscan[128], gb[128], scratch[16];
+    __shared__ uint32_t st_v[MODE ? P2_CHUNK : 1];
+    __shared__ uint16_t st_l[MODE ? P2_CHUNK : 1];
+    __shared__ uint8_t st_b[MODE ? P2_CHUNK : 1];
+    uint32_t sg, chunk, nch, start, end, cbase;
+    if (!p2_locate(p2m, nb1, &sg, &chunk, &nch, &start, &end, &cbase)) return;
+    const uint32_t nsub = 1u << b2, submask = nsub - 1u, lowmask = (1u << b3) - 1u;
+    const size_t idx0 = (size_t)nsub * cbase + chunk;
+    constexpr uint32_t PER = P2_CHUNK / 256;
+    uint2 e[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t i = start + k * 256 + threadIdx.x;
+        e[k] = i < end ? in[i] : make_uint2(0u, 0u);
+    }
+    if (MODE == 0) {
+        if (threadIdx.x < nsub) hist[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++)
+            if (start + k * 256 + threadIdx.x < end) atomicAdd(&hist[(e[k].y >> b3) & submask], 1u);
+        __syncthreads();
+        if (threadIdx.x < nsub) tab2[idx0 + (size_t)threadIdx.x * nch] = hist[threadIdx.x];
+        return;
+    }
+    uint32_t cnt = 0;
+    if (threadIdx.x < nsub) {
+        const size_t ix = idx0 + (size_t)threadIdx.x * nch;
+        const uint32_t g = tab2[ix];
+        gb[threadIdx.x] = g;
+        cnt = tab2[ix + 1] - g;   // the next table entry in scan order: the next chunk of this sub-bin, or what follows it
+    }
+    uint32_t n_t;
+    const uint32_t ex = block_excl_scan(cnt, scratch, n_t);
+    if (threadIdx.x < nsub) {
+        lscan[threadIdx.x] = ex;
+        hist[threadIdx.x] = ex;   // placement cursor
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        if (start + k * 256 + threadIdx.x < end) {
+            const uint32_t sb = (e[k].y >> b3) & submask;
+            const uint32_t pos = atomicAdd(&hist[sb], 1u);
+            st_v[pos] = e[k].x;
+            st_l[pos] = (uint16_t)(e[k].y & lowmask);
+            st_b[pos] = (uint8_t)sb;
+        }
+    }
+    __syncthreads();
+    for (uint32_t pos = threadIdx.x; pos < n_t; pos += 256) {
+        const uint32_t b = st_b[pos];
+        out[gb[b] + (pos - lscan[b])] = make_uint2(st_v[pos], st_l[pos]);
+    }
+}
+// start of level-3 segment `bin` = (level-1 bin, sub-bin) in the order of the scanned level-2 table; bin == nb1 << b2 is
+// the ones bin, one more the total
+__device__ __forceinline__ uint32_t p3_start(const uint32_t* __restrict__ p2m, const uint32_t* __restrict__ tab2, uint32_t nb1,
+                                             int b2, uint32_t bin) {
+    const uint32_t sg = bin >> b2, sub = bin & ((1u << b2) - 1u);
+    if (sg >= nb1) return p2m[nb1 + sub];   // seg_off[nb1] (ones), seg_off[nb1 + 1] (total)
+    const uint32_t* cb = p2m + nb1 + 2;
+    const uint32_t c0 = cb[sg], nch = cb[sg + 1] - c0;
+    if (nch == 0) return p2m[sg];           // an empty level-1 segment
+    return tab2[((size_t)c0 << b2) + (size_t)sub * nch];
+}
+
 // ------------------------------------------------------------------------------------------------ scans
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_PER_THREAD = 16;
@@ -568,16 +852,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_one(const uint32_t* __res
 // entries also still sit in the 256 MB Infinity Cache when this kernel reads them).  Staged, with the counting pass's loads
 // eight deep and the next tile prefetched: 7.5 ms (counting 1.8, tiles 3.7, writes 2.0); the multiexp 103 -> 86 ms.
 static constexpr uint32_t PART_STAGE_TILE = 8192;
+// (p2m != nullptr: the segments are those of the staged three-level partition, see p3_start)
 __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
                                                     uint32_t ntiles, uint32_t nbins, int lb, uint32_t stage_min,
-                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted) {
+                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ p2m, const uint32_t* __restrict__ tab2,
+                                                    uint32_t nb1, int b2) {
     extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, 16 words of scan scratch; staged: see below
     const uint32_t bin = blockIdx.x;
     const int bits = bin + 1 == nbins ? 0 : lb;   // the ones bin is a single bucket
     const uint32_t nl = 1u << bits;
     uint32_t* scratch = lds_l + (1u << lb);
-    const uint32_t start = tile_off[(size_t)bin * ntiles];
-    const uint32_t end = tile_off[(size_t)(bin + 1) * ntiles];   // the scanned table has nbins*ntiles + 1 entries
+    const uint32_t start = p2m ? p3_start(p2m, tab2, nb1, b2, bin) : tile_off[(size_t)bin * ntiles];
+    const uint32_t end = p2m ? p3_start(p2m, tab2, nb1, b2, bin + 1)
+                             : tile_off[(size_t)(bin + 1) * ntiles];   // the scanned table has nbins*ntiles + 1 entries
     if (bin + 1 == nbins) {   // scalars == 1: k_part<1> already wrote them in final order
         if (threadIdx.x == 0) counts[bin << lb] = end - start;
         return;
@@ -1129,26 +1417,60 @@ struct MsmJob : MsmJobBase {
         }
         ones_key = P.nkeys;  // one extra bucket after the kw * B regular ones
         nkeys = P.nkeys + 1;
-        // bucket bits split into high (level-1 bins) and low (level-2, in LDS) parts
+        // bucket bits split into high (level-1 bins) and low (last level, in LDS) parts -- and for a large job a middle
+        // part as well: the staged three-level partition (see k_part_staged)
         const int bbits = P.c - 1;
-        int hb = (bbits + 1) / 2;
-        if (hb > 8) hb = 8;
-        if (P.kw == 1 && bbits > 12) hb = std::min(bbits - 7, 12);   // folded windows: keep about 4096 level-1 bins
-        while (hb > 0 && (((size_t)P.kw << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
-        const int lb = bbits - hb;
-        const uint32_t nbins = ((uint32_t)P.kw << hb) + 1u;
-        const uint32_t tp = n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
+        const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
+        const bool small_job = eager_small || n <= msm_small_n();
+        bool staged = !small_job && max_entries >= ((size_t)1 << 20) && bbits >= 7;
+        if (const char* e = getenv("ZA_AMD_SORT_STAGED")) staged = staged && atoi(e) != 0;   // A/B switch: 0 = the two-level scatter
+        int hb, lb, b2 = 0;
+        if (staged) {
+            const int b3 = 7, r = bbits - b3;
+            int lgkw = 0;
+            while ((1 << lgkw) < P.kw) lgkw++;
+            if (((size_t)P.kw << r) <= 512) {   // the key space is small enough for two levels
+                hb = r;
+            } else {
+                hb = std::min(r, std::max(0, 7 - lgkw));
+                b2 = r - hb;
+                if (b2 > 7) {
+                    hb += b2 - 7;
+                    b2 = 7;
+                }
+            }
+            lb = b2 + b3;   // what level 1 leaves in an entry's low word
+            if ((((size_t)P.kw << hb) + 1) > 1024) staged = false;   // (c > 23 with unfolded windows: not a plan we make)
+        }
+        if (!staged) {
+            b2 = 0;
+            hb = (bbits + 1) / 2;
+            if (hb > 8) hb = 8;
+            if (P.kw == 1 && bbits > 12) hb = std::min(bbits - 7, 12);   // folded windows: keep about 4096 level-1 bins
+            while (hb > 0 && (((size_t)P.kw << hb) + 1) * 4 > 48 * 1024) hb--;   // level-1 LDS histogram budget
+            lb = bbits - hb;
+        }
+        const uint32_t nbins = ((uint32_t)P.kw << hb) + 1u;   // level-1 bins (+ the ones bin)
+        const uint32_t tp = staged ? (n >= ((size_t)1 << 23) ? 4096u : 2048u) : n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
         const uint32_t ntiles = (uint32_t)((n + tp - 1) / tp);
         const size_t tab_n = (size_t)nbins * ntiles;
-        const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
-        // counts is indexed by key = bin << lb | low bits; the ones bin only uses low bits == 0
-        const size_t counts_n = ((size_t)nbins << lb) + 1;
+        // last level: lb3 low bits per segment, nbins3 segments (+ the ones bin)
+        const int lb3 = staged ? 7 : lb;
+        const uint32_t nb1 = nbins - 1u, nbins3 = staged ? (nb1 << b2) + 1u : nbins;
+        // counts is indexed by key = segment << lb3 | low bits; the ones bin only uses low bits == 0
+        const size_t counts_n = ((size_t)nbins3 << lb3) + 1;
         ZG_HIP(ctx, S.counts.reserve(counts_n * 4));
         ZG_HIP(ctx, S.offsets.reserve((size_t)(nkeys + 1) * 4));
         ZG_HIP(ctx, S.item_off.reserve((size_t)(nkeys + 1) * 4));
         ZG_HIP(ctx, S.tile_tab.reserve((tab_n + 1) * 4));
         ZG_HIP(ctx, S.abuf.reserve(max_entries * 8));
         ZG_HIP(ctx, S.sorted.reserve(max_entries * 4));
+        // level-2 table of the staged partition: [segment][sub-bin][chunk], sized from the bound on the entries
+        const size_t maxchunks = max_entries / P2_CHUNK + nb1 + 1, n2 = staged && b2 > 0 ? maxchunks << b2 : 0;
+        // (one block-sum buffer for every scan of this phase, reserved before anything is queued: growing it later would
+        // free memory that queued kernels still use)
+        ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>(std::max<size_t>((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE, (n2 + 1 + SCAN_TILE - 1) / SCAN_TILE),
+                                                    (size_t)2 * ((nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE)) * 4));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
@@ -1157,33 +1479,59 @@ struct MsmJob : MsmJobBase {
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
                            d_cls);
-        {   // exclusive scan of the [bin][tile] table (+ total in the last entry)
-            const uint32_t nbx = (uint32_t)((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE);
-            const uint32_t nbk = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
-            ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>((size_t)nbx, (size_t)2 * nbk) * 4));
-            if (tab_n + 1 <= SCAN_ONE_MAX) {
-                hipLaunchKernelGGL(k_xscan_one, dim3(1), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n);
+        // exclusive scan of a u32 table of tn entries in place (+ the total in entry tn)
+        auto xscan = [&](uint32_t* tab, size_t tn) -> int {
+            const uint32_t nbx = (uint32_t)((tn + 1 + SCAN_TILE - 1) / SCAN_TILE);
+            if (tn + 1 <= SCAN_ONE_MAX) {
+                hipLaunchKernelGGL(k_xscan_one, dim3(1), dim3(SCAN_THREADS), 0, st, tab, tn);
             } else {
-                hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
-                                   S.bsum.as<uint32_t>());
+                hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
                 hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
-                hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, S.tile_tab.as<uint32_t>(), tab_n,
-                                   S.bsum.as<uint32_t>());
+                hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
             }
-        }
-        hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
-                           quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
-                           use_ones_bin, d_cls);
-        // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
-        // (long segments go through an LDS stage, see k_part_local; ZA_AMD_PART_STAGE_MIN: the tests force it for all)
+            return ZG_OK;
+        };
+        ZG_TRY(xscan(S.tile_tab.as<uint32_t>(), tab_n));   // the [bin][tile] table
+        // (long segments of the last level go through an LDS stage, see k_part_local; ZA_AMD_PART_STAGE_MIN: the tests
+        // force it for all)
         uint32_t stage_min = 2 * PART_STAGE_TILE;
         if (const char* e = getenv("ZA_AMD_PART_STAGE_MIN")) stage_min = (uint32_t)atol(e);
-        const bool may_stage = max_entries / nbins * 2 >= stage_min && lb <= 10;   // mean segment within 2x of the threshold
+        const bool may_stage = max_entries / nbins3 * 2 >= stage_min && lb3 <= 10;   // mean segment within 2x of the threshold
         if (!may_stage) stage_min = 0xffffffffu;
-        const size_t lds2 = ((size_t)4 << lb) + 64 + (may_stage ? ((size_t)8 << lb) + PART_STAGE_TILE * 6 : 0);
-        hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
-                           S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
-                           S.sorted.as<uint32_t>());
+        const size_t lds2 = ((size_t)4 << lb3) + 64 + (may_stage ? ((size_t)8 << lb3) + PART_STAGE_TILE * 6 : 0);
+        if (staged) {
+            const size_t lds_s = ((size_t)4 * nbins + 16 + tp + 1) * 4 + (size_t)PS_CAP * 8;
+            hipLaunchKernelGGL(k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
+                               vstride, quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(),
+                               S.sorted.as<uint32_t>(), use_ones_bin, d_cls);
+            if (b2 > 0) {
+                ZG_HIP(ctx, S.p2m.reserve(((size_t)2 * nb1 + 4) * 4));
+                ZG_HIP(ctx, S.tab2.reserve((n2 + 1) * 4));
+                ZG_HIP(ctx, S.abuf2.reserve(max_entries * 8));
+                hipLaunchKernelGGL(k_p2_plan, dim3(1), dim3(256), 0, st, S.tile_tab.as<uint32_t>(), ntiles, nb1, S.p2m.as<uint32_t>());
+                ZG_HIP(ctx, hipMemsetAsync(S.tab2.p, 0, (n2 + 1) * 4, st));   // chunks beyond the data-dependent count stay empty
+                hipLaunchKernelGGL(k_p2<0>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
+                                   nb1, b2, 7, S.tab2.as<uint32_t>(), (uint2*)nullptr);
+                ZG_TRY(xscan(S.tab2.as<uint32_t>(), n2));
+                hipLaunchKernelGGL(k_p2<1>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
+                                   nb1, b2, 7, S.tab2.as<uint32_t>(), S.abuf2.as<uint2>());
+                hipLaunchKernelGGL(k_part_local, dim3(nbins3), dim3(1024), lds2, st, S.abuf2.as<uint2>(), (const uint32_t*)nullptr,
+                                   0u, nbins3, lb3, stage_min, S.counts.as<uint32_t>(), S.sorted.as<uint32_t>(),
+                                   S.p2m.as<uint32_t>(), S.tab2.as<uint32_t>(), nb1, b2);
+            } else {
+                hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
+                                   S.tile_tab.as<uint32_t>(), ntiles, nbins, lb3, stage_min, S.counts.as<uint32_t>(),
+                                   S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+            }
+        } else {
+            hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
+                               quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
+                               use_ones_bin, d_cls);
+            // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
+            hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
+                               S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
+                               S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+        }
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
         if ((size_t)nkeys + 1 <= SCAN_ONE_MAX) {
@@ -1272,7 +1620,20 @@ struct MsmJob : MsmJobBase {
             static const long pair_max = getenv("ZA_AMD_G2_PAIR_ITEMS") ? atol(getenv("ZA_AMD_G2_PAIR_ITEMS")) : 0x7fffffffL;
             const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
             const uint32_t* acc_perm = order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr;
-            if (CLP > 1 && (long)total_items <= pair_max)
+            // A small G1 job's accumulation is a chain of T dependent mixed additions per item on a nearly idle GPU: every
+            // addition then runs on four lanes (ecd.h add_mixed_quad: four rounds of one product instead of ten serial ones).
+            // ZA_AMD_QUAD_ACC: largest such launch in lanes (0 = off).
+            bool quad_acc = false;
+            if constexpr (IS_G1) {
+                const long qa_max = getenv("ZA_AMD_QUAD_ACC") ? atol(getenv("ZA_AMD_QUAD_ACC")) : 262144;
+                quad_acc = (eager_small || n <= msm_small_n()) && (long)total_items * 4 <= qa_max;
+            }
+            if (quad_acc) {
+                if constexpr (IS_G1)
+                    hipLaunchKernelGGL((k_accumulate<F, FqQL, 4>), dim3((unsigned)(((size_t)total_items * 4 + 255) / 256)), dim3(256), 0, st,
+                                       acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
+                                       S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
+            } else if (CLP > 1 && (long)total_items <= pair_max)
                 hipLaunchKernelGGL((k_accumulate<F, CL, CLP>), dim3((unsigned)(((size_t)total_items * CLP + 255) / 256)), dim3(256), 0, st,
                                    acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                    S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());

@@ -457,6 +457,107 @@ extern "C" int zg_selftest_curve_host(int group, const uint8_t* p, const uint8_t
 } catch (...) {
     return zg::on_exception(nullptr);
 }
+// ---- device point arithmetic, operation by operation (tests/test_gpu_curve.py).  The multiexp kernels only ever see
+// ecd.h's additions end to end; here every form runs on the device over caller-chosen operands: one lane per point
+// (FqL / Fq2L), G2 on lane pairs (Fq2PL), G1 on four lanes (FqQL).
+// P, Q: affine, device form.  ZP, ZQ: field elements z != 0 that pick the XYZZ representation (x z^2, y z^3, z^2, z^3).
+template <class F>
+__global__ void __launch_bounds__(128) k_st_mkxyzz(const Affine<F>* __restrict__ a, const F* __restrict__ z,
+                                                   XYZZ<F>* __restrict__ out, size_t n) {
+    using L = typename LazyOf<F>::L;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffD<L> p = AffD<L>::load(&a[i]);
+    if (p.inf) {
+        XYZZd<L>::inf().store(&out[i]);
+        return;
+    }
+    const typename L::T zv = L::load_canon(&z[i]);
+    const typename L::T zz = L::sqr(zv), zzz = L::mul(zz, zv);
+    XYZZd<L>{L::mul(p.x, zz), L::mul(p.y, zzz), zz, zzz}.store(&out[i]);
+}
+// op: 0 A + B (both XYZZ), 1 A + Q (mixed), 2 A - Q (mixed, y negated lazily as k_accumulate does), 3 2A,
+//     4 (A + Q) + Q and 5 (A + B) + A: the second addition's operands are the first one's outputs (bounds of a chain)
+template <class F, class L, int LP>
+__global__ void __launch_bounds__(128) k_st_curve(int op, const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ B,
+                                                  const Affine<F>* __restrict__ Q, XYZZ<F>* __restrict__ out, size_t n) {
+    const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LP;
+    if (t >= n) return;   // (the LP lanes of a point leave together)
+    const XYZZd<L> a = XYZZd<L>::load(&A[t]);
+    XYZZd<L> r = XYZZd<L>::inf();
+    switch (op) {
+        case 0: r = a.add(XYZZd<L>::load(&B[t])); break;
+        case 1: r = a.add_mixed(AffD<L>::load(&Q[t])); break;
+        case 2: r = a.add_mixed(AffD<L>::load(&Q[t]).negated_lazy()); break;
+        case 3: r = a.dbl(); break;
+        case 4: { const AffD<L> q = AffD<L>::load(&Q[t]); r = a.add_mixed(q).add_mixed(q); break; }
+        default: r = a.add(XYZZd<L>::load(&B[t])).add(a); break;
+    }
+    r.store(&out[t]);
+}
+template <class F>
+__global__ void __launch_bounds__(128) k_st_toaffine(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, size_t n) {
+    using L = typename LazyOf<F>::L;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZd<L>::load(&in[i]).to_affine_mem(&out[i]);
+}
+template <class F>
+static int st_curve_dev(zg_ctx* ctx, int lanes, int op, const uint8_t* p, const uint8_t* zp, const uint8_t* q,
+                        const uint8_t* zq, uint8_t* out, size_t n) {
+    constexpr bool G1 = sizeof(F) == sizeof(Fq);
+    if ((lanes != 1 && lanes != (G1 ? 4 : 2)) || op < 0 || op > 5) return fail(ctx, ZG_E_INVALID_ARG, "selftest: lanes / op");
+    if (n == 0) return ZG_OK;
+    const size_t ab = sizeof(Affine<F>), fb = sizeof(F);
+    DevBuf dp, dq, dzp, dzq, xa, xb, xo, ao;
+    ZG_HIP(ctx, dp.alloc(n * ab)); ZG_HIP(ctx, dq.alloc(n * ab)); ZG_HIP(ctx, dzp.alloc(n * fb)); ZG_HIP(ctx, dzq.alloc(n * fb));
+    ZG_HIP(ctx, xa.alloc(n * sizeof(XYZZ<F>))); ZG_HIP(ctx, xb.alloc(n * sizeof(XYZZ<F>))); ZG_HIP(ctx, xo.alloc(n * sizeof(XYZZ<F>)));
+    ZG_HIP(ctx, ao.alloc(n * ab));
+    hipStream_t st = ctx->stream;
+    ZG_HIP(ctx, hipMemcpyAsync(dp.p, p, n * ab, hipMemcpyHostToDevice, st));
+    ZG_HIP(ctx, hipMemcpyAsync(dq.p, q, n * ab, hipMemcpyHostToDevice, st));
+    ZG_HIP(ctx, hipMemcpyAsync(dzp.p, zp, n * fb, hipMemcpyHostToDevice, st));
+    ZG_HIP(ctx, hipMemcpyAsync(dzq.p, zq, n * fb, hipMemcpyHostToDevice, st));
+    ZG_TRY(convert_mont_dev(ctx, dp.p, n * ab / 32, 0, 0));   // ABI form -> device form, canonical
+    ZG_TRY(convert_mont_dev(ctx, dq.p, n * ab / 32, 0, 0));
+    ZG_TRY(convert_mont_dev(ctx, dzp.p, n * fb / 32, 0, 0));
+    ZG_TRY(convert_mont_dev(ctx, dzq.p, n * fb / 32, 0, 0));
+    const unsigned g1 = (unsigned)((n + 127) / 128);
+    hipLaunchKernelGGL((k_st_mkxyzz<F>), dim3(g1), dim3(128), 0, st, dp.as<Affine<F>>(), dzp.as<F>(), xa.as<XYZZ<F>>(), n);
+    hipLaunchKernelGGL((k_st_mkxyzz<F>), dim3(g1), dim3(128), 0, st, dq.as<Affine<F>>(), dzq.as<F>(), xb.as<XYZZ<F>>(), n);
+    const unsigned gl = (unsigned)((n * (size_t)lanes + 127) / 128);
+    if constexpr (G1) {
+        if (lanes == 4)
+            hipLaunchKernelGGL((k_st_curve<F, FqQL, 4>), dim3(gl), dim3(128), 0, st, op, xa.as<XYZZ<F>>(), xb.as<XYZZ<F>>(),
+                               dq.as<Affine<F>>(), xo.as<XYZZ<F>>(), n);
+        else
+            hipLaunchKernelGGL((k_st_curve<F, FqL, 1>), dim3(gl), dim3(128), 0, st, op, xa.as<XYZZ<F>>(), xb.as<XYZZ<F>>(),
+                               dq.as<Affine<F>>(), xo.as<XYZZ<F>>(), n);
+    } else {
+        if (lanes == 2)
+            hipLaunchKernelGGL((k_st_curve<F, Fq2PL, 2>), dim3(gl), dim3(128), 0, st, op, xa.as<XYZZ<F>>(), xb.as<XYZZ<F>>(),
+                               dq.as<Affine<F>>(), xo.as<XYZZ<F>>(), n);
+        else
+            hipLaunchKernelGGL((k_st_curve<F, Fq2L, 1>), dim3(gl), dim3(128), 0, st, op, xa.as<XYZZ<F>>(), xb.as<XYZZ<F>>(),
+                               dq.as<Affine<F>>(), xo.as<XYZZ<F>>(), n);
+    }
+    hipLaunchKernelGGL((k_st_toaffine<F>), dim3(g1), dim3(128), 0, st, xo.as<XYZZ<F>>(), ao.as<Affine<F>>(), n);
+    ZG_HIP(ctx, hipGetLastError());
+    ZG_TRY(convert_mont_dev(ctx, ao.p, n * ab / 32, 0, 1));
+    ZG_HIP(ctx, hipMemcpyAsync(out, ao.p, n * ab, hipMemcpyDeviceToHost, st));
+    ZG_HIP(ctx, hipStreamSynchronize(st));
+    return ZG_OK;
+}
+extern "C" int zg_selftest_curve_dev(zg_ctx* ctx, int group, int lanes, int op, const uint8_t* p, const uint8_t* zp,
+                                     const uint8_t* q, const uint8_t* zq, uint8_t* out, size_t n) try {
+    if (!ctx || !p || !zp || !q || !zq || !out) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    if (group == 1) return st_curve_dev<Fq>(ctx, lanes, op, p, zp, q, zq, out, n);
+    if (group == 2) return st_curve_dev<Fq2>(ctx, lanes, op, p, zp, q, zq, out, n);
+    return fail(ctx, ZG_E_INVALID_ARG, "selftest: group %d", group);
+} catch (...) {
+    return zg::on_exception(ctx);
+}
 // Parse and validate a bellman Parameters body without a GPU.  counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, consumed.
 // err (nullable) receives the parser's message.
 extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap) try {

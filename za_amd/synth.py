@@ -12,7 +12,7 @@ from . import Context, Params, ZaAmdError, load_library
 SYNTH_SYMBOLS = ["zg_synth_r1cs_new", "zg_synth_r1cs_info", "zg_synth_ptr", "zg_synth_free",
                  "zg_synth_bases_g1_dev", "zg_synth_bases_g2_dev", "zg_synth_params_dev", "zg_synth_dlog",
                  "zg_synth_scalars_dev", "zg_params_download", "zg_params_shard",
-                 "zg_selftest_field_host", "zg_selftest_field_dev", "zg_selftest_curve_host", "zg_params_inspect",
+                 "zg_selftest_field_host", "zg_selftest_field_dev", "zg_selftest_curve_host", "zg_selftest_curve_dev", "zg_params_inspect",
                  "zg_selftest_pack_mt"]
 
 MASK64 = (1 << 64) - 1
