@@ -67,6 +67,30 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  * evaluation-form bases (2 s at 2^22) and the window / subset-sum tables (0.3 s) -- and the proof takes bellman's own
  * schedule of seven transforms.  Same proof bytes either way. */
 #define ZG_OPT_ONE_SHOT 1
+/* What a deployed host may want to change about the precomputation and the witness hand-over (none of it changes a
+ * proof's bytes):
+ *   ZG_OPT_PACK           zg_prove / zg_witness_to_device hand a witness that is mostly zeros and ones over in packed
+ *                         form (host threads build it, 3 % of the bytes cross PCIe): 1 = whenever the witness is of
+ *                         that kind (default), 0 = never (the 32-byte array is copied as it is), 2 = as 1, but while the
+ *                         pass measures slower than the plain copy on this host the next 32 witnesses go over unpacked.
+ *   ZG_OPT_PACK_THREADS   host threads of that pass, the caller's included (default min(8, half the hardware threads);
+ *                         0 = the default).
+ *   ZG_OPT_PACK_MIN_LOG_N witnesses of fewer than 2^value values are never packed (default 20).
+ *   ZG_OPT_PACK_PIN       1 (default): the pass's worker threads are bound to the CPUs of the GPU's NUMA node, where
+ *                         zg_host_alloc's pinned memory lives; 0 = left to the scheduler.
+ *   ZG_OPT_H_EVAL         1 (default): keys get their h query in evaluation form (one transform fewer per proof, paid
+ *                         once per key); 0 = bellman's coefficient form.  Read when a key is loaded / first used.
+ *   ZG_OPT_TABLES         bit mask over (h, l, a, b_g1, b_g2): the queries that may get a window / subset-sum table
+ *                         (default 31; 0 = none).  Read when a key's tables are first built.
+ *   ZG_OPT_TABLES_MAX_MB  cap on the memory of one table in MB (default 0 = 60 % of the free HBM). */
+#define ZG_OPT_PACK 2
+#define ZG_OPT_PACK_THREADS 3
+#define ZG_OPT_PACK_MIN_LOG_N 4
+#define ZG_OPT_PACK_PIN 5
+#define ZG_OPT_H_EVAL 6
+#define ZG_OPT_TABLES 7
+#define ZG_OPT_TABLES_MAX_MB 8
+#define ZG_OPT_PACK_BUDGET_PERMILLE 9   /* ZG_OPT_PACK = 2: the share of the plain copy's time the pass may take (default 900) */
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 

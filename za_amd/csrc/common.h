@@ -30,6 +30,15 @@ struct Ctx {
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
     bool one_shot = false;       // zg_set_option(ZG_OPT_ONE_SHOT): no per-key precomputation
+    // zg_set_option: the witness hand-over and the per-key precomputation (include/za_amd.h)
+    int opt_pack = 1;            // 0 never, 1 always for a bit-heavy witness, 2 with the slow-host fallback
+    int opt_pack_threads = 0;    // 0 = min(8, hardware threads / 2)
+    int opt_pack_min_log_n = 20;
+    bool opt_pack_pin = true;
+    int opt_pack_budget_permille = 900;
+    bool opt_h_eval = true;
+    unsigned opt_tables = 31;
+    uint64_t opt_tables_max_mb = 0;
     bool ntt_attr_set = false;   // the transform kernels' dynamic-LDS attribute is set on this ctx's device
     // persistent prove workspace (a, b, c evaluation vectors and H scalars), grown on demand
     struct ProveWs* prove_ws = nullptr;
@@ -189,7 +198,7 @@ int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const
 // points of the h query -- the bases that go with h_eval_dev's scalars.  One-time work per key.
 int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log_m, G1Affine* d_out);
 // prover.hip: give a SHARDED key its slice of the evaluation-form h bases from the whole query (device form, on this
-// device); no-op (state -1) when the query length is not 2^k - 1 or ZA_AMD_H_EVAL=0
+// device); no-op (state -1) when the query length is not 2^k - 1 or ZG_OPT_H_EVAL is 0
 int params_h_eval_slice(Ctx* ctx, const struct ::zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full);
 int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out);
 int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host);

@@ -1423,7 +1423,10 @@ struct MsmJob : MsmJobBase {
         const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
         const bool small_job = eager_small || n <= msm_small_n();
         bool staged = !small_job && max_entries >= ((size_t)1 << 20) && bbits >= 7;
-        if (const char* e = getenv("ZA_AMD_SORT_STAGED")) staged = staged && atoi(e) != 0;   // A/B switch: 0 = the two-level scatter
+        if (const char* e = getenv("ZA_AMD_SORT_STAGED")) {   // 0 = the two-level scatter (A/B); 2 / 3 = staged for every large /
+            const int v = atoi(e);                             // every job with at least 2^7 buckets (tests)
+            staged = v == 0 ? false : v == 2 ? (!small_job && bbits >= 7) : v == 3 ? bbits >= 7 : staged;
+        }
         int hb, lb, b2 = 0;
         if (staged) {
             const int b3 = 7, r = bbits - b3;

@@ -14,8 +14,11 @@
 #include <memory>
 #include <cstdarg>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <random>
+#include <pthread.h>
+#include <sched.h>
 
 #include "common.h"
 #include "formats.h"
@@ -176,11 +179,22 @@ __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, co
 
 // A few persistent host threads for the one piece of per-proof host work that is worth spreading: packing a
 // bit-heavy witness before it crosses PCIe (zg_prove).  parallel_for(n, fn) runs fn(0) .. fn(n - 1) on the workers
-// and the calling thread and returns when all are done.
+// and the calling thread and returns when all TASKS are done -- not when every worker has checked in: on a busy host a
+// worker may wake a millisecond late, and then it simply finds nothing left to do (the caller and the others have taken
+// its share), instead of the whole pass waiting for it.
+// cpus (may be empty): the workers are bound to these CPUs -- the GPU's NUMA node, where the pinned witness lives.
 class WorkerPool {
 public:
-    explicit WorkerPool(int n_threads) {
+    WorkerPool(int n_threads, const std::vector<int>& cpus) {
         for (int i = 0; i < n_threads; i++) th.emplace_back([this] { loop(); });
+        if (!cpus.empty()) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int c : cpus)
+                if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+            for (auto& t : th) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);   // best effort
+            pinned = true;
+        }
     }
     ~WorkerPool() {
         {
@@ -191,65 +205,119 @@ public:
         for (auto& t : th) t.join();
     }
     int threads() const { return (int)th.size() + 1; }
+    bool is_pinned() const { return pinned; }
     void parallel_for(int n_tasks, const std::function<void(int)>& f) {
+        if (n_tasks <= 0) return;
+        uint32_t g;
         {
             std::lock_guard<std::mutex> lock(mu);
             fn = &f;
             total = n_tasks;
-            next.store(0);
-            busy = (int)th.size();
-            busy_relaxed.store(busy, std::memory_order_release);
-            gen++;
+            g = ++gen;
+            done.store(0, std::memory_order_relaxed);
+            next.store((uint64_t)g << 32, std::memory_order_release);
         }
         cv.notify_all();
-        run();
-        // the workers are done within microseconds of this thread: spin briefly before sleeping on the condition variable
-        for (int spin = 0; spin < 20000 && busy_relaxed.load(std::memory_order_acquire) != 0; spin++) {
+        run(g, &f, n_tasks);
+        // what is left are the tasks other threads are in the middle of: microseconds
+        for (int spin = 0; spin < 200000 && done.load(std::memory_order_acquire) != n_tasks; spin++) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
         }
         std::unique_lock<std::mutex> lock(mu);
-        cv_done.wait(lock, [this] { return busy == 0; });
+        cv_done.wait(lock, [&] { return done.load(std::memory_order_acquire) == n_tasks; });
         fn = nullptr;
     }
 
 private:
-    void run() {
+    // take tasks of generation g only: a worker that wakes after its generation is over must neither run a stale
+    // function nor take an index of the next generation
+    void run(uint32_t g, const std::function<void(int)>* f, int n_tasks) {
         for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= total) break;
-            (*fn)(i);
+            uint64_t v = next.load(std::memory_order_acquire);
+            if ((uint32_t)(v >> 32) != g || (int)(uint32_t)v >= n_tasks) return;
+            if (!next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
+            (*f)((int)(uint32_t)v);
+            if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == n_tasks) {
+                std::lock_guard<std::mutex> lock(mu);   // (the waiter checks `done` under this mutex: no lost wake-up)
+                cv_done.notify_one();
+            }
         }
     }
     void loop() {
-        uint64_t seen = 0;
+        uint32_t seen = 0;
         for (;;) {
+            const std::function<void(int)>* f;
+            int n_tasks;
+            uint32_t g;
             {
                 std::unique_lock<std::mutex> lock(mu);
                 cv.wait(lock, [&] { return stop || gen != seen; });
                 if (stop) return;
-                seen = gen;
+                seen = g = gen;
+                f = fn;
+                n_tasks = total;
             }
-            run();
-            {
-                std::lock_guard<std::mutex> lock(mu);
-                busy--;
-                busy_relaxed.store(busy, std::memory_order_release);
-            }
-            cv_done.notify_one();
+            if (f) run(g, f, n_tasks);
         }
     }
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv, cv_done;
     const std::function<void(int)>* fn = nullptr;
-    int total = 0, busy = 0;
-    std::atomic<int> next{0};
-    std::atomic<int> busy_relaxed{0};   // mirror of `busy` for the caller's spin
-    uint64_t gen = 0;
-    bool stop = false;
+    int total = 0;
+    std::atomic<uint64_t> next{0};   // generation << 32 | next task
+    std::atomic<int> done{0};
+    uint32_t gen = 0;
+    bool stop = false, pinned = false;
 };
+
+// CPUs of the NUMA node the GPU hangs off (sysfs; empty when that cannot be told, when the node has no CPUs this process
+// may run on, or when there is only one node)
+static std::vector<int> gpu_node_cpus(int device) {
+    std::vector<int> cpus;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return cpus;
+    }
+    for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+    int node = -1;
+    {
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return cpus;
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return cpus;
+    {
+        FILE* f = fopen("/sys/devices/system/node/node1/cpulist", "r");   // a single-node host: nothing to choose
+        if (!f) return cpus;
+        fclose(f);
+    }
+    char list[4096] = {0};
+    {
+        const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return cpus;
+        if (!fgets(list, sizeof(list), f)) list[0] = 0;
+        fclose(f);
+    }
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return cpus;
+    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k < 1) continue;
+        if (k == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+    }
+    return cpus;
+}
 
 static inline uint32_t value_class(const uint8_t* v) {
     uint64_t q[4];
@@ -270,10 +338,12 @@ struct HostPacker {
     std::vector<Slice> slices;
     static constexpr size_t SLICE_VALS = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
 
+    // pin_cpus: where the worker threads run (empty = wherever the scheduler puts them)
     void run(const uint8_t* witness32, size_t nv, int nthreads, uint8_t* classes, uint32_t* idx_out, uint8_t* val_out,
-             size_t* n_others_out, const std::function<void(const char*)>& stamp) {
+             size_t* n_others_out, const std::function<void(const char*)>& stamp, const std::vector<int>& pin_cpus = {}) {
         *n_others_out = SIZE_MAX;
-        if (!pool || pool->threads() != nthreads) pool.reset(new WorkerPool(nthreads - 1));
+        if (!pool || pool->threads() != nthreads || pool->is_pinned() != !pin_cpus.empty())
+            pool.reset(new WorkerPool(nthreads - 1, pin_cpus));
         const int n_slices = (int)((nv + SLICE_VALS - 1) / SLICE_VALS);
         const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
         if ((int)slices.size() < n_slices) slices.resize(n_slices);
@@ -286,9 +356,11 @@ struct HostPacker {
                 if (abort.load(std::memory_order_relaxed)) return;
                 const size_t lo = (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
                 const size_t cap = SLICE_VALS / 2;   // a slice denser than 50 % ends the attempt
-                if (sl.idx.size() < cap) {
-                    sl.idx.resize(cap);
-                    sl.val.resize(cap * 32);
+                // (the lists grow on demand: sized for 50 % from the start they were 74 MB of zero-filled heap at 2^22, 1.2 GB
+                // at 2^26, for a witness whose slices are 3 % dense)
+                if (sl.idx.size() < SLICE_VALS / 16) {
+                    sl.idx.resize(SLICE_VALS / 16);
+                    sl.val.resize(SLICE_VALS / 16 * 32);
                 }
                 size_t k = 0;
                 for (size_t i = lo; i < hi; i += 4) {   // slice bounds are multiples of 4: one class byte per group
@@ -299,9 +371,13 @@ struct HostPacker {
                         const uint32_t c = value_class(v);
                         byte |= c << (2 * (j - i));
                         if (c == 2u) {
-                            if (k == cap) {
-                                abort.store(true);
-                                return;
+                            if (k == sl.idx.size()) {
+                                if (k >= cap) {
+                                    abort.store(true);
+                                    return;
+                                }
+                                sl.idx.resize(std::min(cap, 2 * k));
+                                sl.val.resize(sl.idx.size() * 32);
                             }
                             sl.idx[k] = (uint32_t)j;
                             memcpy(&sl.val[32 * k], v, 32);
@@ -342,8 +418,14 @@ struct ProveWs {
     double pack_ema_ms = 0;   // running average of the packing pass's host time
     int pack_slow = 0;        // consecutive passes slower than the plain upload
     int pack_skip = 0;        // proofs left to hand over unpacked after the pass turned out slower than the plain upload
-    uint8_t* stage = nullptr;   // pinned: [classes | other_index | others32]
-    size_t stage_bytes = 0;
+    // pinned: [classes | other_index | others32].  Two of them, used in turn, each with the event behind its copies: a
+    // hand-over is queued, not waited for (zg_witness_to_device), so the next one must not pack into bytes still in flight
+    uint8_t* stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    std::vector<int> pin_cpus;   // the GPU's NUMA node (ZG_OPT_PACK_PIN), looked up once
+    bool pin_looked_up = false;
     DevBuf pk_cls, pk_idx, pk_val;   // zg_prove_packed: the packed witness as uploaded
     // wcls: one class byte per witness value (k_witness_classes), shared by the evaluator and the witness multiexps.
     // wcls_for: the witness it was computed from; wcls_fresh: computed inside the current API call (the evaluator
@@ -357,7 +439,10 @@ struct ProveWs {
     hipEvent_t bad_ev = nullptr;
     bool bad_pending = false;
     ~ProveWs() {
-        if (stage) (void)hipHostFree(stage);
+        for (int k = 0; k < 2; k++) {
+            if (stage[k]) (void)hipHostFree(stage[k]);
+            if (stage_ev[k]) (void)hipEventDestroy(stage_ev[k]);
+        }
         if (bad_host) (void)hipHostFree(bad_host);
         if (bad_ev) (void)hipEventDestroy(bad_ev);
     }
@@ -600,6 +685,32 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
     if (!ctx) return ZG_E_INVALID_ARG;
     switch (option) {
         case ZG_OPT_ONE_SHOT: ctx->one_shot = value != 0; return ZG_OK;
+        case ZG_OPT_PACK:
+            if (value < 0 || value > 2) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK takes 0, 1 or 2");
+            ctx->opt_pack = (int)value;
+            return ZG_OK;
+        case ZG_OPT_PACK_THREADS:
+            if (value < 0 || value > 1024) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_THREADS: 0 .. 1024");
+            ctx->opt_pack_threads = (int)value;
+            return ZG_OK;
+        case ZG_OPT_PACK_MIN_LOG_N:
+            if (value < 10 || value > 32) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_MIN_LOG_N: 10 .. 32");
+            ctx->opt_pack_min_log_n = (int)value;
+            return ZG_OK;
+        case ZG_OPT_PACK_PIN: ctx->opt_pack_pin = value != 0; return ZG_OK;
+        case ZG_OPT_PACK_BUDGET_PERMILLE:
+            if (value < 0 || value > 100000) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_BUDGET_PERMILLE: 0 .. 100000");
+            ctx->opt_pack_budget_permille = (int)value;
+            return ZG_OK;
+        case ZG_OPT_H_EVAL: ctx->opt_h_eval = value != 0; return ZG_OK;
+        case ZG_OPT_TABLES:
+            if (value < 0 || value > 31) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_TABLES: a mask over five queries");
+            ctx->opt_tables = (unsigned)value;
+            return ZG_OK;
+        case ZG_OPT_TABLES_MAX_MB:
+            if (value < 0) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_TABLES_MAX_MB is negative");
+            ctx->opt_tables_max_mb = (uint64_t)value;
+            return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -1504,8 +1615,8 @@ extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void*
 // Fixed-base window tables for this rank's part of each query, built once per key: every proof with the key
 // re-uses them.  The digit width is planned from the number of scalars that are neither 0 nor 1 in the witness the
 // tables are first built for (a circuit's share of bit signals is structural), and a table is only built where it
-// beats the per-window schedule.  Budget: ZA_AMD_FBW_MAX_GB (default: 60% of the free HBM) in the order b_g2, h, l,
-// a, b_g1; ZA_AMD_FBW=0 turns the tables off.
+// beats the per-window schedule.  Budget: ZG_OPT_TABLES_MAX_MB (default: 60% of the free HBM) in the order b_g2, h, l,
+// a, b_g1; ZG_OPT_TABLES = 0 turns the tables off.
 struct QueryUse {
     const void* bases;
     const uint32_t* scalars;
@@ -1514,11 +1625,8 @@ struct QueryUse {
     const uint8_t* cls = nullptr;   // class bytes addressed like `scalars` (MsmDesc::cls)
 };
 // The h query in evaluation form (heval.hip), built on first use: unsharded keys only (the group transform needs the
-// whole query); ZA_AMD_H_EVAL=0 keeps bellman's coefficient form (seven transforms per proof).
-static bool h_eval_allowed() {
-    const char* e = getenv("ZA_AMD_H_EVAL");   // read per key (tests switch it between key loads)
-    return !(e && atoi(e) == 0);
-}
+// whole query); ZG_OPT_H_EVAL = 0 keeps bellman's coefficient form (seven transforms per proof).
+static bool h_eval_allowed(const Ctx* ctx) { return ctx->opt_h_eval; }   // ZG_OPT_H_EVAL, read per key
 // A sharded key's slice: positions [rank * ceil(m / world), ...) of the m-point evaluation-form array.  The group
 // transform needs the whole query, so this runs where it is at hand: zg_params_load (every rank parses the whole key),
 // zg_params_shard (cut from a full resident key; d_h_eval_full = its transformed array if it has one).
@@ -1528,7 +1636,7 @@ int zg::params_h_eval_slice(Ctx* ctx, const zg_params* p, const G1Affine* d_h_fu
     p->h_eval_state = -1;
     uint32_t log_m = 0;
     while (((uint64_t)1 << log_m) < n_h + 1) log_m++;
-    if (!h_eval_allowed() || log_m == 0 || log_m >= 28 || ((uint64_t)1 << log_m) != n_h + 1) return ZG_OK;   // bellman: |h| = m - 1
+    if (!h_eval_allowed(ctx) || log_m == 0 || log_m >= 28 || ((uint64_t)1 << log_m) != n_h + 1) return ZG_OK;   // bellman: |h| = m - 1
     const uint64_t m = (uint64_t)1 << log_m, chunk = (m + p->world - 1) / p->world;
     const uint64_t lo = std::min<uint64_t>(m, (uint64_t)p->rank * chunk), hi = std::min<uint64_t>(m, lo + chunk);
     DevBuf full;
@@ -1562,7 +1670,7 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
     p->fbw_he.state = 0;
     p->h_eval_state = -1;
     const uint64_t m = (uint64_t)1 << log_m;
-    if (!h_eval_allowed() || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
+    if (!h_eval_allowed(ctx) || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
     if (p->h_eval.alloc(m * sizeof(G1Affine)) != hipSuccess) {
         (void)hipGetLastError();
         return ZG_OK;   // no room: the coefficient form is used
@@ -1588,8 +1696,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (ctx->one_shot) continue;   // no tables for a key that is used once (their state stays "not tried")
         t.buf.release();
         t.state = -1;
-        const char* off = getenv("ZA_AMD_FBW");   // "0" = no tables, otherwise a bit mask over (h, l, a, b_g1, b_g2)
-        if (off && !((unsigned)atoi(off) & (1u << k))) continue;
+        if (!(ctx->opt_tables & (1u << k))) continue;   // ZG_OPT_TABLES
         if (n < 64) continue;
         uint64_t n_real = n;
         if (k != 0) {   // h is dense by construction
@@ -1608,7 +1715,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         reserve += (size_t)use[0].n * 32 * 8;
         const size_t avail = free_b > reserve ? free_b - reserve : 0;
         size_t budget = (size_t)((double)avail * 0.6);
-        if (const char* cap = getenv("ZA_AMD_FBW_MAX_GB")) budget = std::min<size_t>(budget, (size_t)(atof(cap) * 1e9));
+        if (ctx->opt_tables_max_mb) budget = std::min<size_t>(budget, (size_t)ctx->opt_tables_max_mb * 1000000u);
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
         // latency bound (msm.hip small-job mode: always a window table): a dense query up to 2^16 points; a witness query up
         // to ~2^19 positions IF few of its scalars are "real" (a bit-heavy circuit: shard of a 2^22 proof, 3 % of 2^19) --
@@ -2007,14 +2114,14 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
 // everything else -- at memory speed, and 3 % of the bytes cross PCIe.  Returns false (nothing queued) when the witness
 // is not of that kind: then it is uploaded as it is.  ZA_AMD_PACK_THREADS sets the thread count (0 = never pack).
 // Host time at 2^22 with 8 threads: 0.73 ms scan + 0.07 ms to put the lists back to back + 0.03 ms of queueing.
-static int host_pack_threads() {
+static int host_pack_threads(const Ctx* ctx) {
+    if (ctx->opt_pack_threads > 0) return ctx->opt_pack_threads;   // ZG_OPT_PACK_THREADS
+    // Measured on the GPU box (256 hardware threads, shared with other jobs; 134 MB witness).  Alone, the pass takes
+    // 1.37 ms with 4 threads, 0.82 with 8, 0.73 with 16, 0.56 with 32, 1.0 with 64 (the plain upload: 2.34 ms).  Inside
+    // the benchmark loop on a loaded host the order flips -- every thread is one more chance of a late wake-up:
+    // 11.76 ms per proof with 8 threads, 11.81 / 12.06 with 16, 12.19 / 12.31 with 32 (and a 20 ms outlier).  So: 8,
+    // or half of a small host's threads; a host with fewer than 8 hardware threads uploads the array as it is.
     static const int n = [] {
-        if (const char* e = getenv("ZA_AMD_PACK_THREADS")) return std::max(0, atoi(e));
-        // Measured on the GPU box (256 hardware threads, shared with other jobs; 134 MB witness).  Alone, the pass takes
-        // 1.37 ms with 4 threads, 0.82 with 8, 0.73 with 16, 0.56 with 32, 1.0 with 64 (the plain upload: 2.34 ms).  Inside
-        // the benchmark loop on a loaded host the order flips -- every thread is one more chance of a late wake-up:
-        // 11.76 ms per proof with 8 threads, 11.81 / 12.06 with 16, 12.19 / 12.31 with 32 (and a 20 ms outlier).  So: 8,
-        // or half of a small host's threads; a host with fewer than 8 hardware threads uploads the array as it is.
         const unsigned hc = std::thread::hardware_concurrency();
         if (hc < 8) return 0;
         return (int)std::min<unsigned>(8, hc / 2);
@@ -2034,17 +2141,16 @@ extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int thre
 
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {
     *done = false;
-    const int nthreads = host_pack_threads();
-    // below ~2^20 values (32 MB, 0.6 ms of PCIe) waking the threads costs what the pass saves
-    // (ZA_AMD_PACK_MIN_LOG_N: the tests lower it)
-    int min_log = 20;
-    if (const char* e = getenv("ZA_AMD_PACK_MIN_LOG_N")) min_log = std::min(std::max(atoi(e), 10), 30);
-    if (nthreads <= 0 || nv < ((size_t)1 << min_log)) return ZG_OK;
-    {   // a cheap look first: 1024 evenly spread values; a witness of field elements is left alone
+    if (ctx->opt_pack == 0) return ZG_OK;   // ZG_OPT_PACK
+    const int nthreads = host_pack_threads(ctx);
+    // below ~2^20 values (32 MB, 0.6 ms of PCIe) waking the threads costs what the pass saves (ZG_OPT_PACK_MIN_LOG_N)
+    if (nthreads <= 0 || nv < ((size_t)1 << ctx->opt_pack_min_log_n)) return ZG_OK;
+    {   // a cheap look first: 1024 evenly spread values; a witness of field elements is left alone (8 %: below what makes
+        // the pass itself give up, so a borderline witness does not flip between the two forms)
         size_t others = 0;
         const size_t step = nv / 1024;
         for (size_t k = 0; k < 1024; k++) others += value_class(witness32 + 32 * (k * step)) == 2u;
-        if (others > 128) return ZG_OK;
+        if (others > 82) return ZG_OK;
     }
     static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
     const double t_begin = trace ? now_ms() : 0;
@@ -2052,7 +2158,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         if (trace) fprintf(stderr, "[za_amd trace] pack %-14s +%.3f ms\n", what, now_ms() - t_begin);
     };
     ProveWs& ws = prove_ws(ctx);
-    if (ws.pack_skip > 0) {   // see below: the host is too busy for the pass to pay
+    if (ws.pack_skip > 0) {   // see below
         ws.pack_skip--;
         return ZG_OK;
     }
@@ -2060,31 +2166,44 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     const size_t max_others = nv / 8;
     const size_t cls_bytes = (nv + 3) / 4;
     const size_t need = ((cls_bytes + 63) & ~(size_t)63) + max_others * 36 + 64;
+    const int sk = ws.stage_next;
     // a pass that first allocates (worker threads, per-slice lists, the pinned stage) says nothing about the host's load
-    const bool cold = !ws.packer || ws.stage_bytes < need;
+    const bool cold = !ws.packer || ws.stage_bytes[sk] < need;
     if (!ws.packer) ws.packer.reset(new HostPacker());
-    if (ws.stage_bytes < need) {
-        if (ws.stage) (void)hipHostFree(ws.stage);
-        ws.stage = nullptr;
-        ws.stage_bytes = 0;
-        ZG_HIP(ctx, hipHostMalloc((void**)&ws.stage, need, hipHostMallocDefault));
-        ws.stage_bytes = need;
+    if (!ws.stage_ev[sk]) ZG_HIP(ctx, hipEventCreateWithFlags(&ws.stage_ev[sk], hipEventDisableTiming));
+    else ZG_HIP(ctx, hipEventSynchronize(ws.stage_ev[sk]));   // the copies of the hand-over before last have left this stage
+    if (ws.stage_bytes[sk] < need) {
+        if (ws.stage[sk]) (void)hipHostFree(ws.stage[sk]);
+        ws.stage[sk] = nullptr;
+        ws.stage_bytes[sk] = 0;
+        ZG_HIP(ctx, hipHostMalloc((void**)&ws.stage[sk], need, hipHostMallocDefault));
+        ws.stage_bytes[sk] = need;
     }
-    uint8_t* classes = ws.stage;
-    uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage + ((cls_bytes + 63) & ~(size_t)63));
+    if (ctx->opt_pack_pin && !ws.pin_looked_up) {
+        ws.pin_cpus = gpu_node_cpus(ctx->device);
+        ws.pin_looked_up = true;
+    }
+    static const std::vector<int> nowhere;
+    uint8_t* classes = ws.stage[sk];
+    uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage[sk] + ((cls_bytes + 63) & ~(size_t)63));
     uint8_t* val_out = reinterpret_cast<uint8_t*>(idx_out + max_others);
     size_t n_others = SIZE_MAX;
-    ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp);
-    if (n_others == SIZE_MAX) return ZG_OK;
+    ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp, ctx->opt_pack_pin ? ws.pin_cpus : nowhere);
+    if (n_others == SIZE_MAX) {   // not the kind of witness that packs: no point in scanning the next ones either
+        ws.pack_skip = 32;
+        return ZG_OK;
+    }
     ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
+    ZG_HIP(ctx, hipEventRecord(ws.stage_ev[sk], ctx->stream));
+    ws.stage_next = sk ^ 1;
     stamp("queued");
-    {   // The pass competes with whatever else runs on the host (on a shared 256-thread host with a load average of 30 it
-        // has been seen to take 2.7 ms instead of 0.8): when its running average exceeds what the plain upload costs
-        // (32 B per value at ~55 GB/s), the next 32 proofs go over PCIe unpacked, then it is tried again.
-        // (ZA_AMD_PACK_BUDGET: the fraction of the plain upload's time the pass may take, default 0.9; the tests set 0 to
-        // walk through the fallback)
-        double budget = 0.9;
-        if (const char* e = getenv("ZA_AMD_PACK_BUDGET")) budget = atof(e);
+    if (ctx->opt_pack == 2) {
+        // ZG_OPT_PACK = 2: the pass competes with whatever else runs on the host (on a shared 256-thread host with a load
+        // average of 30 it has been seen to take 2.7 ms instead of 0.8): when its running average exceeds what the plain
+        // upload costs (32 B per value at ~55 GB/s), the next 32 proofs go over PCIe unpacked, then it is tried again.
+        // (ZG_OPT_PACK_BUDGET_PERMILLE: the share of the plain upload's time the pass may take, default 900; the tests
+        // set 0 to walk through the fallback.)  The default, ZG_OPT_PACK = 1, never looks at the clock.
+        const double budget = ctx->opt_pack_budget_permille / 1000.0;
         const double t = now_ms() - t_pack0, plain_ms = (double)nv * 32.0 / 55e6 * budget / 0.9;
         if (!cold && nv >= ((size_t)1 << 20)) {
             ws.pack_ema_ms = ws.pack_ema_ms > 0 ? 0.7 * ws.pack_ema_ms + 0.3 * t : t;
