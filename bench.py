@@ -187,9 +187,7 @@ def acc_roofline(prof, pmc=None):
 
 
 def host_pack_threads():
-    """zg_prove's host-side packing threads (csrc/prover.hip host_pack_threads)."""
-    if os.environ.get("ZA_AMD_PACK_THREADS"):
-        return max(0, int(os.environ["ZA_AMD_PACK_THREADS"]))
+    """zg_prove's host-side packing threads (csrc/prover.hip host_pack_threads: the default of ZG_OPT_PACK_THREADS)."""
     hc = os.cpu_count() or 1
     return 0 if hc < 8 else min(8, hc // 2)
 
@@ -212,11 +210,12 @@ def pmc_for(args):
     return None
 
 
-def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live):
+def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live, eval_form=True):
     """The H pipeline against the HBM roofline: algorithmic 64 B per element per transform."""
-    n_transforms = 6
+    n_transforms = 6 if eval_form else 7
     alg = n_transforms * 64 * m
-    out = {"bound": "hbm", "kernel": "k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form: %d transforms in %d launches)"
+    out = {"bound": "hbm", "kernel": ("k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form: %d transforms in %d launches)"
+                                      if eval_form else "k_ntt_pass (H in coefficient form, bellman's %d transforms, in %d launches)")
            % (n_transforms, passes), "algorithmic_bytes": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "h_pipeline_ms_in_proof": h_ms_live,
            "achieved_in_proof": alg / (h_ms_live * 1e-3) / 1e9 if h_ms_live else None,
@@ -409,9 +408,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_get()
-    phases = ctx.last_timings()
-    if world > 1:
-        phases = dict(phases, upload_bytes=float(upload_sent[0]))
+    phases = dict(ctx.last_timings())
+    upload_bytes = int(upload_sent[0]) if world > 1 else int(phases.get("upload_bytes", 0))
+    phases.pop("upload_bytes", None)   # (a byte count, reported under its own key)
+    # the form of H the timed proofs took: the key's (a sharded run: what the ranks agreed on)
+    h_eval_form = bool(getattr(engine, "h_eval", False)) if world > 1 else bool(P.h_eval_info()[0])
     h_ms_live = float(np.mean(h_ms_acc)) if h_ms_acc else None
     phase_ms = {k: v / max(args.steps, 1) for k, v in phase_acc.items()}
     elapsed = max_over_ranks(elapsed)
@@ -549,12 +550,34 @@ def main():
             ctx.prove_partials_dev(full_key, r1, d_w, d_h, h_mask)
             full_w.append((t2 - t1, time.perf_counter() - t2))
         full_w = np.array(full_w[1:]) * 1e3
-        shard_line = {"world": W, "h_form": "evaluation" if ev else "coefficient", "h_ntt_ms": float(ts[:, 0].mean()), "witness_msm_ms": float(ts[:, 1].mean()),
+        # The same phases as they run in the real flow (za_amd/dist.py): H queued, the witness multiexps beside it, the h
+        # multiexp once H is there.  What the multiexps add to the rank's critical path is that wall time minus H's own.
+        enq = ctx.prove_h_eval_enqueue_dev if ev else ctx.prove_h_enqueue_dev
+        flow = {}
+        for name, key in (("shard", Pk), ("unsharded", full_key)):
+            tt = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                enq(r1, d_w, d_h)
+                ctx.prove_partials_dev(key, r1, d_w, d_h, 0x1e)
+                ctx.prove_partials_dev(key, r1, d_w, d_h, h_mask)
+                tt.append(time.perf_counter() - t1)
+            flow[name] = 1e3 * float(np.mean(tt[1:]))
+        h_alone = float(ts[:, 0].mean())
+        shard_line = {"world": W, "h_form": "evaluation" if ev else "coefficient", "h_ntt_ms": h_alone, "witness_msm_ms": float(ts[:, 1].mean()),
                       "h_msm_ms": float(ts[:, 2].mean()), "msm_phase_ms": float(ts[:, 1:].sum(axis=1).mean()),
                       "unsharded_msm_phase_ms": float(full_w.sum(axis=1).mean()),
                       "msm_scaling_model": float(full_w.sum(axis=1).mean() / ts[:, 1:].sum(axis=1).mean()),
-                      "note": "one GPU, phases run one after the other (no overlap): rank 0's shard of a proof sharded %d ways "
-                              "vs the same phases unsharded; the scatter of (m*32 B)/%d per xGMI link is not included" % (W, W)}
+                      "flow_ms": flow["shard"], "unsharded_flow_ms": flow["unsharded"],
+                      "msm_critical_path_ms": max(flow["shard"] - h_alone, 0.0),
+                      "unsharded_msm_critical_path_ms": max(flow["unsharded"] - h_alone, 0.0),
+                      "msm_critical_path_scaling": (flow["unsharded"] - h_alone) / max(flow["shard"] - h_alone, 1e-9),
+                      "note": "one GPU.  msm_phase_ms / msm_scaling_model: the phases run one after the other (no overlap), rank "
+                              "0's shard of a proof sharded %d ways vs the same phases unsharded.  flow_ms: the phases as the "
+                              "sharded flow runs them on rank 0 (H queued, witness multiexps beside it, h multiexp behind it); "
+                              "msm_critical_path_ms = flow_ms - h_ntt_ms.  The scatter of (m*32 B)/%d per xGMI link is not "
+                              "included.  No multi-GPU hardware measurement exists: these are one-GPU models" % (W, W)}
         ctx.free(d_h)
         Pk.close()
 
@@ -673,7 +696,7 @@ def main():
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         roof = acc_roofline(prof, pmc=pmc_for(args))
         ntt_ms, ntt_n = prof_all["ntt_pass"][0] / n_break, prof_all["ntt_pass"][1] / n_break
-        roof_ntt = ntt_roofline(m, int(round(ntt_n)), ntt_ms, int(round(ntt_n)), h_ms_live) if world == 1 else None
+        roof_ntt = ntt_roofline(m, int(round(ntt_n)), ntt_ms, int(round(ntt_n)), h_ms_live, h_eval_form) if world == 1 else None
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -695,14 +718,16 @@ def main():
                                       "synthetic proving key with known discrete logs" if args.synthetic_key
                                       else "proving key from zg_setup (valid CRS, fixed toxic waste)"),
                        "step": "%s: witness (%d bytes, 32 B per value) in pinned host memory, handed over inside every step; "
-                               "R1CS and key resident.  %s; H in evaluation form (6 transforms; h bases transformed once per key)"
+                               "R1CS and key resident.  %s; %s"
                                % ("zg_prove" if world == 1 else "sharded proof (za_amd/dist.py), every rank takes the whole witness",
                                   witness_bytes,
                                   "packed by %d host threads before it crossed PCIe (%d bytes sent in the last step)"
-                                  % (host_pack_threads(), int(phases.get("upload_bytes", 0)))
-                                  if 0 < int(phases.get("upload_bytes", 0)) < witness_bytes else
+                                  % (host_pack_threads(), upload_bytes)
+                                  if 0 < upload_bytes < witness_bytes else
                                   "sent over PCIe as it is in the last step (packing applies from 2^20 values, to a mostly-0/1 "
-                                  "witness, on a host where the pass is faster than the plain copy)"),
+                                  "witness)",
+                                  "H in evaluation form (6 transforms; h bases transformed once per key)" if h_eval_form else
+                                  "H in coefficient form (bellman's 7 transforms: this key has no transformed h bases)"),
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
                        "parallelism": "msm-sharded x%d, ntt on rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
@@ -716,6 +741,7 @@ def main():
             "prove_dev_ms": prove_dev_ms,
             "prove_packed": packed_line,
             "phases_ms_last_step": phases,
+            "upload_bytes_last_step": upload_bytes,
             "kernel_ms_per_step": {k: v[0] / n_break for k, v in prof_all.items()},
             "setup_s": t_setup,
             "key_tables": {name: {"kind": ("none", "window", "subset-sum")[P.table_info(k)[0]],

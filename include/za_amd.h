@@ -120,7 +120,8 @@ int zg_msm_g2_dev(zg_ctx* ctx, const void* d_bases, const void* d_scalars,
 
 /* Resident bases: bellman's multiexp takes its bases as a shared `Arc<Vec<G::Affine>>` that outlives the call
  * (SourceBuilder); the analogue here is a handle that keeps n affine bases in HBM (converted to the device form once)
- * and, if table_budget_gb > 0 and it pays, a fixed-base window table 2^(c w) P_i over them (see zg_params_prepare).
+ * and, if table_budget_gb > 0 and it pays, a fixed-base window table 2^(c w) P_i over them (see zg_params_prepare);
+ * table_budget_gb < 0: a table within |table_budget_gb| is built whenever one fits (the cost model is not asked).
  * zg_msm_resident takes host scalars (n <= the handle's n, canonical LE; pinned memory from zg_host_alloc gives PCIe
  * speed) and overlaps their chunked upload with the multiexp, which is BASELINE.json's "G1 MSM points/s" measurement:
  * bases resident, scalars uploaded.  zg_msm_resident_dev takes scalars already in HBM.  dense_hint != 0 promises that

@@ -143,6 +143,76 @@ def test_g1_msm_2p26_points_discrete_log_identity(ctx):
     ctx.free(d_b); ctx.free(d_s)
 
 
+def test_largest_legal_domain_2p27_multiexp_and_transform(ctx):
+    """bellman's limit: Fr has 2-adicity 28 and create_proof refuses a domain of 2^28
+    (prover/src/groth16/prover.rs:173 -> PolynomialDegreeTooLarge), so 2^27 is the largest size the path can meet --
+    "2^26 constraints" read literally.  Here the data reaches the guards that inspection had to vouch for: a 2^27-point G1
+    multiexp through its window table (12 rows x 2^27 entries: table indices up to 1.6e9 of the 2^31 the sort's value word
+    holds; four parts of 4.0e8 (point, digit) entries each) against the discrete-log expectation, and the Fr transform at
+    2^27 (4 GiB per vector, 3.2 GiB per twiddle table: byte offsets beyond 32 bits) against the definition at sampled
+    positions and as a round trip."""
+    from za_amd import synth
+    lg = 27
+    n = 1 << lg
+    seed_b, seed_s = 2727, 127
+    d_b = synth.synth_bases_g1(ctx, n, seed_b)
+    d_s = synth.synth_scalars(ctx, n, seed_s)
+    sc = ctx.d2h(d_s, 32 * n)
+    e = co.dot_u64(sc, synth.splitmix64_array(seed_b, n)) % bn.R
+    want = co.g1_mul(bn.g1_to_mont_bytes(bn.G1_GEN), e)
+    # (i) the schedule the library picks by itself: at this size the per-window plan (c = 22, twelve windows of 2^21
+    # buckets, 4.0e8 entries per part) is within 8 % of the table's cost, so no table is built
+    H = ctx.msm_bases_g1_dev(d_b, n, table_budget_gb=150.0)
+    assert ctx.msm_bases_info(H)["n"] == n
+    got = ctx.msm_resident_dev(H, d_s, n, dense_hint=True)
+    assert got[:64] == want and got[64:] == bn.le32(bn.mont(1, bn.Q))
+    ctx.msm_bases_free(H)
+    # (ii) the window table built regardless (negative budget): 12 rows x 2^27 entries = 103 GB, table indices to 1.6e9
+    H = ctx.msm_bases_g1_dev(d_b, n, table_budget_gb=-150.0)
+    ctx.free(d_b)
+    info = ctx.msm_bases_info(H)
+    assert info["n"] == n and info["table_bytes"] >= 10 * 64 * n, info
+    assert ctx.msm_resident_dev(H, d_s, n, dense_hint=True)[:64] == want
+    ctx.msm_bases_free(H)
+    # ---- the transform: x = the uploaded scalars read as Montgomery residues (all below 2^253 < r)
+    sample = [0, 1, 2, n // 2 - 1, n // 2, n - 1, 0x5a5a5a5 % n]
+    # (i) forward then inverse is the identity, for the plain and the coset pair
+    ctx.ntt_dev(d_s, lg, False, False)
+    fwd = {k: bn.unmont(bn.from_le32(bytes(ctx.d2h(d_s + 32 * k, 32))), bn.R) for k in sample}
+    ctx.ntt_dev(d_s, lg, True, False)
+    ctx.ntt_dev(d_s, lg, False, True)
+    ctx.ntt_dev(d_s, lg, True, True)
+    assert bytes(ctx.d2h(d_s, 32 * n)) == bytes(sc)
+    # (ii) sum_k X[k] = m x[0], and X[0] = sum_i x[i], X[m/2] = sum_i (-1)^i x[i] (omega^(m/2) = -1): the definition, exactly
+    xs = np.frombuffer(sc, dtype="<u8").reshape(n, 4)
+    def total(rows):   # sum of 256-bit little-endian integers, limb by limb in Python integers
+        t = 0
+        for limb in range(4):
+            lo = rows[:, limb] & np.uint64(0xFFFFFFFF)
+            hi = rows[:, limb] >> np.uint64(32)
+            t += (int(lo.sum(dtype=np.uint64)) + (int(hi.sum(dtype=np.uint64)) << 32)) << (64 * limb)
+        return t
+    rinv = bn.inv(bn.MONT_R, bn.R)
+    s_all, s_even = total(xs), total(xs[0::2])
+    assert fwd[0] == s_all * rinv % bn.R
+    assert fwd[n // 2] == (2 * s_even - s_all) * rinv % bn.R
+    # (iii) a sparse vector: X[k] = x_a omega^(a k) + x_b omega^(b k) at the sampled k
+    ctx.free(d_s)
+    omega = pow(bn.FR_ROOT_OF_UNITY, 1 << (bn.FR_S - lg), bn.R)
+    pa, pb, va, vb = 3, n - 5, 0x1234567, 0x7654321
+    d = ctx.alloc(32 * n)
+    z = np.zeros(1 << 26, dtype=np.uint8)
+    for off in range(0, 32 * n, z.size):
+        ctx.h2d(d + off, z)
+    ctx.h2d(d + 32 * pa, np.frombuffer(bn.le32(bn.mont(va, bn.R)), dtype=np.uint8))
+    ctx.h2d(d + 32 * pb, np.frombuffer(bn.le32(bn.mont(vb, bn.R)), dtype=np.uint8))
+    ctx.ntt_dev(d, lg, False, False)
+    for k in sample:
+        got_k = bn.unmont(bn.from_le32(bytes(ctx.d2h(d + 32 * k, 32))), bn.R)
+        assert got_k == (va * pow(omega, pa * k, bn.R) + vb * pow(omega, pb * k, bn.R)) % bn.R, k
+    ctx.free(d)
+
+
 def test_config4_on_its_own_circuit_sha256_merkle_depth_32(ctx):
     """BASELINE config 4 as named: a depth-32 SHA-256 Merkle inclusion proof on the bit-level circuit of
     za_amd/workloads.py (1.48 M constraints, 2^21 domain; root and witness asserted against hashlib by the generator).

@@ -204,6 +204,28 @@ def test_za2c_symbols_from_c(lib_built, tmp_path):
     assert "za2c ok" in r.stdout
 
 
+def test_za2c_prove_reads_its_witness_path_like_serde_json(lib_built, tmp_path):
+    """The inputs argument of za2c's prove names the witness dump as a JSON string; escapes follow serde_json: a
+    surrogate PAIR is one code point (4 bytes of UTF-8), a lone surrogate and \\u0000 are Json errors.  CPU only: a path
+    that parses reaches the file system (Io(..)), one that does not never gets that far."""
+    from za_amd import build as zb
+    lib = C.CDLL(zb.LIB_ZA2C)
+
+    def prove(inputs):
+        out, err = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        rc = lib.prove(str(tmp_path / "missing.key").encode(), inputs.encode(), out, C.c_size_t(4096), err, C.c_size_t(4096))
+        return rc, err.value.decode()
+
+    rc, err = prove('{"@binwitness": "w\\ud83d\\ude00.bin"}')
+    assert rc == 100 and err.startswith("Io("), err            # parsed: the missing key file is what fails
+    (tmp_path / "missing.key").write_bytes(b"x")
+    rc, err = prove('{"@binwitness": "%s/w\\ud83d\\ude00.bin"}' % tmp_path)
+    assert rc == 100 and "w\U0001F600.bin" in err, err           # ... and the path is the 4-byte UTF-8 form
+    for bad in ('"\\ud83d"', '"\\ud83dx"', '"\\ude00"', '"a\\u0000b"', '"\\ud83d\\u0041"'):
+        rc, err = prove('{"@binwitness": %s}' % bad)
+        assert rc == 100 and err.startswith("Json("), (bad, err)
+
+
 def test_za_gpu_driver_verify_arm(lib_built, tmp_path):
     from za_amd import build as zb
     pf = golden("proof_chain7.json")

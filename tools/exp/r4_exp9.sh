@@ -1,0 +1,10 @@
+# round 4, experiment 9: fewer launches in the staged chain; 2^27
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r4
+ZA_AMD_SORT_STAGED=3 timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_golden_1k.py tests/test_gpu_prove.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r4/exp9_tests_forced.txt
+ZA_AMD_SORT_STAGED=2 timeout 600 python tools/fuzz_prove.py 60 2>&1 | tail -3 > gpurun_out/r4/exp9_fuzz.txt
+timeout 600 python tools/ab_env.py ZA_AMD_SORT_STAGED 0,1 22 8 6 > gpurun_out/r4/exp9_ab22.txt 2>&1
+timeout 600 python tools/ab_env.py ZA_AMD_SORT_STAGED 0,1 22 3 4 0.0 > gpurun_out/r4/exp9_ab22_dense.txt 2>&1
+timeout 600 python tools/msm_trace_run.py 26 > gpurun_out/r4/exp9_msm26.txt 2>&1
+timeout 1500 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "2p27" 2>&1 | tail -15 > gpurun_out/r4/exp9_2p27.txt

@@ -105,6 +105,11 @@ def density_bitmap(flags):
     return np.packbits(f, bitorder="little").view("<u8").copy()
 
 
+# zg_set_option (include/za_amd.h)
+OPT_ONE_SHOT, OPT_PACK, OPT_PACK_THREADS, OPT_PACK_MIN_LOG_N, OPT_PACK_PIN, OPT_H_EVAL, OPT_TABLES, OPT_TABLES_MAX_MB, \
+    OPT_PACK_BUDGET_PERMILLE = 1, 2, 3, 4, 5, 6, 7, 8, 9
+
+
 class Context:
     """One per process and GPU (zg_ctx)."""
 
@@ -140,6 +145,10 @@ class Context:
     def set_one_shot(self, on=True):
         """ZG_OPT_ONE_SHOT: no per-key precomputation (a key used for one proof)."""
         self._check(self.lib.zg_set_option(self.h, C.c_int(1), C.c_int64(1 if on else 0)))
+
+    def set_option(self, option, value):
+        """zg_set_option: `option` one of the OPT_* numbers below (include/za_amd.h ZG_OPT_*)."""
+        self._check(self.lib.zg_set_option(self.h, C.c_int(option), C.c_int64(int(value))))
 
     def sync(self):
         self._check(self.lib.zg_sync(self.h))

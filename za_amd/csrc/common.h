@@ -172,7 +172,8 @@ struct MsmDesc {
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);
 size_t msm_quad_entries(size_t n);
-bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force = false);
+bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force = false,
+                  bool always = false);
 size_t msm_small_n();           // dense jobs up to this size are latency bound (planned for depth, always with a window table)
 size_t msm_small_witness_n();   // witness (non-dense) jobs: queued whole, always with a window table
 int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table);

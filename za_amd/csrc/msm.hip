@@ -131,7 +131,10 @@ static MsmPlan plan_fbw_for(int c, int nwin, size_t n) {
 // it would not beat the plain per-window plan by at least 8%.
 // force: take the best table plan even if it does not beat the per-window plan by 8 % (small jobs: what a table buys them
 // is one bucket set and a host pass of c - 1 doublings instead of 254)
-bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force) {
+// always: take the best table plan that fits even when the per-window plan is within 8 % of it (at 2^27 points c = 22 is
+// within reach of both: the table then saves one bucket reduction out of twelve, not digits)
+bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force,
+                  bool always) {
     if (force) {
         // A small job is bound by the DEPTH of its chain of dependent additions (6 us each in G1, 19 us in G2), not by
         // their number: about T + 1.25 mean / T in the accumulation and its bucket sums (T ~ sqrt(2 mean), see
@@ -177,7 +180,7 @@ bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_b
     const MsmPlan plain = plan_msm(n_real, 0);
     const double plain_cost = (double)n_real * plain.nwin + 4.8 * plain.nwin * (double)plain.B +
                               3000.0 * ((plain.c - 1 + TREE_LAMBDA - 1) / TREE_LAMBDA);
-    if (best_cost > 0.92 * plain_cost) return false;
+    if (best_cost > 0.92 * plain_cost && !always) return false;
     *c_out = bc;
     *nwin_out = bw;
     return true;
@@ -365,8 +368,33 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
 //            LDS-staged scatter.  Skipped when the key space is small enough for two levels;
 //   level 3  k_part_local as before: one workgroup per (level-1 bin, level-2 sub-bin) segment, at most 2^7 buckets.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total);   // (with the scans below)
+__device__ __forceinline__ void p2_plan(const uint32_t* __restrict__ tile_tab, uint32_t ntiles, uint32_t nb1,
+                                        uint32_t* __restrict__ p2m, uint32_t* lds);
 static constexpr uint32_t PS_CAP = 4096;      // staged entries per round (8 bytes of LDS each)
 static constexpr uint32_t P2_CHUNK = 4096;    // entries per level-2 chunk (16 per thread)
+
+// Signed digit w of the scalar at `sw` (8 words) on its own: the same value next_digit() reaches after w steps.  The
+// carry into window w is 1 iff the raw digit below exceeds 2^(c-1), or equals it and has a carry itself (then the walk
+// goes one window further down: probability 2^-c per step).
+__device__ __forceinline__ uint32_t raw_digit(const uint32_t* sw, int w, int c) {
+    const int o = w * c, wi = o >> 5, sh = o & 31;   // o < 256: w < nwin = ceil(255 / c)
+    const uint64_t lo = sw[wi], hi = wi + 1 < 8 ? sw[wi + 1] : 0u;
+    return (uint32_t)(((hi << 32) | lo) >> sh) & ((1u << c) - 1u);
+}
+__device__ __forceinline__ int32_t digit_lds(const uint32_t* sw, int w, int c) {
+    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int k = w - 1; k >= 0; k--) {
+        const uint32_t r = raw_digit(sw, k, c);
+        if (r != half) {
+            carry = r > half ? 1u : 0u;
+            break;
+        }
+        if (k == 0) carry = 0;   // r == half all the way down: v = half is not above half
+    }
+    const uint32_t v = raw_digit(sw, w, c) + carry;
+    return v > half ? (int32_t)v - (int32_t)(1u << c) : (int32_t)v;
+}
 
 // (key, value) of every entry of point i -- the one place the digit walk of k_part lives for the staged kernel
 template <class Emit>
@@ -386,7 +414,7 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
                                                      size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
                                                      int lb, uint32_t ntiles, uint32_t tp, const uint32_t* __restrict__ tile_tab,
                                                      uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
-                                                     const uint8_t* __restrict__ wcls) {
+                                                     const uint8_t* __restrict__ wcls, uint32_t* __restrict__ p2m) {
     extern __shared__ uint32_t lds_s[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;   // last bin: scalars == 1 (final order, goes to `sorted`)
     uint32_t* hist = lds_s;                  // [nbins] the round's counts
@@ -402,6 +430,10 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
     const uint32_t tile = blockIdx.x;
     const size_t base = (size_t)tile * tp;
     const uint32_t lomask = (1u << lb) - 1u;
+    if (p2m && blockIdx.x == 0) {   // the level-2 plan (for the kernels after this one)
+        p2_plan(tile_tab, ntiles, nbins - 1u, p2m, scratch);
+        __syncthreads();
+    }
     for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) gbase[b] = tile_tab[(size_t)b * ntiles + tile];
     // ---- entry bound of every point (0, 1 or nwin) and its class, prefix-summed over the tile
     {
@@ -461,6 +493,97 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
         }
         walk_digits(s, (uint32_t)i, c, nwin, wsel, vstride, hb, lb, lomask, emit);
     };
+    // ---- a tile in which every point may contribute all of its nwin digits (the h job, a uniform witness).  A round is
+    // PS_CAP / nwin whole points: their scalars come in by coalesced 16-byte loads (issued a round ahead, parked in
+    // registers) and sit in LDS -- aliased with the stage, which is only written once the digits are out -- and the round's
+    // entries are (point, window) pairs dealt out sixteen per thread: every lane busy whatever nwin is, each digit cut
+    // straight out of the scalar's words with its carry from the window below (digit_lds), ranked by ONE returning LDS
+    // atomic and kept in registers across the scan.  One global-memory latency per round, hidden behind the round before;
+    // the general rounds below make two passes over the scalars with a thread walking its points' digits one by one.
+    {
+        const uint32_t live = base >= n ? 0u : (uint32_t)std::min<size_t>(tp, n - base);
+        const bool full = (pfx[tp] & 0x3FFFFFFFu) == live * (uint32_t)nwin && (wcls || !use_ones_bin) && !quad_n && nwin >= 8;
+        if (full) {
+            constexpr uint32_t PER = PS_CAP / 256, PRE = 4;   // nwin >= 8: at most 512 points = 1024 16-byte units per round
+            const uint32_t ppr = PS_CAP / (uint32_t)nwin;
+            const uint32_t magic = 0xFFFFFFFFu / (uint32_t)nwin + 1u;   // s / nwin = umulhi(s, magic) for s < 2^16
+            uint32_t* sc_lds = st_v;   // [ppr * 8] words, aliased with the stage
+            uint4 pre[PRE];
+            auto fetch = [&](uint32_t p0) {   // the scalars of points [p0, p0 + ppr) of the tile, two 16-byte halves each
+                const uint32_t npts = p0 >= live ? 0u : std::min(ppr, live - p0);
+#pragma unroll
+                for (uint32_t q = 0; q < PRE; q++) {
+                    const uint32_t u = q * 256 + threadIdx.x;
+                    if (u < 2 * npts) {
+                        const size_t i = base + p0 + (u >> 1);
+                        pre[q] = reinterpret_cast<const uint4*>(scalars + (index ? (size_t)index[i] : i) * 8)[u & 1u];
+                    }
+                }
+            };
+            fetch(0);
+            for (uint32_t p0 = 0; p0 < live; p0 += ppr) {
+                const uint32_t npts = std::min(ppr, live - p0), nslots = npts * (uint32_t)nwin;
+#pragma unroll
+                for (uint32_t q = 0; q < PRE; q++) {
+                    const uint32_t u = q * 256 + threadIdx.x;
+                    if (u < 2 * npts) reinterpret_cast<uint4*>(sc_lds)[u] = pre[q];
+                }
+                for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) hist[b] = 0;
+                __syncthreads();
+                fetch(p0 + ppr);   // in flight while this round runs
+                uint32_t ev[PER], el[PER], er[PER];   // value | low key and bin | rank in the bin
+#pragma unroll
+                for (uint32_t e = 0; e < PER; e++) {
+                    const uint32_t sl = e * 256 + threadIdx.x;
+                    el[e] = 0xffffffffu;
+                    if (sl < nslots) {
+                        const uint32_t kl = __umulhi(sl, magic), w = sl - kl * (uint32_t)nwin;
+                        const int32_t d = digit_lds(sc_lds + 8 * kl, (int)w, c);
+                        if (d != 0) {
+                            const uint32_t i = (uint32_t)base + p0 + kl;
+                            const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1u;
+                            const uint32_t bin = ((w & wsel) << hb) | (mag >> lb);
+                            ev[e] = (i + w * vstride) | (d < 0 ? 0x80000000u : 0u);
+                            el[e] = (mag & lomask) | (bin << 16);
+                            er[e] = atomicAdd(&hist[bin], 1u);
+                        }
+                    }
+                }
+                __syncthreads();   // (every digit is out of sc_lds: the stage may be written)
+                uint32_t n_round;
+                {
+                    const uint32_t per = (nbins + blockDim.x - 1) / blockDim.x, b0 = threadIdx.x * per;
+                    uint32_t sum = 0;
+                    for (uint32_t q = 0; q < per; q++) sum += b0 + q < nbins ? hist[b0 + q] : 0u;
+                    uint32_t ex = block_excl_scan(sum, scratch, n_round);
+                    for (uint32_t q = 0; q < per; q++) {
+                        if (b0 + q < nbins) {
+                            lscan[b0 + q] = ex;
+                            ex += hist[b0 + q];
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t e = 0; e < PER; e++) {
+                    if (el[e] != 0xffffffffu) {
+                        const uint32_t bin = el[e] >> 16, pos = lscan[bin] + er[e];
+                        st_v[pos] = ev[e];
+                        st_l[pos] = (uint16_t)el[e];
+                        st_b[pos] = (uint16_t)bin;
+                    }
+                }
+                __syncthreads();
+                for (uint32_t pos = threadIdx.x; pos < n_round; pos += blockDim.x) {
+                    const uint32_t b = st_b[pos];
+                    A[gbase[b] + (pos - lscan[b])] = make_uint2(st_v[pos], st_l[pos]);   // (no ones bin on this path)
+                }
+                __syncthreads();
+                for (uint32_t b = threadIdx.x; b < nbins; b += blockDim.x) gbase[b] += hist[b];
+            }
+            return;
+        }
+    }
     // ---- rounds: points [k_lo, k_hi), both multiples of four (a subset-sum group never straddles a round), whose
     // entry bounds sum to at most PS_CAP
     for (uint32_t k_lo = 0; k_lo < tp;) {
@@ -521,11 +644,10 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
     }
 }
 
-// level-2 plan (one workgroup): p2m = [nb1 + 2] segment starts (regular bins, the ones bin, the total) | [nb1 + 1]
-// exclusive prefix of the segments' chunk counts
-__global__ void __launch_bounds__(256) k_p2_plan(const uint32_t* __restrict__ tile_tab, uint32_t ntiles, uint32_t nb1,
-                                                 uint32_t* __restrict__ p2m) {
-    __shared__ uint32_t lds[16];
+// level-2 plan (one workgroup -- the first of k_part_staged: the scanned level-1 table is all it needs):
+// p2m = [nb1 + 2] segment starts (regular bins, the ones bin, the total) | [nb1 + 1] exclusive prefix of the segments' chunk counts
+__device__ __forceinline__ void p2_plan(const uint32_t* __restrict__ tile_tab, uint32_t ntiles, uint32_t nb1,
+                                        uint32_t* __restrict__ p2m, uint32_t* lds /*[16]*/) {
     uint32_t* seg_off = p2m;
     uint32_t* cb = p2m + nb1 + 2;
     for (uint32_t s = threadIdx.x; s < nb1 + 2; s += blockDim.x) seg_off[s] = tile_tab[(size_t)s * ntiles];
@@ -572,8 +694,13 @@ __global__ void __launch_bounds__(256) k_p2(const uint2* __restrict__ in, const 
     __shared__ uint16_t st_l[MODE ? P2_CHUNK : 1];
     __shared__ uint8_t st_b[MODE ? P2_CHUNK : 1];
     uint32_t sg, chunk, nch, start, end, cbase;
-    if (!p2_locate(p2m, nb1, &sg, &chunk, &nch, &start, &end, &cbase)) return;
     const uint32_t nsub = 1u << b2, submask = nsub - 1u, lowmask = (1u << b3) - 1u;
+    if (!p2_locate(p2m, nb1, &sg, &chunk, &nch, &start, &end, &cbase)) {
+        // the grid is sized from a bound on the entries; the table entries of the chunks that do not exist -- a dense tail
+        // after the nsub * chunks used ones -- must read zero for the scan (no memset launch)
+        if (MODE == 0 && threadIdx.x < nsub) tab2[(size_t)blockIdx.x * nsub + threadIdx.x] = 0;
+        return;
+    }
     const size_t idx0 = (size_t)nsub * cbase + chunk;
     constexpr uint32_t PER = P2_CHUNK / 256;
     uint2 e[PER];
@@ -857,7 +984,7 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
                                                     uint32_t ntiles, uint32_t nbins, int lb, uint32_t stage_min,
                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ p2m, const uint32_t* __restrict__ tab2,
-                                                    uint32_t nb1, int b2) {
+                                                    uint32_t nb1, int b2, uint32_t single_max) {
     extern __shared__ uint32_t lds_l[];   // [2^lb] histogram / cursors, 16 words of scan scratch; staged: see below
     const uint32_t bin = blockIdx.x;
     const int bits = bin + 1 == nbins ? 0 : lb;   // the ones bin is a single bucket
@@ -872,6 +999,41 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
     }
     for (uint32_t b = threadIdx.x; b < nl; b += blockDim.x) lds_l[b] = 0;
     __syncthreads();
+    if (single_max && end - start <= single_max && nl <= blockDim.x) {
+        // A segment that fits the stage goes through in ONE pass: its entries are read once (eight per thread, in
+        // registers), ranked by one returning LDS atomic, placed in LDS by bucket and written out as consecutive words --
+        // where the general path below reads the segment twice and writes sorted[cursor++] entry by entry.
+        // [2^lb] histogram | 16 scratch | [2^lb] bucket starts | [single_max] values
+        constexpr uint32_t PER1 = PART_STAGE_TILE / 1024;
+        uint32_t* bstart = scratch + 16;
+        uint32_t* stv = bstart + (1u << lb);
+        const uint32_t len = end - start;
+        uint2 e1[PER1];
+        uint32_t r1[PER1];
+#pragma unroll
+        for (uint32_t k = 0; k < PER1; k++) {
+            const uint32_t i = k * 1024 + threadIdx.x;
+            if (i < len) {
+                e1[k] = A[start + i];
+                r1[k] = atomicAdd(&lds_l[e1[k].y], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t tot1;
+        const uint32_t cnt1 = threadIdx.x < nl ? lds_l[threadIdx.x] : 0u;
+        const uint32_t ex1 = block_excl_scan(cnt1, scratch, tot1);
+        if (threadIdx.x < nl) {
+            bstart[threadIdx.x] = ex1;
+            counts[(bin << lb) + threadIdx.x] = cnt1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER1; k++)
+            if (k * 1024 + threadIdx.x < len) stv[bstart[e1[k].y] + r1[k]] = e1[k].x;
+        __syncthreads();
+        for (uint32_t pos = threadIdx.x; pos < len; pos += 1024) sorted[start + pos] = stv[pos];
+        return;
+    }
     {   // (eight loads in flight per thread: a long segment is otherwise a chain of 96 load -> atomic round trips)
         constexpr uint32_t U = 8;
         uint32_t i = start + threadIdx.x;
@@ -1019,22 +1181,30 @@ __global__ void __launch_bounds__(256) k_item_hist(const uint32_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
         if (h[i]) atomicAdd(&hist[i], h[i]);
 }
-// cursor[s] = number of items longer than s (longest first)
-__global__ void __launch_bounds__(64) k_item_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor) {
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int sz = (int)ITEM_CLASSES - 1; sz >= 0; sz--) {
-            cursor[sz] = run;
-            run += hist[sz];
-        }
-    }
-}
+// `hist` is complete (k_item_hist); `taken` (zeroed, ITEM_CLASSES words) counts what the workgroups have claimed per size.
+// Every workgroup derives the classes' starts itself -- first[s] = number of items longer than s (longest first): a
+// 513-word suffix sum -- instead of a single-thread kernel between the two (one launch less in every job's chain).
 __global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict__ item_key, const uint32_t* __restrict__ item_off,
                                                       const uint32_t* __restrict__ offsets, uint32_t nkeys, uint32_t T,
-                                                      uint32_t ones_key, uint32_t* __restrict__ cursor,
-                                                      uint32_t* __restrict__ perm) {
-    __shared__ uint32_t h[ITEM_CLASSES], base[ITEM_CLASSES];
+                                                      uint32_t ones_key, const uint32_t* __restrict__ hist,
+                                                      uint32_t* __restrict__ taken, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t h[ITEM_CLASSES], base[ITEM_CLASSES], first[ITEM_CLASSES + 3], sc[8];
     const uint32_t total = item_off[nkeys];
+    {   // suffix sums of hist: thread t owns sizes 3t, 3t + 1, 3t + 2 (ITEM_CLASSES = 513 <= 3 * 256), taken from the top
+        const int hi = (int)ITEM_CLASSES - 1 - 3 * (int)threadIdx.x;   // this thread's largest size
+        uint32_t v[3], sum = 0;
+        for (int q = 0; q < 3; q++) {
+            v[q] = hi - q >= 0 ? hist[hi - q] : 0u;
+            sum += v[q];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, sc, tot);   // items of sizes above this thread's
+        for (int q = 0; q < 3; q++) {
+            if (hi - q >= 0) first[hi - q] = ex;
+            ex += v[q];
+        }
+        __syncthreads();
+    }
     // grid-stride in whole-block chunks so that every thread of a block sees the same number of rounds
     for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < total; t0 += gridDim.x * blockDim.x) {
         for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x) h[i] = 0;
@@ -1047,7 +1217,7 @@ __global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
-            if (h[i]) base[i] = atomicAdd(&cursor[i], h[i]);
+            if (h[i]) base[i] = first[i] + atomicAdd(&taken[i], h[i]);
         __syncthreads();
         if (t < total) perm[base[sz] + rank] = t;
         __syncthreads();
@@ -1422,7 +1592,9 @@ struct MsmJob : MsmJobBase {
         const int bbits = P.c - 1;
         const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
         const bool small_job = eager_small || n <= msm_small_n();
-        bool staged = !small_job && max_entries >= ((size_t)1 << 20) && bbits >= 7;
+        // (for jobs in which most points carry their nwin digits: a bit-heavy witness query -- 3 % field elements among
+        // zeros and ones -- leaves the staged kernel's tiles nearly empty and is better off with the plain scatter)
+        bool staged = !small_job && max_entries >= ((size_t)1 << 20) && bbits >= 7 && max_entries >= n * (size_t)P.nwin / 2;
         if (const char* e = getenv("ZA_AMD_SORT_STAGED")) {   // 0 = the two-level scatter (A/B); 2 / 3 = staged for every large /
             const int v = atoi(e);                             // every job with at least 2^7 buckets (tests)
             staged = v == 0 ? false : v == 2 ? (!small_job && bbits >= 7) : v == 3 ? bbits >= 7 : staged;
@@ -1454,7 +1626,13 @@ struct MsmJob : MsmJobBase {
             lb = bbits - hb;
         }
         const uint32_t nbins = ((uint32_t)P.kw << hb) + 1u;   // level-1 bins (+ the ones bin)
-        const uint32_t tp = staged ? (n >= ((size_t)1 << 23) ? 4096u : 2048u) : n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
+        // (staged tiles: as many points as fill ONE round of the stage -- every workgroup then runs a single straight-line
+        // round, thousands of them in flight, instead of a loop of dependent rounds)
+        // (... up to 16 K tiles: beyond that the [bin][tile] table costs more than the rounds' latencies, which the many
+        // workgroups in flight hide anyway)
+        const uint32_t tp = staged ? std::max(std::max(256u, (PS_CAP / (uint32_t)P.nwin) & ~255u),
+                                              (uint32_t)(((n >> 14) + 255) & ~(size_t)255))
+                                   : n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
         const uint32_t ntiles = (uint32_t)((n + tp - 1) / tp);
         const size_t tab_n = (size_t)nbins * ntiles;
         // last level: lb3 low bits per segment, nbins3 segments (+ the ones bin)
@@ -1501,18 +1679,23 @@ struct MsmJob : MsmJobBase {
         if (const char* e = getenv("ZA_AMD_PART_STAGE_MIN")) stage_min = (uint32_t)atol(e);
         const bool may_stage = max_entries / nbins3 * 2 >= stage_min && lb3 <= 10;   // mean segment within 2x of the threshold
         if (!may_stage) stage_min = 0xffffffffu;
-        const size_t lds2 = ((size_t)4 << lb3) + 64 + (may_stage ? ((size_t)8 << lb3) + PART_STAGE_TILE * 6 : 0);
+        // (segments of up to PART_STAGE_TILE entries go through in one pass, see k_part_local; ZA_AMD_PART_SINGLE=0: A/B switch)
+        uint32_t single_max = lb3 <= 10 ? PART_STAGE_TILE : 0u;
+        if (const char* e = getenv("ZA_AMD_PART_SINGLE")) single_max = atoi(e) ? single_max : 0u;
+        const size_t lds2 = ((size_t)4 << lb3) + 64 +
+                            std::max<size_t>(may_stage ? ((size_t)8 << lb3) + PART_STAGE_TILE * 6 : 0,
+                                             single_max ? ((size_t)4 << lb3) + (size_t)single_max * 4 : 0);
         if (staged) {
             const size_t lds_s = ((size_t)4 * nbins + 16 + tp + 1) * 4 + (size_t)PS_CAP * 8;
-            hipLaunchKernelGGL(k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
-                               vstride, quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(),
-                               S.sorted.as<uint32_t>(), use_ones_bin, d_cls);
             if (b2 > 0) {
                 ZG_HIP(ctx, S.p2m.reserve(((size_t)2 * nb1 + 4) * 4));
                 ZG_HIP(ctx, S.tab2.reserve((n2 + 1) * 4));
                 ZG_HIP(ctx, S.abuf2.reserve(max_entries * 8));
-                hipLaunchKernelGGL(k_p2_plan, dim3(1), dim3(256), 0, st, S.tile_tab.as<uint32_t>(), ntiles, nb1, S.p2m.as<uint32_t>());
-                ZG_HIP(ctx, hipMemsetAsync(S.tab2.p, 0, (n2 + 1) * 4, st));   // chunks beyond the data-dependent count stay empty
+            }
+            hipLaunchKernelGGL(k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
+                               vstride, quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(),
+                               S.sorted.as<uint32_t>(), use_ones_bin, d_cls, b2 > 0 ? S.p2m.as<uint32_t>() : (uint32_t*)nullptr);
+            if (b2 > 0) {
                 hipLaunchKernelGGL(k_p2<0>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
                                    nb1, b2, 7, S.tab2.as<uint32_t>(), (uint2*)nullptr);
                 ZG_TRY(xscan(S.tab2.as<uint32_t>(), n2));
@@ -1520,11 +1703,11 @@ struct MsmJob : MsmJobBase {
                                    nb1, b2, 7, S.tab2.as<uint32_t>(), S.abuf2.as<uint2>());
                 hipLaunchKernelGGL(k_part_local, dim3(nbins3), dim3(1024), lds2, st, S.abuf2.as<uint2>(), (const uint32_t*)nullptr,
                                    0u, nbins3, lb3, stage_min, S.counts.as<uint32_t>(), S.sorted.as<uint32_t>(),
-                                   S.p2m.as<uint32_t>(), S.tab2.as<uint32_t>(), nb1, b2);
+                                   S.p2m.as<uint32_t>(), S.tab2.as<uint32_t>(), nb1, b2, single_max);
             } else {
                 hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                                    S.tile_tab.as<uint32_t>(), ntiles, nbins, lb3, stage_min, S.counts.as<uint32_t>(),
-                                   S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+                                   S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, single_max);
             }
         } else {
             hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
@@ -1533,7 +1716,7 @@ struct MsmJob : MsmJobBase {
             // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
             hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                                S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
-                               S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+                               S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, single_max);
         }
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
@@ -1584,7 +1767,7 @@ struct MsmJob : MsmJobBase {
         trace_point("phase_c reserved items");
         {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
-            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] its scan, [1] the heavy-bucket counter
+            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] claimed per size (k_item_scatter), [1] the heavy-bucket counter
             ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
             uint32_t* hist = S.ihist.as<uint32_t>();
             hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
@@ -1603,9 +1786,8 @@ struct MsmJob : MsmJobBase {
                 const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
                 hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
                                    S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist);
-                hipLaunchKernelGGL(k_item_scan, dim3(1), dim3(64), 0, st, hist, hist + ITEM_CLASSES);
                 hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
-                                   S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key,
+                                   S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist,
                                    hist + ITEM_CLASSES, S.perm.as<uint32_t>());
             }
         }

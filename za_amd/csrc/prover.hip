@@ -417,7 +417,9 @@ struct ProveWs {
     std::unique_ptr<HostPacker> packer;
     double pack_ema_ms = 0;   // running average of the packing pass's host time
     int pack_slow = 0;        // consecutive passes slower than the plain upload
-    int pack_skip = 0;        // proofs left to hand over unpacked after the pass turned out slower than the plain upload
+    int pack_skip = 0;        // hand-overs of pack_skip_nv values left to go unpacked: the pass was slower than the plain upload
+                              // (ZG_OPT_PACK = 2), or gave up on a witness of this size (not the kind that packs)
+    size_t pack_skip_nv = 0;
     // pinned: [classes | other_index | others32].  Two of them, used in turn, each with the event behind its copies: a
     // hand-over is queued, not waited for (zg_witness_to_device), so the next one must not pack into bytes still in flight
     uint8_t* stage[2] = {nullptr, nullptr};
@@ -945,7 +947,10 @@ static int msm_bases_make(zg_ctx* ctx, const void* src, bool src_is_device, size
         ZG_TRY(convert_mont_dev(ctx, b->bases.p, n * sizeof(Affine<F>) / 32, 0, 0));   // ABI form -> device form, once
     }
     int c = 0, nwin = 0;
-    if (n >= 64 && table_budget_gb > 0 && msm_fbw_plan(n, n, (size_t)(table_budget_gb * 1e9), sizeof(Affine<F>), &c, &nwin) &&
+    // (a negative budget: that much, and the table is built even where the cost model sees less than 8 % in it)
+    const double budget_gb = table_budget_gb < 0 ? -table_budget_gb : table_budget_gb;
+    if (n >= 64 && budget_gb > 0 &&
+        msm_fbw_plan(n, n, (size_t)(budget_gb * 1e9), sizeof(Affine<F>), &c, &nwin, false, table_budget_gb < 0) &&
         b->table.alloc((size_t)nwin * n * sizeof(Affine<F>)) == hipSuccess) {
         if constexpr (sizeof(F) == sizeof(Fq))
             ZG_TRY(msm_fbw_build_g1(ctx, b->bases.as<G1Affine>(), n, n, c, nwin, b->table.as<G1Affine>()));
@@ -1645,37 +1650,66 @@ int zg::params_h_eval_slice(Ctx* ctx, const zg_params* p, const G1Affine* d_h_fu
             (void)hipGetLastError();
             return ZG_OK;
         }
-        ZG_TRY(h_eval_bases_build(ctx, d_h_full, n_h, log_m, full.as<G1Affine>()));
+        if (h_eval_bases_build(ctx, d_h_full, n_h, log_m, full.as<G1Affine>()) != ZG_OK) {   // a fallback, not an error
+            (void)hipGetLastError();
+            ctx->last_error.clear();
+            return ZG_OK;
+        }
         d_h_eval_full = full.as<G1Affine>();
     }
     if (p->h_eval.alloc(std::max<uint64_t>(hi - lo, 1) * sizeof(G1Affine)) != hipSuccess) {
         (void)hipGetLastError();
         return ZG_OK;
     }
-    if (hi > lo) ZG_HIP(ctx, hipMemcpyAsync(p->h_eval.p, d_h_eval_full + lo, (hi - lo) * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream));
-    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((hi > lo && hipMemcpyAsync(p->h_eval.p, d_h_eval_full + lo, (hi - lo) * sizeof(G1Affine), hipMemcpyDeviceToDevice,
+                                   ctx->stream) != hipSuccess) ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        p->h_eval.release();
+        return ZG_OK;
+    }
     p->h_eval_log_m = log_m;
     p->h_eval_lo = lo;
     p->h_eval_hi = hi;
     p->h_eval_state = 1;
     return ZG_OK;
 }
-static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m) {
-    if (p->world != 1) return ZG_OK;   // a sharded key has its slice from the start, or never (params_h_eval_slice)
+// States of zg_params::h_eval_state: 0 not tried, 2 being built by some context, 1 built -- and from then on IMMUTABLE for
+// the key's lifetime (readers may keep the pointer after dropping the lock), -1 no evaluation form for this key (switched
+// off, the query has another shape, no room, the build failed): sticky, so a proof never pays a second attempt -- only
+// zg_params_prepare (retry) tries again.  The multi-second build runs OUTSIDE fbw_mu: contexts sharing the key go on in
+// the coefficient form meanwhile.  Any failure on the way is a fallback to bellman's seven transforms, never an error.
+static bool h_eval_ready(const zg_params* p, uint32_t log_m) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
-    if (p->h_eval_state == 1 && p->h_eval_log_m == log_m) return ZG_OK;
-    if (ctx->one_shot) return ZG_OK;   // (the state stays as it is: another context may still build the bases)
-    p->h_eval.release();
-    p->fbw_he.buf.release();
-    p->fbw_he.state = 0;
-    p->h_eval_state = -1;
+    return p->h_eval_state == 1 && p->h_eval_log_m == log_m;
+}
+static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m, bool retry = false) {
+    if (p->world != 1) return ZG_OK;   // a sharded key has its slice from the start, or never (params_h_eval_slice)
     const uint64_t m = (uint64_t)1 << log_m;
-    if (!h_eval_allowed(ctx) || log_m == 0 || p->q[0].total < m - 1) return ZG_OK;
-    if (p->h_eval.alloc(m * sizeof(G1Affine)) != hipSuccess) {
-        (void)hipGetLastError();
-        return ZG_OK;   // no room: the coefficient form is used
+    {
+        std::lock_guard<std::mutex> lock(p->fbw_mu);
+        if (p->h_eval_state == 1 || p->h_eval_state == 2) return ZG_OK;
+        if (p->h_eval_state == -1 && !retry) return ZG_OK;
+        if (ctx->one_shot) return ZG_OK;   // (the state stays as it is: another context may still build the bases)
+        if (!h_eval_allowed(ctx) || log_m == 0 || p->q[0].total < m - 1) {
+            p->h_eval_state = -1;
+            return ZG_OK;
+        }
+        p->h_eval_state = 2;
     }
-    ZG_TRY(h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, p->h_eval.as<G1Affine>()));
+    DevBuf built;
+    int rc = ZG_OK;
+    if (built.alloc(m * sizeof(G1Affine)) != hipSuccess) rc = ZG_E_HIP;   // no room: the coefficient form is used
+    if (rc == ZG_OK) rc = h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, built.as<G1Affine>());
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    if (rc != ZG_OK) {
+        (void)hipGetLastError();
+        ctx->last_error.clear();
+        p->h_eval_state = -1;
+        return ZG_OK;
+    }
+    std::swap(p->h_eval.p, built.p);
+    std::swap(p->h_eval.bytes, built.bytes);
     p->h_eval_log_m = log_m;
     p->h_eval_lo = 0;
     p->h_eval_hi = m;
@@ -1816,8 +1850,8 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     ZG_TRY(query_uses(ctx, p, r, d_witness, nullptr, 0x1f, use));
     // zg_prove* takes H in evaluation form when the key allows it: then the table that matters is the one over the
     // transformed bases (the coefficient-form table is still built on demand by the phase API)
-    ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
-    const bool eval_form = p->h_eval_state == 1 && p->h_eval_log_m == r->log_m;
+    ZG_TRY(ensure_h_eval(ctx, p, r->log_m, /*retry=*/true));
+    const bool eval_form = h_eval_ready(p, r->log_m);
     if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, p->h_eval_hi - p->h_eval_lo};   // (a sharded key: its slice)
     return ensure_tables(ctx, p, use, 0x1f, eval_form);
 } catch (...) {
@@ -1849,7 +1883,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     ws.wcls_armed = false;
     ZG_TRY(query_uses(ctx, p, r, d_witness, d_h_shard, mask, use, (mask & 0x1eu) ? ws.wcls.as<uint8_t>() : nullptr));
     if (h_eval_form && (mask & 1u)) {
-        if (!(p->h_eval_state == 1 && p->h_eval_log_m == r->log_m))
+        if (!h_eval_ready(p, r->log_m))
             return fail(ctx, ZG_E_INVALID_ARG, "this key has no evaluation-form h bases for a 2^%u domain", r->log_m);
         use[0] = QueryUse{p->h_eval.p, (const uint32_t*)d_h_shard, nullptr, p->h_eval_hi - p->h_eval_lo};
     }
@@ -1996,7 +2030,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     } class_guard{prove_ws(ctx)};
     // H in evaluation form where the key has (or can get) its transformed h bases: six transforms instead of seven
     ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
-    const bool eval_form = p->h_eval_state == 1 && p->h_eval_log_m == r->log_m;
+    const bool eval_form = h_eval_ready(p, r->log_m);
     ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
@@ -2158,10 +2192,11 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         if (trace) fprintf(stderr, "[za_amd trace] pack %-14s +%.3f ms\n", what, now_ms() - t_begin);
     };
     ProveWs& ws = prove_ws(ctx);
-    if (ws.pack_skip > 0) {   // see below
+    if (ws.pack_skip > 0 && ws.pack_skip_nv == nv) {   // see below
         ws.pack_skip--;
         return ZG_OK;
     }
+    ws.pack_skip = 0;
     const double t_pack0 = now_ms();
     const size_t max_others = nv / 8;
     const size_t cls_bytes = (nv + 3) / 4;
@@ -2191,6 +2226,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp, ctx->opt_pack_pin ? ws.pin_cpus : nowhere);
     if (n_others == SIZE_MAX) {   // not the kind of witness that packs: no point in scanning the next ones either
         ws.pack_skip = 32;
+        ws.pack_skip_nv = nv;
         return ZG_OK;
     }
     ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
@@ -2210,6 +2246,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
             ws.pack_slow = t > 0.9 * plain_ms ? ws.pack_slow + 1 : 0;
             if (ws.pack_slow >= 2 && ws.pack_ema_ms > 0.9 * plain_ms) {   // two slow passes in a row, not one late wake-up
                 ws.pack_skip = 32;
+                ws.pack_skip_nv = nv;
                 ws.pack_ema_ms = 0;
                 ws.pack_slow = 0;
             }

@@ -276,9 +276,14 @@ extern "C" int zg_params_shard(zg_ctx* ctx, const zg_params* full, int rank, int
     }
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     {   // the shard's slice of the evaluation-form h bases: from the full key's transformed array if it has one, else made here
-        const bool have = full->h_eval_state == 1 && ((uint64_t)1 << full->h_eval_log_m) == full->q[0].total + 1;
-        ZG_TRY(params_h_eval_slice(ctx, p.get(), full->q[0].buf.as<G1Affine>(), full->q[0].total,
-                                   have ? full->h_eval.as<G1Affine>() : nullptr));
+        // (sampled under the full key's lock; a built array is immutable for the key's lifetime -- prover.hip ensure_h_eval)
+        const G1Affine* have = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(full->fbw_mu);
+            if (full->h_eval_state == 1 && ((uint64_t)1 << full->h_eval_log_m) == full->q[0].total + 1)
+                have = full->h_eval.as<G1Affine>();
+        }
+        ZG_TRY(params_h_eval_slice(ctx, p.get(), full->q[0].buf.as<G1Affine>(), full->q[0].total, have));
     }
     *out = p.release();
     return ZG_OK;

@@ -136,23 +136,46 @@ bool json_string(const std::string& s, size_t q0, std::string* out) {
             case 'r': out->push_back('\r'); break;
             case 't': out->push_back('\t'); break;
             case 'u': {
-                if (i + 4 >= s.size()) return false;
+                // as serde_json: a high surrogate must be followed by a \uXXXX low surrogate and the pair is ONE code point
+                // (4 bytes of UTF-8); a lone surrogate is an error.  \u0000 is refused too: the string is a path, and an
+                // embedded NUL would silently cut it short at fopen.
+                auto hex4 = [&](size_t at, unsigned* v) {
+                    if (at + 3 >= s.size()) return false;
+                    unsigned x = 0;
+                    for (int d = 0; d < 4; d++) {
+                        const char h = s[at + d];
+                        x <<= 4;
+                        if (h >= '0' && h <= '9') x |= (unsigned)(h - '0');
+                        else if (h >= 'a' && h <= 'f') x |= (unsigned)(h - 'a' + 10);
+                        else if (h >= 'A' && h <= 'F') x |= (unsigned)(h - 'A' + 10);
+                        else return false;
+                    }
+                    *v = x;
+                    return true;
+                };
                 unsigned cp = 0;
-                for (int d = 1; d <= 4; d++) {
-                    const char h = s[i + d];
-                    cp <<= 4;
-                    if (h >= '0' && h <= '9') cp |= (unsigned)(h - '0');
-                    else if (h >= 'a' && h <= 'f') cp |= (unsigned)(h - 'a' + 10);
-                    else if (h >= 'A' && h <= 'F') cp |= (unsigned)(h - 'A' + 10);
-                    else return false;
-                }
+                if (!hex4(i + 1, &cp)) return false;
                 i += 4;
+                if (cp >= 0xDC00 && cp <= 0xDFFF) return false;   // a low surrogate on its own
+                if (cp >= 0xD800 && cp <= 0xDBFF) {
+                    unsigned lo = 0;
+                    if (i + 2 >= s.size() || s[i + 1] != '\\' || s[i + 2] != 'u' || !hex4(i + 3, &lo)) return false;
+                    if (lo < 0xDC00 || lo > 0xDFFF) return false;
+                    cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                    i += 6;
+                }
+                if (cp == 0) return false;
                 if (cp < 0x80) out->push_back((char)cp);
                 else if (cp < 0x800) {
                     out->push_back((char)(0xC0 | (cp >> 6)));
                     out->push_back((char)(0x80 | (cp & 0x3F)));
-                } else {
+                } else if (cp < 0x10000) {
                     out->push_back((char)(0xE0 | (cp >> 12)));
+                    out->push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+                    out->push_back((char)(0x80 | (cp & 0x3F)));
+                } else {
+                    out->push_back((char)(0xF0 | (cp >> 18)));
+                    out->push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
                     out->push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
                     out->push_back((char)(0x80 | (cp & 0x3F)));
                 }
