@@ -189,7 +189,7 @@ def acc_roofline(prof, pmc=None):
 def host_pack_threads():
     """zg_prove's host-side packing threads (csrc/prover.hip host_pack_threads: the default of ZG_OPT_PACK_THREADS)."""
     hc = os.cpu_count() or 1
-    return 0 if hc < 8 else min(8, hc // 2)
+    return 0 if hc < 8 else min(16, hc // 2)
 
 
 def pmc_for(args):

@@ -73,7 +73,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                         form (host threads build it, 3 % of the bytes cross PCIe): 1 = whenever the witness is of
  *                         that kind (default), 0 = never (the 32-byte array is copied as it is), 2 = as 1, but while the
  *                         pass measures slower than the plain copy on this host the next 32 witnesses go over unpacked.
- *   ZG_OPT_PACK_THREADS   host threads of that pass, the caller's included (default min(8, half the hardware threads);
+ *   ZG_OPT_PACK_THREADS   host threads of that pass, the caller's included (default min(16, half the hardware threads);
  *                         0 = the default).
  *   ZG_OPT_PACK_MIN_LOG_N witnesses of fewer than 2^value values are never packed (default 20).
  *   ZG_OPT_PACK_PIN       1 (default): the pass's worker threads are bound to the CPUs of the GPU's NUMA node, where

@@ -833,12 +833,15 @@ def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts, opts):
     sr.close()
 
 
-def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch, opts):
-    """An all-0/1 witness takes the subset-sum ("quad") tables for l and a.  Rows (u - v + w) * 1 = w give the a and l
-    queries pairs of opposite points in neighbouring positions (their subset sum is the identity), rows
-    (x + y) * 1 = z pairs of equal points; proof against the C oracle, the plain schedule, and the pairing check."""
+@pytest.mark.parametrize("qw", ["4", "8"])
+def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch, opts, qw):
+    """An all-0/1 witness takes the subset-sum tables for l and a (groups of four or of eight positions).  Rows
+    (u - v + w) * 1 = w give the a and l queries pairs of opposite points in neighbouring positions (their subset sum is
+    the identity), rows (x + y) * 1 = z pairs of equal points; proof against the C oracle, the plain schedule, and the
+    pairing check."""
     import za_amd
     monkeypatch.setenv("ZA_AMD_SMALL_LOG_N", "0")   # (jobs of this size otherwise take the small-job mode: window tables)
+    monkeypatch.setenv("ZA_AMD_QUAD_W", qw)
     rng = np.random.default_rng(7)
     w = [1, 1]                       # ONE, one public input (a constant 1)
     cons = []
@@ -872,6 +875,54 @@ def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch, opts
     P2, _ = ctx.setup(R, 0x91, 0x82, 0x73, 0x64, 0x55)
     assert ctx.prove_dev(P2, R, d_w, 1234, 5678) == got
     ctx.free(d_w)
+
+
+def test_compact_window_table_over_the_field_element_positions_and_its_fallback(ctx, monkeypatch):
+    """A bit-heavy query's subset-sum table carries a window table over the positions that held field elements in the
+    witness it was built from (their digits then share one bucket set).  Same proof as the C oracle; a LATER witness with a
+    field element at a position that was a bit takes the per-window path for that proof (k_classify counts such
+    positions) -- again the oracle's bytes; and the same proofs with the compact rows switched off (ZA_AMD_CW=0)."""
+    from za_amd import synth
+    monkeypatch.setenv("ZA_AMD_SMALL_LOG_N", "0")   # (queries of this size otherwise take the small-job mode: window tables)
+    lg = 15
+    sr = synth.SynthR1CS(lg, 2, 0.95, 4242)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    w1 = np.array(sr.witness, copy=True)
+    # a second witness: some aux values that are bits in w1 become field elements (the system is no longer satisfied; the
+    # proof is still a well-defined group element, and the oracle computes the same one)
+    w2 = w1.copy().reshape(-1, 32)
+    rng = np.random.default_rng(9)
+    changed = 0
+    for v in range(sr.n_inputs + 100, sr.n_inputs + sr.n_aux, 997):
+        if not w2[v, 1:].any() and w2[v, 0] <= 1:
+            w2[v, :31] = np.frombuffer(rng.bytes(31), dtype=np.uint8)
+            changed += 1
+    assert changed >= 8
+    w2 = w2.reshape(-1)
+    proofs = {}
+    for cw in ("1", "0"):
+        monkeypatch.setenv("ZA_AMD_CW", cw)
+        P = synth.synth_params(ctx, *sizes, 61)
+        d_w = ctx.upload(w1)
+        P.prepare(R, d_w)
+        kinds = [P.table_info(k) for k in range(5)]
+        assert [k[0] for k in kinds[1:]] == [2, 2, 2, 2], kinds       # subset-sum tables for l, a, b_g1, b_g2
+        proofs[cw] = (ctx.prove_dev(P, R, d_w, 77, 88), ctx.prove(P, R, w2, 77, 88), ctx.prove_dev(P, R, d_w, 77, 88),
+                      [k[1] for k in kinds])
+        ctx.free(d_w)
+        if cw == "1":
+            mp = download_params(ctx, P)
+        P.close()
+    assert proofs["1"][:3] == proofs["0"][:3]
+    # the l query's table carries the compact rows (its 5 % of field elements are enough of them; the shorter a / b queries
+    # may fall below the 1024 the rows are built from)
+    assert proofs["1"][3][1] > proofs["0"][3][1], (proofs["1"][3], proofs["0"][3])
+    assert proofs["1"][0] == proofs["1"][2] == co.prove(mp, csr, w1, 77, 88, threads=8)
+    assert proofs["1"][1] == co.prove(mp, csr, w2, 77, 88, threads=8)
+    R.close(); sr.close()
 
 
 def test_h_coefficient_equal_to_one_single_constraint(ctx):

@@ -158,10 +158,16 @@ struct MsmDesc {
     size_t fbw_stride = 0;
     // optional subset-sum table for a mostly-0/1 assignment: [n bases][15 sums per 4 positions]
     const void* quad_table = nullptr;
+    int quad_w = 4;   // positions per group of the subset-sum table (4: 15 sums, 8: 255 sums)
+    // optional with quad_table: the compact window table behind the subset sums (msm.hip MsmJob::cw_rank)
+    const uint32_t* cw_rank = nullptr;
+    uint32_t cw_off = 0, cw_n = 0;
+    int cw_c = 0, cw_nwin = 0;
     // optional, dense jobs run in parts: part k's stream waits for part_gate[k] (e.g. "scalar chunk k has arrived")
     const hipEvent_t* part_gate = nullptr;
     bool part_gate_only = false;   // the part gates replace the job's common gate (ev_h) instead of adding to it
     int parts = 0;   // 0 = the scheduler's choice
+    const size_t* part_bounds = nullptr;   // optional with parts > 0: parts + 1 ascending positions, [0] = 0, [parts] = n
     // optional: one class byte per scalar position (0 = zero, 1 = one, 2 = anything else; addressed like `scalars`,
     // through `index` if there is one).  The classification and the digit sort then read 1 byte instead of 32 for
     // every 0 / 1 scalar -- a witness query of the SHA-like workload is 97 % of those, and each job makes three passes.
@@ -169,9 +175,9 @@ struct MsmDesc {
     // small-job mode (msm.hip): 1 / 0 = decided with the key's table for this query, -1 = by the job's size
     int small_hint = -1;
 };
-int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf);
-int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf);
-size_t msm_quad_entries(size_t n);
+int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf, int qw);
+int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf, int qw);
+size_t msm_quad_entries(size_t n, int qw);
 bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force = false,
                   bool always = false);
 size_t msm_small_n();           // dense jobs up to this size are latency bound (planned for depth, always with a window table)
@@ -180,6 +186,12 @@ int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride,
 int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table);
 int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,
                         uint64_t* ones);
+// d_rank[i] = column of position i among the n scalars that are neither 0 nor 1 (in position order), ~0 for the others;
+// d_compact[column] = d_bases[i].  *n_real = their number.  Blocking.
+int msm_compact_reals_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
+                         uint32_t* d_rank, G1Affine* d_compact, uint64_t* n_real);
+int msm_compact_reals_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
+                         uint32_t* d_rank, G2Affine* d_compact, uint64_t* n_real);
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
                hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr);

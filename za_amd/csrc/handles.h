@@ -40,7 +40,13 @@ struct zg_params {
     struct Fbw {
         zg::DevBuf buf;
         int c = 0, nwin = 0;
-        int kind = 0;    // 0 = window table, 1 = subset-sum ("quad") table
+        int kind = 0;    // 0 = window table, 1 = subset-sum table
+        int qw = 4;      // subset-sum table: positions per group (4 or 8)
+        // subset-sum table with a compact window table behind it (msm.hip MsmJob::cw_rank): cw_nwin rows of cw_n points
+        // from entry cw_off of buf on; rank: column per position
+        zg::DevBuf rank;
+        uint32_t cw_off = 0, cw_n = 0;
+        int cw_c = 0, cw_nwin = 0;
         uint64_t n = 0;
         int state = 0;   // 0 = not tried, 1 = built, -1 = disabled / does not fit / does not pay
         bool small = false;   // planned for a latency-bound job (msm.hip small-job mode): decided with the table, when the

@@ -222,42 +222,51 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
 }
 
 // zeros / ones / other scalars (through the index indirection), one atomic per wave and class
+// rank (or NULL): the job's compact window table (MsmJob::cw_rank); cls[2] counts the scalars that are neither 0 nor 1
+// at positions the table does not cover -- any such scalar sends the job down the per-window path for this proof
 __global__ void __launch_bounds__(256) k_classify(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
                                                   const uint8_t* __restrict__ wcls, size_t n,
-                                                  uint32_t* __restrict__ cls /*[3]*/) {
+                                                  uint32_t* __restrict__ cls /*[3]*/, const uint32_t* __restrict__ rank) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n_round = (n + 63) & ~(size_t)63;
-    uint32_t zeros = 0, ones = 0;
+    uint32_t zeros = 0, ones = 0, unranked = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        uint32_t c = 0;
         if (i < n && wcls) {
-            const uint32_t c = wcls[index ? (size_t)index[i] : i];
-            zeros += c == 0;
-            ones += c == 1;
+            c = wcls[index ? (size_t)index[i] : i];
         } else if (i < n) {
             Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
             uint32_t hi = s.w[1] | s.w[2] | s.w[3] | s.w[4] | s.w[5] | s.w[6] | s.w[7];
-            zeros += (hi | s.w[0]) == 0;
-            ones += hi == 0 && s.w[0] == 1;
+            c = (hi | s.w[0]) == 0 ? 0u : hi == 0 && s.w[0] == 1 ? 1u : 2u;
+        }
+        if (i < n) {
+            zeros += c == 0;
+            ones += c == 1;
+            if (rank && c == 2) unranked += rank[i] == 0xffffffffu;
         }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         zeros += __shfl_down(zeros, d);
         ones += __shfl_down(ones, d);
+        unranked += __shfl_down(unranked, d);
     }
-    // one pair of device-scope atomics per WORKGROUP: per wave they were 16 k serialised read-modify-writes on two
+    // one set of device-scope atomics per WORKGROUP: per wave they were 16 k serialised read-modify-writes on two
     // addresses for a 4 M-position query (0.2 - 0.35 ms of a kernel that reads 20 MB)
-    __shared__ uint32_t part[2][4];
+    __shared__ uint32_t part[3][4];
     if (lane_id() == 0) {
         part[0][threadIdx.x >> 6] = zeros;
         part[1][threadIdx.x >> 6] = ones;
+        part[2][threadIdx.x >> 6] = unranked;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t z = part[0][0] + part[0][1] + part[0][2] + part[0][3];
         const uint32_t o = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        const uint32_t u = part[2][0] + part[2][1] + part[2][2] + part[2][3];
         if (z) atomicAdd(&cls[0], z);
         if (o) atomicAdd(&cls[1], o);
+        if (u) atomicAdd(&cls[2], u);
     }
 }
 
@@ -288,7 +297,8 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
                                               size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
                                               int lb, uint32_t ntiles, uint32_t tp, uint32_t* __restrict__ tile_tab,
                                               uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
-                                              const uint8_t* __restrict__ wcls) {
+                                              const uint8_t* __restrict__ wcls, int qw, const uint32_t* __restrict__ rank,
+                                              uint32_t rank_off) {
     extern __shared__ uint32_t lds_bins[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;  // last bin: scalars == 1
     const uint32_t wsel = kw == 1 ? 0u : ~0u;            // folded windows (fbw table): the window goes into the value
@@ -319,15 +329,16 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
             zero = !live || scalar_is_zero(s);
         }
         if (quad_n) {
-            // Subset-sum table (msm_quad_build): the four lanes of an aligned group of positions whose scalars are
-            // all 0 or 1 emit ONE entry, the table's sum over the positions holding a 1.
-            const uint64_t mo = __ballot(one), mr = __ballot(!one && !zero);
-            const uint32_t qb = lane_id() & ~3u;
-            const uint32_t q_ones = (uint32_t)(mo >> qb) & 15u, q_real = (uint32_t)(mr >> qb) & 15u;
-            if (q_real == 0) {
-                if (one && (lane_id() & 3u) == (uint32_t)__builtin_ctz(q_ones)) {
+            // Subset-sum table (msm_quad_build): the qw (4 or 8) lanes of an aligned group of positions emit ONE entry for
+            // all of the group's scalars equal to 1 -- the table's sum over the positions holding one -- whatever the other
+            // positions hold (a field element among them takes its digits as usual).
+            const uint64_t mo = __ballot(one);
+            const uint32_t qb = lane_id() & ~((uint32_t)qw - 1u), gm = (1u << qw) - 1u;
+            const uint32_t q_ones = (uint32_t)(mo >> qb) & gm;
+            if (one) {
+                if ((lane_id() - qb) == (uint32_t)__builtin_ctz(q_ones)) {
                     uint32_t pos = atomicAdd(&lds_bins[nbins - 1], 1u);
-                    if (MODE == 1) sorted[pos] = quad_n + 15u * (uint32_t)(i >> 2) + q_ones - 1u;
+                    if (MODE == 1) sorted[pos] = quad_n + gm * (uint32_t)(i / (uint32_t)qw) + q_ones - 1u;
                 }
                 continue;
             }
@@ -338,6 +349,8 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
             if (MODE == 1) sorted[pos] = (uint32_t)i;   // the ones bin is one bucket and the last bin: final order
             continue;
         }
+        // (rank: the point's row-0 entry in the compact window table that follows the subset sums, MsmJob::cw_rank)
+        const uint32_t vi = rank ? rank_off + rank[i] : (uint32_t)i;
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
             int32_t d = next_digit(s, c, carry);
@@ -345,7 +358,7 @@ __global__ void __launch_bounds__(256) k_part(const uint32_t* __restrict__ scala
             const uint32_t mag = (uint32_t)(d < 0 ? -d : d) - 1u;
             uint32_t pos = atomicAdd(&lds_bins[(((uint32_t)w & wsel) << hb) | (mag >> lb)], 1u);
             if (MODE == 1)
-                A[pos] = make_uint2(((uint32_t)i + (uint32_t)w * vstride) | (d < 0 ? 0x80000000u : 0u), mag & lomask);
+                A[pos] = make_uint2((vi + (uint32_t)w * vstride) | (d < 0 ? 0x80000000u : 0u), mag & lomask);
         }
     }
     if (MODE == 0) {
@@ -414,7 +427,8 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
                                                      size_t n, int c, int nwin, int kw, uint32_t vstride, uint32_t quad_n, int hb,
                                                      int lb, uint32_t ntiles, uint32_t tp, const uint32_t* __restrict__ tile_tab,
                                                      uint2* __restrict__ A, uint32_t* __restrict__ sorted, int use_ones_bin,
-                                                     const uint8_t* __restrict__ wcls, uint32_t* __restrict__ p2m) {
+                                                     const uint8_t* __restrict__ wcls, uint32_t* __restrict__ p2m, int qw,
+                                                     const uint32_t* __restrict__ rank, uint32_t rank_off) {
     extern __shared__ uint32_t lds_s[];
     const uint32_t nbins = ((uint32_t)kw << hb) + 1u;   // last bin: scalars == 1 (final order, goes to `sorted`)
     uint32_t* hist = lds_s;                  // [nbins] the round's counts
@@ -477,12 +491,12 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
             zero = !live || scalar_is_zero(s);
         }
         if (quad_n) {
-            const uint64_t mo = __ballot(one), mr = __ballot(!one && !zero);
-            const uint32_t qb = lane_id() & ~3u;
-            const uint32_t q_ones = (uint32_t)(mo >> qb) & 15u, q_real = (uint32_t)(mr >> qb) & 15u;
-            if (q_real == 0) {
-                if (one && (lane_id() & 3u) == (uint32_t)__builtin_ctz(q_ones))
-                    emit(nbins - 1, quad_n + 15u * (uint32_t)(i >> 2) + q_ones - 1u, 0u);
+            const uint64_t mo = __ballot(one);
+            const uint32_t qb = lane_id() & ~((uint32_t)qw - 1u), gm = (1u << qw) - 1u;
+            const uint32_t q_ones = (uint32_t)(mo >> qb) & gm;
+            if (one) {
+                if ((lane_id() - qb) == (uint32_t)__builtin_ctz(q_ones))
+                    emit(nbins - 1, quad_n + gm * (uint32_t)(i / (uint32_t)qw) + q_ones - 1u, 0u);
                 return;
             }
         }
@@ -491,7 +505,7 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
             emit(nbins - 1, (uint32_t)i, 0u);
             return;
         }
-        walk_digits(s, (uint32_t)i, c, nwin, wsel, vstride, hb, lb, lomask, emit);
+        walk_digits(s, rank ? rank_off + rank[i] : (uint32_t)i, c, nwin, wsel, vstride, hb, lb, lomask, emit);
     };
     // ---- a tile in which every point may contribute all of its nwin digits (the h job, a uniform witness).  A round is
     // PS_CAP / nwin whole points: their scalars come in by coalesced 16-byte loads (issued a round ahead, parked in
@@ -502,7 +516,7 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
     // the general rounds below make two passes over the scalars with a thread walking its points' digits one by one.
     {
         const uint32_t live = base >= n ? 0u : (uint32_t)std::min<size_t>(tp, n - base);
-        const bool full = (pfx[tp] & 0x3FFFFFFFu) == live * (uint32_t)nwin && (wcls || !use_ones_bin) && !quad_n && nwin >= 8;
+        const bool full = (pfx[tp] & 0x3FFFFFFFu) == live * (uint32_t)nwin && (wcls || !use_ones_bin) && !quad_n && !rank && nwin >= 8;
         if (full) {
             constexpr uint32_t PER = PS_CAP / 256, PRE = 4;   // nwin >= 8: at most 512 points = 1024 16-byte units per round
             const uint32_t ppr = PS_CAP / (uint32_t)nwin;
@@ -584,16 +598,16 @@ __global__ void __launch_bounds__(256) k_part_staged(const uint32_t* __restrict_
             return;
         }
     }
-    // ---- rounds: points [k_lo, k_hi), both multiples of four (a subset-sum group never straddles a round), whose
+    // ---- rounds: points [k_lo, k_hi), both multiples of eight (a subset-sum group never straddles a round), whose
     // entry bounds sum to at most PS_CAP
     for (uint32_t k_lo = 0; k_lo < tp;) {
         const uint32_t p_lo = pfx[k_lo] & 0x3FFFFFFFu;
-        uint32_t lo = k_lo / 4 + 1, hi = tp / 4;   // group indices; the answer is the largest g with pfx[4 g] - p_lo <= PS_CAP
-        while (lo < hi) {
+        uint32_t lo = k_lo / 8 + 1, hi = tp / 8;   // group indices; the answer is the largest g with pfx[8 g] - p_lo <= PS_CAP
+        while (lo < hi) {                          // (a group's bound is at most 8 nwin <= 1024)
             const uint32_t mid = (lo + hi + 1) / 2;
-            if ((pfx[4 * mid] & 0x3FFFFFFFu) - p_lo <= PS_CAP) lo = mid; else hi = mid - 1;
+            if ((pfx[8 * mid] & 0x3FFFFFFFu) - p_lo <= PS_CAP) lo = mid; else hi = mid - 1;
         }
-        const uint32_t k_hi = 4 * lo;
+        const uint32_t k_hi = 8 * lo;
         const uint32_t bound = (pfx[k_hi] & 0x3FFFFFFFu) - p_lo;
         if (bound == 0) {   // nothing but zeros up to k_hi (uniform: every thread reads the same words)
             k_lo = k_hi;
@@ -1500,6 +1514,16 @@ struct MsmJob : MsmJobBase {
     bool eager_small = false;
     const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
     uint32_t quad_base = 0;   // entry (relative to quad_table) of group 0's sums; 0 = n (the job covers the whole query)
+    int quad_w = 4;           // positions per subset-sum group (4 or 8)
+    // Compact window table (prover.hip ensure_tables): behind the subset sums of quad_table sit cw_nwin rows of cw_n
+    // points, 2^(cw_c w) P_i for the positions i that hold field elements (a circuit's bit signals are structural: the
+    // positions are those of the witness the table was built from); cw_rank[i] = the position's column, or ~0.  The job
+    // then folds its windows into ONE bucket set like a window-table job while its ones keep their subset sums.  A
+    // proof whose witness has a field element anywhere else (k_classify counts them) takes the per-window path.
+    const uint32_t* cw_rank = nullptr;
+    uint32_t cw_off = 0, cw_n = 0;
+    int cw_c = 0, cw_nwin = 0;
+    bool use_cw = false;
     const Affine<F>* fbw_table = nullptr;   // fixed-base window table: [fbw_nwin][fbw_stride] affine points
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
@@ -1535,14 +1559,15 @@ struct MsmJob : MsmJobBase {
         ZG_HIP(ctx, S.meta.reserve(64));
         if (dense || eager_small) {   // counts are taken as (0 zeros, 0 ones): the plan and the buffer bounds stay valid for any data
             uint32_t* cls = reinterpret_cast<uint32_t*>(S.host);
-            cls[0] = cls[1] = 0;
+            cls[0] = cls[1] = cls[2] = 0;
             eager = true;
             return ZG_OK;
         }
         ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
-        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8);
-        ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 8, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8,
+                           cw_rank);
+        ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 12, hipMemcpyDeviceToHost, st));
         return ZG_OK;
     }
 
@@ -1561,7 +1586,8 @@ struct MsmJob : MsmJobBase {
             return ZG_OK;
         }
         if (dep && dep->ev_sorted) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_sorted, 0));
-        P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : plan_msm(n_real, n_ones);
+        use_cw = cw_rank && !fbw_table && !dense && !eager_small && cls[2] == 0 && n_real > 0;
+        P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : use_cw ? plan_fbw_for(cw_c, cw_nwin, n_real) : plan_msm(n_real, n_ones);
         {   // Small jobs are latency bound: a thread runs its item's mixed adds one after the other (64 G2 adds are
             // 1.1 ms whatever n is).  Below ~64K items the items are shortened -- down to half the mean bucket load, so
             // that only buckets above twice the mean need the heavy-bucket fold -- and the GPU gets more, shorter threads.
@@ -1654,12 +1680,13 @@ struct MsmJob : MsmJobBase {
                                                     (size_t)2 * ((nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE)) * 4));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
-        const uint32_t vstride = P.kw == 1 ? (uint32_t)fbw_stride : 0u;
+        const uint32_t vstride = use_cw ? cw_n : P.kw == 1 ? (uint32_t)fbw_stride : 0u;
+        const uint32_t* rank = use_cw ? cw_rank : (const uint32_t*)nullptr;
         const uint32_t quad_n = quad_table && !fbw_table && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
         const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
         hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
-                           d_cls);
+                           d_cls, quad_w, rank, cw_off);
         // exclusive scan of a u32 table of tn entries in place (+ the total in entry tn)
         auto xscan = [&](uint32_t* tab, size_t tn) -> int {
             const uint32_t nbx = (uint32_t)((tn + 1 + SCAN_TILE - 1) / SCAN_TILE);
@@ -1694,7 +1721,8 @@ struct MsmJob : MsmJobBase {
             }
             hipLaunchKernelGGL(k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
                                vstride, quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(),
-                               S.sorted.as<uint32_t>(), use_ones_bin, d_cls, b2 > 0 ? S.p2m.as<uint32_t>() : (uint32_t*)nullptr);
+                               S.sorted.as<uint32_t>(), use_ones_bin, d_cls, b2 > 0 ? S.p2m.as<uint32_t>() : (uint32_t*)nullptr, quad_w,
+                               rank, cw_off);
             if (b2 > 0) {
                 hipLaunchKernelGGL(k_p2<0>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
                                    nb1, b2, 7, S.tab2.as<uint32_t>(), (uint2*)nullptr);
@@ -1712,7 +1740,7 @@ struct MsmJob : MsmJobBase {
         } else {
             hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                                quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
-                               use_ones_bin, d_cls);
+                               use_ones_bin, d_cls, quad_w, rank, cw_off);
             // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
             hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                                S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
@@ -2111,9 +2139,18 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     j->dense = d.dense;
     j->eager_small = !d.dense && (d.small_hint >= 0 ? d.small_hint != 0 : hi - lo <= msm_small_n());
     j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
-    if (d.quad_table) {
+    if (d.quad_table) {   // (lo is a multiple of the group width)
         j->quad_table = (const Affine<F>*)d.quad_table + lo;
-        j->quad_base = (uint32_t)(d.n - lo + 15 * (lo / 4));   // the sums start at entry n of the table, 15 per group of 4
+        j->quad_w = d.quad_w;
+        // the sums start at entry n of the table, 2^qw - 1 per group of qw positions
+        j->quad_base = (uint32_t)(d.n - lo + (((size_t)1 << d.quad_w) - 1) * (lo / (size_t)d.quad_w));
+        if (d.cw_rank && lo == 0 && hi == d.n) {   // (the compact rows are addressed from the table's start: whole-query jobs)
+            j->cw_rank = d.cw_rank;
+            j->cw_off = d.cw_off;
+            j->cw_n = d.cw_n;
+            j->cw_c = d.cw_c;
+            j->cw_nwin = d.cw_nwin;
+        }
     }
     if (d.fbw_table) {
         j->fbw_table = (const Affine<F>*)d.fbw_table + lo;   // row w of the range starts at w * stride + lo
@@ -2184,7 +2221,11 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     {
         const size_t n = g1[0].n, chunk = (n + parts - 1) / parts;
         for (int k = 0; k < parts; k++) {
-            const size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
+            size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
+            if (g1[0].part_bounds && parts == g1[0].parts) {   // the caller's own (unequal) split
+                lo = std::min(n, g1[0].part_bounds[k]);
+                hi = std::min(n, g1[0].part_bounds[k + 1]);
+            }
             const int slot = k == 0 ? 0 : 4 + k;
             hp[k] = make_range_job<Fq>(ctx, slot, g1[0], lo, hi, &hout[k]);
             if (g1[0].part_gate) {   // the caller's gates go with ITS part count; fewer parts here: wait for all of them
@@ -2256,38 +2297,40 @@ int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride,
     return ZG_OK;
 }
 
-// Subset-sum ("quad") table for a query whose assignment is mostly 0 / 1: out[15 * g + m - 1] = sum of
-// bases[4g + j] over the bits j of m (m = 1 .. 15), affine.  A group of four 0/1 scalars then costs one mixed add
-// (15/16 on average) instead of one per 1 (2 on average).  3.75x the query's footprint.
+// Subset-sum table for a query whose assignment is mostly 0 / 1: out[(2^qw - 1) g + m - 1] = sum of bases[qw g + j] over
+// the bits j of m (m = 1 .. 2^qw - 1), affine, qw = 4 or 8 positions per group.  The ones of a group then cost ONE mixed
+// add instead of one each (two on average per 4 positions, four per 8).  3.75 x (qw = 4) resp. 31.9 x (qw = 8) the
+// query's footprint -- 8.8 GB for a 2^22-position G1 query: the kind of trade 288 GB of HBM is there for.
 template <class F>
-__global__ void __launch_bounds__(256) k_quad_build(const Affine<F>* __restrict__ bases, size_t n, Affine<F>* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_quad_build(const Affine<F>* __restrict__ bases, size_t n, Affine<F>* __restrict__ out,
+                                                    int qw) {
     using L = typename LazyOf<F>::L;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t groups = (n + 3) / 4;
-    if (t >= groups * 15) return;
-    const size_t g = t / 15;
-    const uint32_t m = (uint32_t)(t - g * 15) + 1u;
+    const size_t nsum = ((size_t)1 << qw) - 1, groups = (n + qw - 1) / qw;
+    if (t >= groups * nsum) return;
+    const size_t g = t / nsum;
+    const uint32_t m = (uint32_t)(t - g * nsum) + 1u;
     XYZZd<L> acc = XYZZd<L>::inf();
-    for (int j = 0; j < 4; j++) {
-        const size_t i = 4 * g + j;
+    for (int j = 0; j < qw; j++) {
+        const size_t i = (size_t)qw * g + j;
         if (!((m >> j) & 1u) || i >= n) continue;
         acc = acc.add_mixed(AffD<L>::load(&bases[i]));
     }
     acc.to_affine_mem(&out[t]);
 }
 template <class F>
-static int quad_build(Ctx* ctx, const Affine<F>* d_bases, size_t n, Affine<F>* d_buf) {
+static int quad_build(Ctx* ctx, const Affine<F>* d_bases, size_t n, Affine<F>* d_buf, int qw) {
     if (n == 0) return ZG_OK;
     ZG_HIP(ctx, hipMemcpyAsync(d_buf, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, ctx->stream));
-    const size_t threads = (n + 3) / 4 * 15;
+    const size_t threads = (n + qw - 1) / qw * (((size_t)1 << qw) - 1);
     hipLaunchKernelGGL((k_quad_build<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n,
-                       d_buf + n);
+                       d_buf + n, qw);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
-int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf) { return quad_build<Fq>(ctx, d_bases, n, d_buf); }
-int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf) { return quad_build<Fq2>(ctx, d_bases, n, d_buf); }
-size_t msm_quad_entries(size_t n) { return n + (n + 3) / 4 * 15; }
+int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf, int qw) { return quad_build<Fq>(ctx, d_bases, n, d_buf, qw); }
+int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf, int qw) { return quad_build<Fq2>(ctx, d_bases, n, d_buf, qw); }
+size_t msm_quad_entries(size_t n, int qw) { return n + (n + qw - 1) / qw * (((size_t)1 << qw) - 1); }
 
 // blocking: how many of the n scalars (through the index indirection) are 0 / 1
 int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,
@@ -2299,13 +2342,66 @@ int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_i
     ZG_HIP(ctx, hipMemsetAsync(cnt.p, 0, 16, ctx->stream));
     const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 4);
     hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, (const uint8_t*)nullptr, n,
-                       cnt.as<uint32_t>());
+                       cnt.as<uint32_t>(), (const uint32_t*)nullptr);
     uint32_t h[2] = {0, 0};
     ZG_HIP(ctx, hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *zeros = h[0];
     *ones = h[1];
     return ZG_OK;
+}
+
+// ---- the positions of a query that hold field elements, compacted (the columns of the compact window table)
+__global__ void __launch_bounds__(256) k_real_flags(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ index,
+                                                    size_t n, uint32_t* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Scalar256 s = load_scalar(scalars, index ? (size_t)index[i] : i);
+    flag[i] = scalar_is_zero(s) || scalar_is_one(s) ? 0u : 1u;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_compact_reals(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ excl,
+                                                       size_t n, uint32_t* __restrict__ rank, Affine<F>* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = excl[i];
+    if (excl[i + 1] != r) {   // (the scanned flags have n + 1 entries)
+        rank[i] = r;
+        out[r] = bases[i];
+    } else {
+        rank[i] = 0xffffffffu;
+    }
+}
+template <class F>
+static int compact_reals(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
+                         uint32_t* d_rank, Affine<F>* d_compact, uint64_t* n_real) {
+    *n_real = 0;
+    if (n == 0) return ZG_OK;
+    DevBuf fl, bs;
+    const uint32_t nbx = (uint32_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    ZG_HIP(ctx, fl.alloc((n + 1) * 4));
+    ZG_HIP(ctx, bs.alloc((size_t)nbx * 4));
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_real_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_index, n, fl.as<uint32_t>());
+    hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
+    hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, bs.as<uint32_t>(), nbx);
+    hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
+    hipLaunchKernelGGL((k_compact_reals<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, fl.as<uint32_t>(), n,
+                       d_rank, d_compact);
+    uint32_t total = 0;
+    ZG_HIP(ctx, hipMemcpyAsync(&total, fl.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
+    ZG_HIP(ctx, hipStreamSynchronize(st));
+    ZG_HIP(ctx, hipGetLastError());
+    *n_real = total;
+    return ZG_OK;
+}
+int msm_compact_reals_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
+                         uint32_t* d_rank, G1Affine* d_compact, uint64_t* n_real) {
+    return compact_reals<Fq>(ctx, d_bases, d_scalars, d_index, n, d_rank, d_compact, n_real);
+}
+int msm_compact_reals_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
+                         uint32_t* d_rank, G2Affine* d_compact, uint64_t* n_real) {
+    return compact_reals<Fq2>(ctx, d_bases, d_scalars, d_index, n, d_rank, d_compact, n_real);
 }
 
 void msm_scratch_free(Ctx* ctx) {

@@ -988,7 +988,7 @@ extern "C" int zg_msm_bases_info(const zg_msm_bases* b, uint64_t info[4]) {
 }
 // one multiexp over resident bases; `gates` (nullable) = per-part events for chunked scalar uploads
 static int msm_resident_run(zg_ctx* ctx, const zg_msm_bases* b, const void* d_scalars, size_t n, int dense_hint, int parts,
-                            const hipEvent_t* gates, uint8_t* out_jac) {
+                            const hipEvent_t* gates, uint8_t* out_jac, const size_t* part_bounds = nullptr) {
     MsmDesc d1[4], d2;
     for (int k = 0; k < 4; k++) d1[k] = MsmDesc{nullptr, nullptr, nullptr, 0};
     d2 = MsmDesc{nullptr, nullptr, nullptr, 0};
@@ -1001,6 +1001,7 @@ static int msm_resident_run(zg_ctx* ctx, const zg_msm_bases* b, const void* d_sc
     }
     d.part_gate = gates;
     d.parts = parts;
+    d.part_bounds = part_bounds;
     G1XYZZ o1[4];
     G2XYZZ o2;
     if (!b->g2) {
@@ -1036,19 +1037,37 @@ extern "C" int zg_msm_resident(zg_ctx* ctx, zg_msm_bases* b, const uint8_t* scal
     }
     int parts = 1;
     if (!b->g2 && dense_hint && n >= ((size_t)1 << 22)) parts = 4;
-    const size_t chunk = (n + parts - 1) / parts;   // msm_batch5 splits the same way
+    // Chunks of 1 : 2 : 4 : 8.  Nothing can start before the first chunk is there, so it is small (1/15 of the scalars:
+    // 2.4 ms of PCIe at 2^26 instead of 9); and since a part computes ~2 x longer than its chunk uploads, a chunk twice the
+    // size of the one before still arrives before the part before it is done.
+    size_t bounds[5] = {0, n, n, n, n};
+    if (parts == 4) {
+        int w[4] = {1, 2, 4, 8};
+        if (const char* e = getenv("ZA_AMD_MSM_CHUNKS")) {   // experiment switch: "a,b,c,d"
+            int t[4];
+            if (sscanf(e, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) == 4 && t[0] > 0 && t[1] > 0 && t[2] > 0 && t[3] > 0)
+                for (int k = 0; k < 4; k++) w[k] = t[k];
+        }
+        const int tot = w[0] + w[1] + w[2] + w[3];
+        size_t acc = 0;
+        for (int k = 0; k < 3; k++) {
+            acc += (size_t)w[k];
+            bounds[k + 1] = std::min(n, (n / (size_t)tot * acc + 4095) & ~(size_t)4095);
+        }
+    }
     // the copy stream must not overtake earlier work of this ctx that still reads the staging buffer
     ZG_HIP(ctx, hipEventRecord(b->chunk_ev[0], ctx->stream));
     ZG_HIP(ctx, hipStreamWaitEvent(b->copy_stream, b->chunk_ev[0], 0));
     for (int k = 0; k < parts; k++) {
-        const size_t lo = std::min(n, (size_t)k * chunk), hi = std::min(n, lo + chunk);
+        const size_t lo = bounds[k], hi = bounds[k + 1];
         if (hi > lo)
             ZG_HIP(ctx, hipMemcpyAsync((uint8_t*)b->scalars.p + lo * 32, scalars32 + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice,
                                        b->copy_stream));
         ZG_HIP(ctx, hipEventRecord(b->chunk_ev[k], b->copy_stream));
     }
     if (parts == 1) ZG_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->chunk_ev[0], 0));
-    return msm_resident_run(ctx, b, b->scalars.p, n, dense_hint, parts, parts > 1 ? b->chunk_ev : nullptr, out_jac);
+    return msm_resident_run(ctx, b, b->scalars.p, n, dense_hint, parts, parts > 1 ? b->chunk_ev : nullptr, out_jac,
+                            parts > 1 ? bounds : nullptr);
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -1759,15 +1778,64 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         t.small = small;
         if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
-            const size_t entries = msm_quad_entries(n);
-            if (entries * elem > budget || entries >= (1ull << 31) || t.buf.alloc(entries * elem) != hipSuccess) {
+            // groups of eight positions (255 sums: 2 KB per position) where that fits, else of four (240 B per position);
+            // ZA_AMD_QUAD_W = 4 | 8: experiment switch
+            int qw = 8;
+            if (const char* e = getenv("ZA_AMD_QUAD_W")) qw = atoi(e) == 4 ? 4 : 8;
+            size_t entries = msm_quad_entries(n, qw);
+            if (qw == 8 && (entries * elem > budget || entries >= (1ull << 31))) {
+                qw = 4;
+                entries = msm_quad_entries(n, qw);
+            }
+            // ... and behind the sums a window table over the positions that hold field elements (3 % of a SHA-like circuit,
+            // fixed by the circuit): their digits then share ONE bucket set like a window-table job's -- 16 digits of 16
+            // bits instead of 22 per-window digits of 12 -- gathered from a table 3 % the size of a full one (the full table was
+            // measured slower: gathers over an 8 GB footprint).  ZA_AMD_CW=0: experiment switch.
+            int cw_c = 0, cw_nwin = 0;
+            const bool cw_on = !(getenv("ZA_AMD_CW") && atoi(getenv("ZA_AMD_CW")) == 0);
+            if (cw_on && n_real >= 1024 && budget > entries * elem &&
+                !msm_fbw_plan(n_real, n_real, budget - entries * elem, elem, &cw_c, &cw_nwin))
+                cw_c = cw_nwin = 0;
+            if (!cw_on || n_real < 1024) cw_c = cw_nwin = 0;
+            const size_t cw_entries = (size_t)cw_nwin * n_real;
+            if (entries + cw_entries >= (1ull << 31)) cw_c = cw_nwin = 0;
+            const size_t all_entries = entries + (size_t)cw_nwin * n_real;
+            if (entries * elem > budget || entries >= (1ull << 31) || t.buf.alloc(all_entries * elem) != hipSuccess) {
                 (void)hipGetLastError();
                 continue;
             }
             if (k == 4)
-                ZG_TRY(msm_quad_build_g2(ctx, (const G2Affine*)use[k].bases, n, t.buf.as<G2Affine>()));
+                ZG_TRY(msm_quad_build_g2(ctx, (const G2Affine*)use[k].bases, n, t.buf.as<G2Affine>(), qw));
             else
-                ZG_TRY(msm_quad_build_g1(ctx, (const G1Affine*)use[k].bases, n, t.buf.as<G1Affine>()));
+                ZG_TRY(msm_quad_build_g1(ctx, (const G1Affine*)use[k].bases, n, t.buf.as<G1Affine>(), qw));
+            t.qw = qw;
+            t.cw_c = t.cw_nwin = 0;
+            t.cw_n = t.cw_off = 0;
+            if (cw_nwin && t.rank.alloc(n * 4) == hipSuccess) {
+                // row 0 = the compacted bases themselves, written where the table's first row belongs
+                uint64_t got = 0;
+                int rc;
+                if (k == 4) {
+                    G2Affine* rows = t.buf.as<G2Affine>() + entries;
+                    rc = msm_compact_reals_g2(ctx, (const G2Affine*)use[k].bases, use[k].scalars, use[k].index, n,
+                                              t.rank.as<uint32_t>(), rows, &got);
+                    if (rc == ZG_OK && got == n_real) rc = msm_fbw_build_g2(ctx, rows, n_real, n_real, cw_c, cw_nwin, rows);
+                } else {
+                    G1Affine* rows = t.buf.as<G1Affine>() + entries;
+                    rc = msm_compact_reals_g1(ctx, (const G1Affine*)use[k].bases, use[k].scalars, use[k].index, n,
+                                              t.rank.as<uint32_t>(), rows, &got);
+                    if (rc == ZG_OK && got == n_real) rc = msm_fbw_build_g1(ctx, rows, n_real, n_real, cw_c, cw_nwin, rows);
+                }
+                ZG_TRY(rc);
+                if (got == n_real) {
+                    t.cw_c = cw_c;
+                    t.cw_nwin = cw_nwin;
+                    t.cw_n = (uint32_t)n_real;
+                    t.cw_off = (uint32_t)entries;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
             ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
             t.kind = 1;
             t.n = n;
@@ -1905,6 +1973,14 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         const auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
         if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
             d.quad_table = t.buf.p;
+            d.quad_w = t.qw;
+            if (t.cw_nwin) {
+                d.cw_rank = t.rank.as<uint32_t>();
+                d.cw_off = t.cw_off;
+                d.cw_n = t.cw_n;
+                d.cw_c = t.cw_c;
+                d.cw_nwin = t.cw_nwin;
+            }
         } else if (use[k].n && t.state == 1 && t.n == use[k].n) {
             d.fbw_table = t.buf.p;
             d.fbw_c = t.c;
@@ -1917,6 +1993,8 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
     if (own_classes) ev_wit = nullptr;   // the class kernel was queued just now: gate on "everything so far"
     ctx->witness_gate_armed = false;
+    if (getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0)
+        fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
@@ -2047,13 +2125,17 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
             if (h_split == 1) h_split = 0;
         }
     }
+    static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
+    if (trace) fprintf(stderr, "[za_amd trace] prove_dev: classes queued      +%.3f ms\n", now_ms() - t0);
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split));
+    if (trace) fprintf(stderr, "[za_amd trace] prove_dev: R1CS + H queued     +%.3f ms\n", now_ms() - t0);
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
     ctx->ev_witness = ctx->gate_w;
     ctx->ev_h = ctx->gate_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
     int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form, h_split);
+    if (trace) fprintf(stderr, "[za_amd trace] prove_dev: multiexps done      +%.3f ms\n", now_ms() - t0);
     ctx->ev_witness = ctx->ev_h = nullptr;
     ctx->witness_gate_armed = false;
     ZG_TRY(rc_p);
@@ -2098,6 +2180,8 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     void* d_w = nullptr;
     size_t sent = 0;
     ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
+    if (getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0)
+        fprintf(stderr, "[za_amd trace] zg_prove: witness handed over  +%.3f ms\n", now_ms() - t0);
     int rc = zg_prove_dev(ctx, p, r, d_w, r_le, s_le, proof_out);
     ctx->timings[0] = (double)sent;   // bytes uploaded (the copy is not timed separately: it is in [5])
     ctx->timings[5] = now_ms() - t0;
@@ -2151,14 +2235,15 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
 static int host_pack_threads(const Ctx* ctx) {
     if (ctx->opt_pack_threads > 0) return ctx->opt_pack_threads;   // ZG_OPT_PACK_THREADS
     // Measured on the GPU box (256 hardware threads, shared with other jobs; 134 MB witness).  Alone, the pass takes
-    // 1.37 ms with 4 threads, 0.82 with 8, 0.73 with 16, 0.56 with 32, 1.0 with 64 (the plain upload: 2.34 ms).  Inside
-    // the benchmark loop on a loaded host the order flips -- every thread is one more chance of a late wake-up:
-    // 11.76 ms per proof with 8 threads, 11.81 / 12.06 with 16, 12.19 / 12.31 with 32 (and a 20 ms outlier).  So: 8,
-    // or half of a small host's threads; a host with fewer than 8 hardware threads uploads the array as it is.
+    // 1.37 ms with 4 threads, 0.82 with 8, 0.73 with 16, 0.56 with 32, 1.0 with 64 (the plain upload: 2.34 ms).  While the
+    // pass waited for every worker to check in, more threads meant more chances of a late wake-up on a loaded host (round
+    // 3: 8).  It now returns when the TASKS are done (WorkerPool), and a zg_prove at 2^22 on a host with a load average of
+    // 52 takes 12.93 / 12.07 / 11.84 / 11.91 ms with 4 / 8 / 16 / 32 threads (tools/ab_opt.py, values alternated in one
+    // process): 16, or half of a small host's threads; a host with fewer than 8 hardware threads uploads the array as it is.
     static const int n = [] {
         const unsigned hc = std::thread::hardware_concurrency();
         if (hc < 8) return 0;
-        return (int)std::min<unsigned>(8, hc / 2);
+        return (int)std::min<unsigned>(16, hc / 2);
     }();
     return n;
 }
