@@ -1,4 +1,5 @@
-/* za_amd synthetic workloads -- NOT part of the drop-in boundary.
+/* za_amd synthetic workloads and self-test hooks -- NOT part of the drop-in boundary, and not in the product library:
+ * these symbols live in libza_amd_synth.so (csrc/synth.hip), which links against libza_amd.so.
  *
  * Generators for the benchmark configurations of BASELINE.json / SURVEY.md section 8(d): the za
  * compiler (which would produce the R1CS and witness) and bellman's generate_random_parameters

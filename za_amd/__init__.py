@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ZA_AMD_LIB: another build of the same library (tools/asan_host.sh: host code under ASan / UBSan)
 LIB_PATH = os.environ.get("ZA_AMD_LIB") or os.path.join(_HERE, "libza_amd.so")
+SYNTH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libza_amd_synth.so")
 
 ZG_OK = 0
 ZG_E_ASSIGNMENT_MISSING = 1
@@ -61,6 +62,30 @@ class ZaAmdError(RuntimeError):
 _lib = None
 
 
+class _Libs:
+    """The product library, plus -- looked up only when a name is not the product's -- the scaffolding library
+    libza_amd_synth.so (synthetic workloads and self-test hooks of include/za_amd_synth.h: tests and bench.py only)."""
+
+    def __init__(self, main, synth_path):
+        self.__dict__["main"] = main
+        self.__dict__["_synth_path"] = synth_path
+        self.__dict__["_synth"] = None
+
+    @property
+    def synth(self):
+        if self.__dict__["_synth"] is None:
+            if not os.path.exists(self._synth_path):
+                raise ZaAmdError(-1, "libza_amd_synth.so is missing: build it with `python za_amd/build.py`")
+            self.__dict__["_synth"] = C.CDLL(self._synth_path)
+        return self.__dict__["_synth"]
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self.__dict__["main"], name)
+        except AttributeError:
+            return getattr(self.synth, name)
+
+
 def load_library():
     """Load libza_amd.so; raises if it has not been built (python -m za_amd.build / __graft_entry__.build())."""
     global _lib
@@ -75,7 +100,8 @@ def load_library():
             import torch  # noqa: F401
         except Exception:
             pass
-        lib = C.CDLL(LIB_PATH)
+        main = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        lib = _Libs(main, SYNTH_LIB_PATH)
         lib.zg_strerror.restype = C.c_char_p
         lib.zg_last_error.restype = C.c_char_p
         lib.zg_last_error_thread.restype = C.c_char_p

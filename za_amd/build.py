@@ -10,7 +10,9 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libza_amd.so")
 LIB_ZA2C = os.path.join(HERE, "libza2c.so")     # the outer drop-in boundary: za's C binding symbols (csrc/za2c.cpp)
 DRIVER = os.path.join(HERE, "za-gpu")           # `za setup|prove` shaped command-line driver (csrc/za_gpu_main.cpp)
-SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "prover.hip", "synth.hip", "setup.hip", "pairing.hip", "outer.hip"]
+LIB_SYNTH = os.path.join(HERE, "libza_amd_synth.so")   # synthetic workloads + self-test hooks (include/za_amd_synth.h): NOT the product
+SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "prover.hip", "setup.hip", "pairing.hip", "outer.hip"]
+SYNTH_SOURCES = ["synth.hip"]
 HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "nttd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc"]
@@ -32,7 +34,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [s for s in SOURCES + SYNTH_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     for s in srcs:
@@ -56,12 +58,20 @@ def build(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs if s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # the test / bench scaffolding as a library of its own, on top of the product library's (C++) internals
+    sobjs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs if s in SYNTH_SOURCES]
+    if force or jobs or _stale(LIB_SYNTH, sobjs + [LIB]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_SYNTH] + sobjs + ["-L" + HERE, "-lza_amd",
+               "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("libza_amd_synth link failed:\n%s\n%s" % (r.stdout, r.stderr))
     # libza2c.so (verbose / setup / prove / verify over the C ABI) and the za-gpu driver: plain host C++
     za2c_src = os.path.join(CSRC, "za2c.cpp")
     if force or jobs or _stale(LIB_ZA2C, [za2c_src, LIB, os.path.join(HERE, "..", "include", "za_amd.h")]):

@@ -63,6 +63,9 @@ int fail(Ctx* ctx, int code, const char* fmt, ...);
 // (std::bad_alloc from a container sized by untrusted input, ...) crosses the C boundary.
 int on_exception(Ctx* ctx);
 int live_contexts();   // zg_ctx handles currently alive in this process (prover.hip)
+// prover.hip's host-side witness packer on plain memory (tests: zg_selftest_pack_mt in libza_amd_synth.so)
+int host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
+                       uint8_t* others32, size_t* n_others);
 
 // kernel classes timed by the profiling facility
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,

@@ -2247,15 +2247,12 @@ static int host_pack_threads(const Ctx* ctx) {
     }();
     return n;
 }
-// test hook (include/za_amd_synth.h): the host packer on plain memory, no GPU
-extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
-                                   uint8_t* others32, size_t* n_others) try {
-    if (!witness32 || !classes || !other_index || !others32 || !n_others || threads < 1) return ZG_E_INVALID_ARG;
+// the host packer on plain memory, no GPU: what the test hook zg_selftest_pack_mt (libza_amd_synth.so) calls
+int zg::host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
+                           uint8_t* others32, size_t* n_others) {
     HostPacker hp;
     hp.run(witness32, nv, threads, classes, other_index, others32, n_others, [](const char*) {});
     return ZG_OK;
-} catch (...) {
-    return zg::on_exception(nullptr);
 }
 
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {

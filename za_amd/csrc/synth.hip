@@ -1,6 +1,7 @@
-// Synthetic workloads for bench.py and the full-size parity tests (include/za_amd_synth.h).
-// Not part of the drop-in boundary: stands in for the za compiler's R1CS + witness output and for
-// bellman's generate_random_parameters, which are out of scope this round.
+// Synthetic workloads for bench.py and the full-size parity tests, and the self-test hooks (include/za_amd_synth.h).
+// Not part of the drop-in boundary and not in the product library: this file is libza_amd_synth.so, which links against
+// libza_amd.so and reaches its internals through the C++ symbols of common.h.  Stands in for the za compiler's R1CS +
+// witness output and for bellman's generate_random_parameters.
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -562,6 +563,14 @@ extern "C" int zg_selftest_curve_dev(zg_ctx* ctx, int group, int lanes, int op, 
     return fail(ctx, ZG_E_INVALID_ARG, "selftest: group %d", group);
 } catch (...) {
     return zg::on_exception(ctx);
+}
+// zg_prove's host-side packer (prover.hip HostPacker) on plain memory, no GPU
+extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
+                                   uint8_t* others32, size_t* n_others) try {
+    if (!witness32 || !classes || !other_index || !others32 || !n_others || threads < 1) return ZG_E_INVALID_ARG;
+    return zg::host_pack_for_test(witness32, nv, threads, classes, other_index, others32, n_others);
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 // Parse and validate a bellman Parameters body without a GPU.  counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, consumed.
 // err (nullable) receives the parser's message.
