@@ -188,6 +188,40 @@ def test_witness_to_device_hands_over_like_zg_prove(ctx, opts):
         ctx.witness_to_device(np.zeros(0, dtype=np.uint8))
 
 
+def test_back_to_back_handovers_do_not_share_a_pinned_stage(ctx, opts):
+    """zg_witness_to_device is queued, not waited for: the packed form of the next witness must not be built in pinned
+    bytes whose copy is still in flight.  Hand-overs of two different witnesses alternate without a synchronisation in
+    between (two pinned stages, each reused only behind the event of its last copy); what the device buffer holds at the end,
+    and the proof from it, are the last witness's."""
+    from za_amd import synth
+    opts(za_amd.OPT_PACK_MIN_LOG_N, 16)
+    lg = 18
+    sr = synth.SynthR1CS(lg, 2, 0.97, 0x51)
+    R = sr.load(ctx)
+    nv = sr.n_inputs + sr.n_aux
+    P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 9)
+    w1 = np.array(sr.witness, copy=True)
+    w2 = w1.copy().reshape(-1, 32)
+    w2[5::7, 0] ^= 1           # another 0/1 pattern and ...
+    w2[11::1013, 1:9] = 0x5a   # ... other field elements (still packable: well below 8 %)
+    w2 = w2.reshape(-1)
+    pins = [ctx.host_alloc(32 * nv), ctx.host_alloc(32 * nv)]
+    pins[0][:] = w1
+    pins[1][:] = w2
+    want = [ctx.prove(P, R, pins[k], 3, 5) for k in (0, 1)]
+    assert want[0] != want[1]
+    for rounds in (2, 3, 7):
+        for k in range(rounds):
+            d_w, sent = ctx.witness_to_device(pins[k & 1])
+            assert sent < 32 * nv // 4
+        last = (rounds - 1) & 1
+        assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pins[last])
+        assert ctx.prove_dev(P, R, d_w, 3, 5) == want[last]
+    for p in pins:
+        ctx.host_free(p)
+    P.close(); R.close(); sr.close()
+
+
 def test_zg_prove_falls_back_to_the_plain_upload_while_packing_is_slow(lib_built):
     """The packing pass competes with whatever else runs on the host: two passes in a row slower than their budget (here:
     a budget of zero) and the next proofs hand the witness over unpacked (ZG_OPT_PACK = 2; the default never looks at the
