@@ -197,7 +197,7 @@ def pmc_for(args):
     were taken on: the default one.  Any other workload gets None -- nothing is pasted across workloads."""
     if not (args.workload == "synthetic" and args.log_m == 22 and abs(args.bit_fraction - 0.97) < 1e-9 and args.seed == 0x5A):
         return None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)))
             vi = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_valu_instructions.json" % rnd)))
