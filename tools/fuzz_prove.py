@@ -71,5 +71,35 @@ while time.time() - t0 < budget:
     if not ok:
         sys.exit(1)
     n_ok += 1
+    if rng.random() < 0.35:
+        # a second witness through the SAME key (its tables were built from the first one): some bits become field
+        # elements and some field elements bits / zeros -- the compact window tables' fallback, subset-sum groups with mixed
+        # contents, the packing pass's give-up path.  The system is no longer satisfied; the proof is still a well-defined
+        # group element and the oracle computes the same one.
+        w2 = np.array(sr.witness, copy=True).reshape(-1, 32)
+        nv = w2.shape[0]
+        for _ in range(rng.choice([1, 5, 40, 400])):
+            v = rng.randrange(1, nv)
+            kind = rng.random()
+            if kind < 0.5:
+                w2[v, :31] = np.frombuffer(rng.randbytes(31), dtype=np.uint8); w2[v, 31] = 0
+            elif kind < 0.8:
+                w2[v, :] = 0; w2[v, 0] = rng.choice([0, 1])
+            else:
+                w2[v, :] = 0
+        w2 = w2.reshape(-1)
+        entry2 = rng.choice(["dev", "host"])
+        if entry2 == "dev":
+            d_w2 = ctx.upload(w2)
+            got2 = ctx.prove_dev(P, R, d_w2, r, s)
+            ctx.free(d_w2)
+        else:
+            got2 = ctx.prove(P, R, w2, r, s)
+        exp2 = co.prove(download_params(ctx, P), csr, w2, r, s, threads=32)
+        ok2 = bytes(got2) == bytes(exp2)
+        print("   second witness through the same key, entry %-4s -> %s" % (entry2, "ok" if ok2 else "MISMATCH"), flush=True)
+        if not ok2:
+            sys.exit(1)
+        n_ok += 1
     ctx.free(d_w); P.close(); R.close(); sr.close()
 print("fuzz: %d cases ok" % n_ok)
