@@ -2299,6 +2299,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     if (ctx->opt_pack_pin && !ws.pin_looked_up) {
         ws.pin_cpus = gpu_node_cpus(ctx->device);
         ws.pin_looked_up = true;
+        if (trace) fprintf(stderr, "[za_amd trace] pack workers bound to %zu CPUs of the GPU's NUMA node\n", ws.pin_cpus.size());
     }
     static const std::vector<int> nowhere;
     uint8_t* classes = ws.stage[sk];
