@@ -222,6 +222,53 @@ def test_back_to_back_handovers_do_not_share_a_pinned_stage(ctx, opts):
     P.close(); R.close(); sr.close()
 
 
+def test_head_of_the_witness_goes_over_as_it_is_while_the_rest_is_packed(ctx, opts):
+    """ZG_OPT_PACK_RAW_PERMILLE: the first part of a pinned witness is queued for the copy engine unpacked, the host threads
+    pack the rest meanwhile.  What the device buffer holds is the witness, byte for byte, whatever the split (also when the
+    packed part turns out not to pack after the head is already on its way, and for a witness in pageable memory, which
+    the option leaves alone); the proof is the C oracle's."""
+    from za_amd import synth
+    opts(za_amd.OPT_PACK_MIN_LOG_N, 16)
+    lg = 18
+    sr = synth.SynthR1CS(lg, 2, 0.97, 0x52)
+    R = sr.load(ctx)
+    nv = sr.n_inputs + sr.n_aux
+    P = synth.synth_params(ctx, (1 << lg) - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 9)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    want = co.prove(download_params(ctx, P), csr, sr.witness, 3, 5, threads=8)
+    pin = ctx.host_alloc(32 * nv)
+    pin[:] = sr.witness
+    base = None
+    for permille in (0, 70, 200, 500, 900):
+        opts(za_amd.OPT_PACK_RAW_PERMILLE, permille)
+        d_w, sent = ctx.witness_to_device(pin)
+        assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pin), permille
+        first = (nv * permille // 1000) & ~((1 << 14) - 1)      # whole 2^14-value slices
+        if permille == 0:
+            base = sent
+        else:
+            assert first > 0 and sent > 32 * first and sent < 32 * first + base, (permille, sent, first, base)
+        assert ctx.prove(P, R, pin, 3, 5) == want
+        assert ctx.last_timings()["upload_bytes"] == sent
+    # pageable memory: the option does not apply (that copy would be staged by the thread that packs)
+    opts(za_amd.OPT_PACK_RAW_PERMILLE, 500)
+    d_w, sent = ctx.witness_to_device(np.array(sr.witness, copy=True))
+    assert sent == base
+    assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(sr.witness)
+    # a dense stretch in the packed part: given up after the head was queued, the rest follows as it is
+    w2 = np.array(sr.witness, copy=True).reshape(-1, 32)
+    rng = np.random.default_rng(6)
+    lo = 3 << 16
+    w2[lo:lo + (1 << 16), :31] = np.frombuffer(rng.bytes(31 << 16), dtype=np.uint8).reshape(-1, 31)
+    w2[lo:lo + (1 << 16), 31] = 0
+    pin[:] = w2.reshape(-1)
+    d_w, sent = ctx.witness_to_device(pin)
+    assert sent == 32 * nv
+    assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pin)
+    ctx.host_free(pin)
+    P.close(); R.close(); sr.close()
+
+
 def test_zg_prove_falls_back_to_the_plain_upload_while_packing_is_slow(lib_built):
     """The packing pass competes with whatever else runs on the host: two passes in a row slower than their budget (here:
     a budget of zero) and the next proofs hand the witness over unpacked (ZG_OPT_PACK = 2; the default never looks at the

@@ -36,6 +36,7 @@ struct Ctx {
     int opt_pack_min_log_n = 20;
     bool opt_pack_pin = true;
     int opt_pack_budget_permille = 900;
+    int opt_pack_raw_permille = 200;  // ZG_OPT_PACK_RAW_PERMILLE
     bool opt_h_eval = true;
     unsigned opt_tables = 31;
     uint64_t opt_tables_max_mb = 0;

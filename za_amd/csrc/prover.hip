@@ -339,13 +339,16 @@ struct HostPacker {
     static constexpr size_t SLICE_VALS = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
 
     // pin_cpus: where the worker threads run (empty = wherever the scheduler puts them)
+    // Packs the values [first, nv) (first: a multiple of SLICE_VALS): classes[0] describes value `first`, the listed
+    // indices are positions in the whole array.
     void run(const uint8_t* witness32, size_t nv, int nthreads, uint8_t* classes, uint32_t* idx_out, uint8_t* val_out,
-             size_t* n_others_out, const std::function<void(const char*)>& stamp, const std::vector<int>& pin_cpus = {}) {
+             size_t* n_others_out, const std::function<void(const char*)>& stamp, const std::vector<int>& pin_cpus = {},
+             size_t first = 0) {
         *n_others_out = SIZE_MAX;
         if (!pool || pool->threads() != nthreads || pool->is_pinned() != !pin_cpus.empty())
             pool.reset(new WorkerPool(nthreads - 1, pin_cpus));
-        const int n_slices = (int)((nv + SLICE_VALS - 1) / SLICE_VALS);
-        const size_t max_others = nv / 8;            // beyond 12.5 % the plain upload is as good
+        const int n_slices = (int)((nv - first + SLICE_VALS - 1) / SLICE_VALS);
+        const size_t max_others = (nv - first) / 8;   // beyond 12.5 % the plain upload is as good
         if ((int)slices.size() < n_slices) slices.resize(n_slices);
         std::atomic<size_t> total{0};
         std::atomic<bool> abort{false};
@@ -354,7 +357,7 @@ struct HostPacker {
                 Slice& sl = slices[si];
                 sl.count = 0;
                 if (abort.load(std::memory_order_relaxed)) return;
-                const size_t lo = (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
+                const size_t lo = first + (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
                 const size_t cap = SLICE_VALS / 2;   // a slice denser than 50 % ends the attempt
                 // (the lists grow on demand: sized for 50 % from the start they were 74 MB of zero-filled heap at 2^22, 1.2 GB
                 // at 2^26, for a witness whose slices are 3 % dense)
@@ -384,7 +387,7 @@ struct HostPacker {
                             k++;
                         }
                     }
-                    classes[i >> 2] = (uint8_t)byte;
+                    classes[(i - first) >> 2] = (uint8_t)byte;
                 }
                 sl.count = k;
                 if (total.fetch_add(k) + k > max_others) abort.store(true);
@@ -703,6 +706,10 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
         case ZG_OPT_PACK_BUDGET_PERMILLE:
             if (value < 0 || value > 100000) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_BUDGET_PERMILLE: 0 .. 100000");
             ctx->opt_pack_budget_permille = (int)value;
+            return ZG_OK;
+        case ZG_OPT_PACK_RAW_PERMILLE:
+            if (value < 0 || value > 900) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_RAW_PERMILLE: 0 .. 900");
+            ctx->opt_pack_raw_permille = (int)value;
             return ZG_OK;
         case ZG_OPT_H_EVAL: ctx->opt_h_eval = value != 0; return ZG_OK;
         case ZG_OPT_TABLES:
@@ -2153,7 +2160,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     return zg::on_exception(ctx);
 }
 
-static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent);
+static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent, size_t* first_raw);
 // The device copy of the witness lives in the ctx's workspace (no allocation per proof) and the upload is simply
 // queued in front of the proof's work: everything after it is gated by stream order / the witness event.  From
 // pinned memory (zg_host_alloc) the copy runs at PCIe speed, 32 (l + v) bytes: 134 MB = 2.4 ms at 2^22 -- unless the
@@ -2164,9 +2171,12 @@ static int witness_handover(zg_ctx* ctx, const uint8_t* witness32, size_t nv, vo
     DevBuf& dw = prove_ws(ctx).w;
     ZG_HIP(ctx, dw.reserve(nv * 32));
     bool packed = false;
+    size_t first = 0;   // values already queued as they are by pack_and_upload (see there)
     *sent = nv * 32;
-    ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, sent));
-    if (!packed) ZG_HIP(ctx, hipMemcpyAsync(dw.p, witness32, nv * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, sent, &first));
+    if (!packed && first < nv)
+        ZG_HIP(ctx, hipMemcpyAsync((uint8_t*)dw.p + first * 32, witness32 + first * 32, (nv - first) * 32, hipMemcpyHostToDevice,
+                                   ctx->stream));
     *d_w = dw.p;
     return ZG_OK;
 }
@@ -2206,14 +2216,17 @@ extern "C" int zg_witness_to_device(zg_ctx* ctx, const uint8_t* witness32, size_
 
 // ---- packed witness (see include/za_amd.h)
 // device side: the packed form crosses PCIe, two kernels rebuild the 32-byte array in the ctx's workspace
+// (first > 0: the packed form describes the values [first, nv) only -- classes[0] is value `first`, other_index holds
+// positions in the whole array; the values below `first` are put there by the caller)
 static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const uint32_t* other_index, const uint8_t* others32,
-                         size_t n_others) {
+                         size_t n_others, size_t first = 0) {
     ProveWs& ws = prove_ws(ctx);
+    const size_t np = nv - first;
     ZG_HIP(ctx, ws.w.reserve(nv * 32));
-    ZG_HIP(ctx, ws.pk_cls.reserve((nv + 3) / 4));
-    ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (nv + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), nv,
-                       ws.w.as<Fr>());
+    ZG_HIP(ctx, ws.pk_cls.reserve((np + 3) / 4));
+    ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (np + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), np,
+                       ws.w.as<Fr>() + first);
     if (n_others) {
         ZG_HIP(ctx, ws.pk_idx.reserve(n_others * 4));
         ZG_HIP(ctx, ws.pk_val.reserve(n_others * 32));
@@ -2255,8 +2268,9 @@ int zg::host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uin
     return ZG_OK;
 }
 
-static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent) {
+static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent, size_t* first_raw) {
     *done = false;
+    *first_raw = 0;
     if (ctx->opt_pack == 0) return ZG_OK;   // ZG_OPT_PACK
     const int nthreads = host_pack_threads(ctx);
     // below ~2^20 values (32 MB, 0.6 ms of PCIe) waking the threads costs what the pass saves (ZG_OPT_PACK_MIN_LOG_N)
@@ -2301,18 +2315,38 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         ws.pin_looked_up = true;
         if (trace) fprintf(stderr, "[za_amd trace] pack workers bound to %zu CPUs of the GPU's NUMA node\n", ws.pin_cpus.size());
     }
+    // While the host threads pack, PCIe idles; while the packed form crosses, the threads idle.  So the head of the array
+    // goes over AS IT IS, queued before the pass starts, and only the rest is packed: with the copy engine at ~57 GB/s
+    // and the pass at ~190 GB/s the two finish together when the head is ~1/5 (ZG_OPT_PACK_RAW_PERMILLE; needs a pinned
+    // witness -- a copy from pageable memory is staged by the calling thread, which is the one that packs).
+    size_t first = 0;
+    if (ctx->opt_pack_raw_permille > 0) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, witness32) == hipSuccess && at.type == hipMemoryTypeHost) {
+            first = (size_t)((double)nv * std::min(ctx->opt_pack_raw_permille, 900) / 1000.0) & ~(HostPacker::SLICE_VALS - 1);
+            if (first) {
+                ZG_HIP(ctx, ws.w.reserve(nv * 32));
+                ZG_HIP(ctx, hipMemcpyAsync(ws.w.p, witness32, first * 32, hipMemcpyHostToDevice, ctx->stream));
+                *first_raw = first;
+                stamp("head queued");
+            }
+        } else {
+            (void)hipGetLastError();   // an unregistered pointer is an error to the attribute query, not to us
+        }
+    }
     static const std::vector<int> nowhere;
     uint8_t* classes = ws.stage[sk];
     uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage[sk] + ((cls_bytes + 63) & ~(size_t)63));
     uint8_t* val_out = reinterpret_cast<uint8_t*>(idx_out + max_others);
     size_t n_others = SIZE_MAX;
-    ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp, ctx->opt_pack_pin ? ws.pin_cpus : nowhere);
+    ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp, ctx->opt_pack_pin ? ws.pin_cpus : nowhere,
+                   first);
     if (n_others == SIZE_MAX) {   // not the kind of witness that packs: no point in scanning the next ones either
         ws.pack_skip = 32;
         ws.pack_skip_nv = nv;
         return ZG_OK;
     }
-    ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others));
+    ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others, first));
     ZG_HIP(ctx, hipEventRecord(ws.stage_ev[sk], ctx->stream));
     ws.stage_next = sk ^ 1;
     stamp("queued");
@@ -2336,7 +2370,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         }
     }
     *done = true;
-    *bytes_sent = cls_bytes + n_others * 36;
+    *bytes_sent = first * 32 + (nv - first + 3) / 4 + n_others * 36;
     return ZG_OK;
 }
 
