@@ -269,6 +269,32 @@ def test_head_of_the_witness_goes_over_as_it_is_while_the_rest_is_packed(ctx, op
     P.close(); R.close(); sr.close()
 
 
+@pytest.mark.parametrize("name", ["proof_factor.json", "proof_chain7.json"])
+def test_combination_beside_the_h_multiexp_or_at_the_end(ctx, opts, name):
+    """ZG_OPT_COMBINE_EARLY: A, B and C without its h term are computed by the thread that finishes the last witness
+    multiexp (while h is still on the GPU), or everything at the end -- the golden proof bytes either way, also for r = s = 0
+    (A = alpha + sum a: no scalar multiplication at all) and r = s = the largest scalar; an r beyond the group order is
+    the same refusal in both orders (prover.rs:173 takes Fr values: nothing larger exists there)."""
+    import za_amd
+    fx = golden(name)
+    R, P, w, csr = _load_fixture(ctx, fx)
+    r0, s0 = int(fx["r"], 16), int(fx["s"], 16)
+    pk = download_params(ctx, P)
+    for early in (1, 0, 1):
+        opts(za_amd.OPT_COMBINE_EARLY, early)
+        assert ctx.prove(P, R, w, r0, s0).hex() == fx["proof"]
+        d_w = ctx.upload(w)
+        assert ctx.prove_dev(P, R, d_w, r0, s0).hex() == fx["proof"]
+        ctx.free(d_w)
+        for r, s in ((0, 0), (bn.R - 1, bn.R - 1), (1, 0)):
+            assert ctx.prove(P, R, w, r, s) == co.prove(pk, csr, w, r, s), (early, r, s)
+        for r, s in ((bn.R, 1), (1, bn.R), (2**256 - 1, 3)):
+            with pytest.raises(za_amd.ZaAmdError) as e:
+                ctx.prove(P, R, w, r, s)
+            assert e.value.code == za_amd.ZG_E_BAD_FORMAT, (early, r, s)
+    P.close(); R.close()
+
+
 def test_zg_prove_falls_back_to_the_plain_upload_while_packing_is_slow(lib_built):
     """The packing pass competes with whatever else runs on the host: two passes in a row slower than their budget (here:
     a budget of zero) and the next proofs hand the witness over unpacked (ZG_OPT_PACK = 2; the default never looks at the

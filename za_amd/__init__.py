@@ -133,7 +133,7 @@ def density_bitmap(flags):
 
 # zg_set_option (include/za_amd.h)
 OPT_ONE_SHOT, OPT_PACK, OPT_PACK_THREADS, OPT_PACK_MIN_LOG_N, OPT_PACK_PIN, OPT_H_EVAL, OPT_TABLES, OPT_TABLES_MAX_MB, \
-    OPT_PACK_BUDGET_PERMILLE, OPT_PACK_RAW_PERMILLE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+    OPT_PACK_BUDGET_PERMILLE, OPT_PACK_RAW_PERMILLE, OPT_COMBINE_EARLY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
 class Context:

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -37,6 +38,10 @@ struct Ctx {
     bool opt_pack_pin = true;
     int opt_pack_budget_permille = 900;
     int opt_pack_raw_permille = 200;  // ZG_OPT_PACK_RAW_PERMILLE
+    bool opt_combine_early = true;    // ZG_OPT_COMBINE_EARLY
+    // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
+    // are final and the h job is still running; set and cleared by zg_prove_dev
+    std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
     bool opt_h_eval = true;
     unsigned opt_tables = 31;
     uint64_t opt_tables_max_mb = 0;

@@ -31,6 +31,8 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <atomic>
+#include <functional>
 #include <future>
 
 #include "common.h"
@@ -1490,6 +1492,7 @@ struct MsmJobBase {
     hipEvent_t ev_sorted = nullptr, ev_acc = nullptr;
     bool launched = false;   // phase_b has run (its events are recorded)
     bool eager = false;      // phase_a leaves nothing to wait for (dense jobs): phase_b is queued right behind it
+    bool witness = false;    // one of the proof's witness multiexps (run_jobs' on_witness fires when the last of them is done)
 };
 
 // Which arithmetic the latency-bound kernels of a job run: G1 one lane per point; G2 a lane PAIR per point (ecd.h Fq2PL).
@@ -2009,9 +2012,21 @@ struct MsmJob : MsmJobBase {
 // simply stays in its first phase while the others run ahead.
 // (One host thread per job with blocking waits was measured: 0.6 ms slower per 2^22 proof -- the runtime's launch
 // path serialises the threads, the waits wake late, and the witness accumulations then crowd the first NTT passes.)
-static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
+// on_witness: called once, by the thread that finished the last job marked `witness`, if all of them succeeded
+static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<void()>& on_witness = {}) {
     int state[16] = {0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
     int remaining = njobs;
+    std::atomic<int> w_left{0};
+    std::atomic<bool> w_ok{true};
+    for (int j = 0; j < njobs; j++) w_left += jobs[j]->witness ? 1 : 0;
+    auto finish_job = [&w_left, &w_ok, &on_witness](MsmJobBase* jb) {
+        const int rc = jb->finish();
+        if (jb->witness) {
+            if (rc != ZG_OK) w_ok.store(false);
+            if (w_left.fetch_sub(1) == 1 && w_ok.load() && on_witness) on_witness();
+        }
+        return rc;
+    };
     std::vector<std::future<int>> finishing;   // (a future of std::async joins in its destructor: early returns are safe)
     // ZA_AMD_TRACE=1: host timestamps (ms since entry) of every phase transition of every job, to stderr
     static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
@@ -2076,9 +2091,9 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs) {
                 // host passes one after the other (0.35 ms each at 2^14).
                 if (remaining > 1) {
                     MsmJobBase* jb = jobs[j];
-                    finishing.push_back(std::async(std::launch::async, [jb] { return jb->finish(); }));
+                    finishing.push_back(std::async(std::launch::async, [jb, &finish_job] { return finish_job(jb); }));
                 } else {
-                    ZG_TRY(jobs[j]->finish());
+                    ZG_TRY(finish_job(jobs[j]));
                 }
                 stamp(j, "finish", tb);
                 remaining--;
@@ -2215,6 +2230,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     std::unique_ptr<MsmJob<Fq2>> wj2;
     for (int q = 0; q < 3; q++) wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);
     wj2 = make_range_job<Fq2>(ctx, w_slot[3], *wq[3], 0, wq[3]->n, out2);
+    for (int q = 0; q < 3; q++) wj1[q]->witness = true;
+    wj2->witness = true;
     // h parts
     G1XYZZ hout[HP];
     std::unique_ptr<MsmJob<Fq>> hp[HP];
@@ -2257,7 +2274,9 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     if (small)   // second: queueing a job takes the host ~80 us, and the NTT pipeline of a small proof is done in 0.3 ms
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
     for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q].get();
-    ZG_TRY(run_jobs(ctx, jobs, nj));
+    std::function<void()> on_witness;
+    if (ctx->witness_hook) on_witness = [&] { ctx->witness_hook(out1, out2); };
+    ZG_TRY(run_jobs(ctx, jobs, nj, on_witness));
     G1XYZZ h = hout[0];
     for (int k = 1; k < parts; k++) h = h.add(hout[k]);
     out1[0] = h;

@@ -711,6 +711,7 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             if (value < 0 || value > 900) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PACK_RAW_PERMILLE: 0 .. 900");
             ctx->opt_pack_raw_permille = (int)value;
             return ZG_OK;
+        case ZG_OPT_COMBINE_EARLY: ctx->opt_combine_early = value != 0; return ZG_OK;
         case ZG_OPT_H_EVAL: ctx->opt_h_eval = value != 0; return ZG_OK;
         case ZG_OPT_TABLES:
             if (value < 0 || value > 31) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_TABLES: a mask over five queries");
@@ -2041,47 +2042,69 @@ static G1XYZZ straus3(const G1XYZZ pts[3], const uint32_t* const k[3]) {
     return acc;
 }
 
-extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world,
-                                const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
-    if (!ctx || !p || !partials_all || world < 1 || !r_le || !s_le || !proof_out) return ZG_E_INVALID_ARG;
+// The part of the combination that needs the witness sums only (everything but "+ sum h"): A and B in affine form and
+// C without its h term.  zg_prove_dev runs it while the h multiexp is still on the GPU (Ctx::witness_hook).
+struct CombineEarly {
+    bool done = false;
+    G1Affine A;
+    G2Affine B;
+    G1XYZZ c_part;
+};
+static bool combine_scalars(const uint8_t r_le[32], const uint8_t s_le[32], uint32_t r[8], uint32_t s[8], uint32_t rs[8]) {
+    scalar_words(r, r_le);
+    scalar_words(s, s_le);
+    if (!scalar_is_canonical(r) || !scalar_is_canonical(s)) return false;
+    Fr fr_r, fr_s;
+    memcpy(&fr_r, r, 32);
+    memcpy(&fr_s, s, 32);
+    Fr prod = (fr_r.to_mont() * fr_s.to_mont()).from_mont();
+    memcpy(rs, &prod, 32);
+    return true;
+}
+static void combine_witness_part(const zg_params* p, const uint32_t r[8], const uint32_t s[8], const uint32_t rs[8],
+                                 const G1XYZZ& l_acc, const G1XYZZ& a_ans, const G1XYZZ& b1_ans, const G2XYZZ& b2_ans,
+                                 CombineEarly* out) {
+    const G1XYZZ delta1 = G1XYZZ::from_affine(p->delta_g1), alpha = G1XYZZ::from_affine(p->alpha_g1),
+                 beta1 = G1XYZZ::from_affine(p->beta_g1);
+    const G2XYZZ delta2 = G2XYZZ::from_affine(p->delta_g2);
+    // B = beta2 + s*delta2 + sum b2: the one G2 multiplication (about 3 G1 ones) runs on a helper thread
+    std::thread tb([&] { out->B = delta2.mul(s).add_mixed(p->beta_g2).add(b2_ans).to_affine(); });
+    // A = alpha + r*delta + sum a
+    out->A = delta1.mul(r).add_mixed(p->alpha_g1).add(a_ans).to_affine();
+    // C = s*(alpha + sum a) + r*(beta1 + sum b1) + rs*delta + sum l + sum h (the last term is the caller's)
+    const G1XYZZ pts[3] = {alpha.add(a_ans), beta1.add(b1_ans), delta1};
+    const uint32_t* const ks[3] = {s, r, rs};
+    out->c_part = straus3(pts, ks).add(l_acc);
+    tb.join();
+    out->done = true;
+}
+
+static int combine_impl(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world, const uint8_t r_le[32],
+                        const uint8_t s_le[32], uint8_t proof_out[256], const CombineEarly* early) {
     double t0 = now_ms();
     G1XYZZ h_acc = G1XYZZ::inf(), l_acc = G1XYZZ::inf(), a_ans = G1XYZZ::inf(), b1_ans = G1XYZZ::inf();
     G2XYZZ b2_ans = G2XYZZ::inf();
     for (int k = 0; k < world; k++) {
         const uint8_t* q = partials_all + (size_t)k * ZG_PARTIALS_BYTES;
         h_acc = h_acc.add(jac_from_bytes<Fq>(q));
+        if (early && early->done) continue;
         l_acc = l_acc.add(jac_from_bytes<Fq>(q + 96));
         a_ans = a_ans.add(jac_from_bytes<Fq>(q + 192));
         b1_ans = b1_ans.add(jac_from_bytes<Fq>(q + 288));
         b2_ans = b2_ans.add(jac_from_bytes<Fq2>(q + 384));
     }
-    if (p->delta_g1.is_inf() || p->delta_g2.is_inf()) return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "vk.delta is the identity");
-    uint32_t r[8], s[8], rs[8];
-    scalar_words(r, r_le);
-    scalar_words(s, s_le);
-    if (!scalar_is_canonical(r) || !scalar_is_canonical(s))
-        return fail(ctx, ZG_E_BAD_FORMAT, "r and s must be canonical scalars (< the group order)");
-    {
-        Fr fr_r, fr_s;
-        memcpy(&fr_r, r, 32);
-        memcpy(&fr_s, s, 32);
-        Fr prod = (fr_r.to_mont() * fr_s.to_mont()).from_mont();
-        memcpy(rs, &prod, 32);
+    CombineEarly own;
+    if (!(early && early->done)) {
+        if (p->delta_g1.is_inf() || p->delta_g2.is_inf()) return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "vk.delta is the identity");
+        uint32_t r[8], s[8], rs[8];
+        if (!combine_scalars(r_le, s_le, r, s, rs))
+            return fail(ctx, ZG_E_BAD_FORMAT, "r and s must be canonical scalars (< the group order)");
+        combine_witness_part(p, r, s, rs, l_acc, a_ans, b1_ans, b2_ans, &own);
+        early = &own;
     }
-    const G1XYZZ delta1 = G1XYZZ::from_affine(p->delta_g1), alpha = G1XYZZ::from_affine(p->alpha_g1),
-                 beta1 = G1XYZZ::from_affine(p->beta_g1);
-    const G2XYZZ delta2 = G2XYZZ::from_affine(p->delta_g2);
-    // B = beta2 + s*delta2 + sum b2: the one G2 multiplication (about 3 G1 ones) runs on a helper thread
-    G2Affine B;
-    std::thread tb([&] { B = delta2.mul(s).add_mixed(p->beta_g2).add(b2_ans).to_affine(); });
-    // A = alpha + r*delta + sum a
-    G1XYZZ g_a = delta1.mul(r).add_mixed(p->alpha_g1).add(a_ans);
-    // C = s*(alpha + sum a) + r*(beta1 + sum b1) + rs*delta + sum h + sum l
-    const G1XYZZ pts[3] = {alpha.add(a_ans), beta1.add(b1_ans), delta1};
-    const uint32_t* const ks[3] = {s, r, rs};
-    G1XYZZ g_c = straus3(pts, ks).add(h_acc).add(l_acc);
-    G1Affine A = g_a.to_affine(), C = g_c.to_affine();
-    tb.join();
+    const G1Affine& A = early->A;
+    const G2Affine& B = early->B;
+    const G1Affine C = early->c_part.add(h_acc).to_affine();
     if (A.is_inf() || B.is_inf() || C.is_inf())
         return fail(ctx, ZG_E_UNEXPECTED_IDENTITY, "a proof element is the identity (BadFormat(\"invalid point\") in za)");
     fq_to_be(proof_out, A.x); fq_to_be(proof_out + 32, A.y);
@@ -2090,6 +2113,11 @@ extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* 
     fq_to_be(proof_out + 192, C.x); fq_to_be(proof_out + 224, C.y);
     ctx->timings[4] = now_ms() - t0;
     return ZG_OK;
+}
+extern "C" int zg_prove_combine(zg_ctx* ctx, const zg_params* p, const uint8_t* partials_all, int world,
+                                const uint8_t r_le[32], const uint8_t s_le[32], uint8_t proof_out[256]) try {
+    if (!ctx || !p || !partials_all || world < 1 || !r_le || !s_le || !proof_out) return ZG_E_INVALID_ARG;
+    return combine_impl(ctx, p, partials_all, world, r_le, s_le, proof_out, nullptr);
 } catch (...) {
     return zg::on_exception(ctx);
 }
@@ -2141,7 +2169,27 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ctx->ev_witness = ctx->gate_w;
     ctx->ev_h = ctx->gate_h;
     uint8_t partials[ZG_PARTIALS_BYTES];
+    // The combination's witness part (two scalar multiplications in G1, one in G2, Straus: 0.16 ms of host time) runs on the
+    // thread that finishes the last witness multiexp, while the h multiexp is still on the GPU; only "+ sum h" and one
+    // inversion are left for the end.  Whatever it cannot do (vk.delta at infinity, r or s out of range) is left to the
+    // full combination below, which reports it.
+    CombineEarly early;
+    struct HookGuard {
+        Ctx* c;
+        ~HookGuard() { c->witness_hook = nullptr; }
+    } hook_guard{ctx};
+    if (ctx->opt_combine_early)
+        ctx->witness_hook = [&](const G1XYZZ* g1, const G2XYZZ* g2) {
+            try {
+                uint32_t rw[8], sw[8], rsw[8];
+                if (p->delta_g1.is_inf() || p->delta_g2.is_inf() || !combine_scalars(r_le, s_le, rw, sw, rsw)) return;
+                combine_witness_part(p, rw, sw, rsw, g1[1], g1[2], g1[3], *g2, &early);
+            } catch (...) {
+                early.done = false;
+            }
+        };
     int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form, h_split);
+    ctx->witness_hook = nullptr;
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: multiexps done      +%.3f ms\n", now_ms() - t0);
     ctx->ev_witness = ctx->ev_h = nullptr;
     ctx->witness_gate_armed = false;
@@ -2153,7 +2201,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
         ctx->timings[1] = ms_eval;
         ctx->timings[2] = ms_h;
     }
-    ZG_TRY(zg_prove_combine(ctx, p, partials, 1, r_le, s_le, proof_out));
+    ZG_TRY(combine_impl(ctx, p, partials, 1, r_le, s_le, proof_out, &early));
     ctx->timings[5] = now_ms() - t0;
     return ZG_OK;
 } catch (...) {
