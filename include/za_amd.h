@@ -92,7 +92,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
 #define ZG_OPT_TABLES_MAX_MB 8
 #define ZG_OPT_PACK_BUDGET_PERMILLE 9   /* ZG_OPT_PACK = 2: the share of the plain copy's time the pass may take (default 900) */
 #define ZG_OPT_COMBINE_EARLY 11        /* 1 (default): the witness part of the combination runs beside the h multiexp; 0: all of it at the end */
-#define ZG_OPT_PACK_RAW_PERMILLE 10     /* the head of a pinned witness that goes over as it is while the rest is packed, in 1/1000 (default 200; 0 = none) */
+#define ZG_OPT_PACK_RAW_PERMILLE 10     /* largest share of a pinned witness the copy engine may take as it is while the threads pack the rest, in 1/1000 (default 400; 0 = none) */
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 

@@ -143,7 +143,7 @@ def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx, opts):
         pin[:] = sr.witness
         assert ctx.prove(P, R, pin, 11, 13) == want
         sent = ctx.last_timings()["upload_bytes"]
-        assert (sent < 32 * nv / 4) == expect_packed, (lg, bits, sent, 32 * nv)
+        assert (sent < 32 * nv / 2) == expect_packed, (lg, bits, sent, 32 * nv)
         d_w = ctx.upload(sr.witness)
         assert ctx.prove_dev(P, R, d_w, 11, 13) == want
         ctx.free(d_w)
@@ -179,7 +179,7 @@ def test_witness_to_device_hands_over_like_zg_prove(ctx, opts):
         pin[:] = sr.witness
         want = ctx.prove(P, R, pin, 9, 10)
         d_w, sent = ctx.witness_to_device(pin)
-        assert (sent < 32 * nv // 4) == (bits > 0.9), (bits, sent)
+        assert (sent < 32 * nv // 2) == (bits > 0.9), (bits, sent)
         assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(sr.witness)
         assert ctx.prove_dev(P, R, d_w, 9, 10) == want
         ctx.host_free(pin)
@@ -213,7 +213,7 @@ def test_back_to_back_handovers_do_not_share_a_pinned_stage(ctx, opts):
     for rounds in (2, 3, 7):
         for k in range(rounds):
             d_w, sent = ctx.witness_to_device(pins[k & 1])
-            assert sent < 32 * nv // 4
+            assert sent < 32 * nv // 2
         last = (rounds - 1) & 1
         assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pins[last])
         assert ctx.prove_dev(P, R, d_w, 3, 5) == want[last]
@@ -222,11 +222,12 @@ def test_back_to_back_handovers_do_not_share_a_pinned_stage(ctx, opts):
     P.close(); R.close(); sr.close()
 
 
-def test_head_of_the_witness_goes_over_as_it_is_while_the_rest_is_packed(ctx, opts):
-    """ZG_OPT_PACK_RAW_PERMILLE: the first part of a pinned witness is queued for the copy engine unpacked, the host threads
-    pack the rest meanwhile.  What the device buffer holds is the witness, byte for byte, whatever the split (also when the
-    packed part turns out not to pack after the head is already on its way, and for a witness in pageable memory, which
-    the option leaves alone); the proof is the C oracle's."""
+def test_copy_engine_and_packing_threads_share_the_witness(ctx, opts):
+    """The hand-over of a pinned, bit-heavy witness: the copy engine takes the array as it is from the front, piece by
+    piece, while the host threads pack it from the back, until the two meet (ZG_OPT_PACK_RAW_PERMILLE caps the copier's
+    share; where they meet depends on the host's load, so only bounds are checked).  What the device buffer holds is the
+    witness, byte for byte, whatever the split -- also when the packed part turns out not to pack after pieces are already
+    on their way, and for a witness in pageable memory, which is packed whole; the proof is the C oracle's."""
     from za_amd import synth
     opts(za_amd.OPT_PACK_MIN_LOG_N, 16)
     lg = 18
@@ -239,23 +240,25 @@ def test_head_of_the_witness_goes_over_as_it_is_while_the_rest_is_packed(ctx, op
     pin = ctx.host_alloc(32 * nv)
     pin[:] = sr.witness
     base = None
-    for permille in (0, 70, 200, 500, 900):
+    for permille in (0, 70, 200, 500, 900, 0):
         opts(za_amd.OPT_PACK_RAW_PERMILLE, permille)
-        d_w, sent = ctx.witness_to_device(pin)
-        assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pin), permille
-        first = (nv * permille // 1000) & ~((1 << 14) - 1)      # whole 2^14-value slices
-        if permille == 0:
-            base = sent
-        else:
-            assert first > 0 and sent > 32 * first and sent < 32 * first + base, (permille, sent, first, base)
+        for _ in range(3):
+            d_w, sent = ctx.witness_to_device(pin)
+            assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(pin), permille
+            cap = (nv * permille // 1000) & ~((1 << 14) - 1)      # the copier takes whole 2^14-value slices
+            if permille == 0:
+                assert base in (None, sent)
+                base = sent
+            else:
+                assert base - cap // 4 - 36 * (cap // 8) <= sent <= 32 * cap + base, (permille, sent, cap, base)
         assert ctx.prove(P, R, pin, 3, 5) == want
-        assert ctx.last_timings()["upload_bytes"] == sent
-    # pageable memory: the option does not apply (that copy would be staged by the thread that packs)
+    # pageable memory: packed whole (that copy would be staged by the thread that feeds the copy engine)
     opts(za_amd.OPT_PACK_RAW_PERMILLE, 500)
     d_w, sent = ctx.witness_to_device(np.array(sr.witness, copy=True))
     assert sent == base
     assert bytes(ctx.d2h(d_w, 32 * nv)) == bytes(sr.witness)
-    # a dense stretch in the packed part: given up after the head was queued, the rest follows as it is
+    # a dense stretch near the end, where the packing threads start: given up with pieces already queued, the rest
+    # follows as it is
     w2 = np.array(sr.witness, copy=True).reshape(-1, 32)
     rng = np.random.default_rng(6)
     lo = 3 << 16
@@ -317,7 +320,7 @@ def test_zg_prove_falls_back_to_the_plain_upload_while_packing_is_slow(lib_built
         sent.append(int(ctx.last_timings()["upload_bytes"]))
     assert len(set(proofs)) == 1
     # (the first pass into each of the two pinned stages allocates and is not judged; the next two are over budget)
-    assert all(b < 32 * nv // 4 for b in sent[:4]) and sent[4] == sent[5] == 32 * nv, sent
+    assert all(b < 32 * nv // 2 for b in sent[:4]) and sent[4] == sent[5] == 32 * nv, sent
     d_w = ctx.upload(sr.witness)
     assert bytes(ctx.prove_dev(P, R, d_w, 3, 4)) == proofs[0]
     ctx.free(d_w); ctx.host_free(pin)

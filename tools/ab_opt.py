@@ -10,6 +10,9 @@ lg = int(sys.argv[3]) if len(sys.argv) > 3 else 22
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 proofs = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 ctx = za_amd.Context(0)
+for kv in os.environ.get("ZA_AB_PRESET", "").split(","):   # other options held fixed: ZA_AB_PRESET="3=4,5=0"
+    if kv:
+        ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
 sr = synth.SynthR1CS(lg, 2, 0.97, 0x5A)
 R = sr.load(ctx)
 P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]

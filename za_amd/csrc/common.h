@@ -37,7 +37,7 @@ struct Ctx {
     int opt_pack_min_log_n = 20;
     bool opt_pack_pin = true;
     int opt_pack_budget_permille = 900;
-    int opt_pack_raw_permille = 200;  // ZG_OPT_PACK_RAW_PERMILLE
+    int opt_pack_raw_permille = 400;  // ZG_OPT_PACK_RAW_PERMILLE
     bool opt_combine_early = true;    // ZG_OPT_COMBINE_EARLY
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev

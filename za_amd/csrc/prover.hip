@@ -206,7 +206,8 @@ public:
     }
     int threads() const { return (int)th.size() + 1; }
     bool is_pinned() const { return pinned; }
-    void parallel_for(int n_tasks, const std::function<void(int)>& f) {
+    // lead: run by the calling thread once the workers have been woken, before it takes tasks itself
+    void parallel_for(int n_tasks, const std::function<void(int)>& f, const std::function<void()>* lead = nullptr) {
         if (n_tasks <= 0) return;
         uint32_t g;
         {
@@ -218,6 +219,7 @@ public:
             next.store((uint64_t)g << 32, std::memory_order_release);
         }
         cv.notify_all();
+        if (lead) (*lead)();
         run(g, &f, n_tasks);
         // what is left are the tasks other threads are in the middle of: microseconds
         for (int spin = 0; spin < 200000 && done.load(std::memory_order_acquire) != n_tasks; spin++) {
@@ -339,25 +341,59 @@ struct HostPacker {
     static constexpr size_t SLICE_VALS = (size_t)1 << 14;   // 512 KiB of witness per task: 256 tasks at 2^22, handed out dynamically
 
     // pin_cpus: where the worker threads run (empty = wherever the scheduler puts them)
-    // Packs the values [first, nv) (first: a multiple of SLICE_VALS): classes[0] describes value `first`, the listed
-    // indices are positions in the whole array.
+    // What the copy engine does meanwhile (pack_and_upload): ready() = it can take another piece now, submit(lo, n) queues
+    // the values [lo, lo + n) as they are.  The array is consumed from both ends: the copier takes pieces from the front,
+    // the packing threads slices from the back, until they meet -- whichever is faster on this host at this moment gets
+    // the larger share, and both are done at the same time.
+    struct RawCopier {
+        std::function<bool()> ready;
+        std::function<bool(size_t, size_t)> submit;
+        size_t max_vals = 0;   // the copier's largest share
+    };
+    // Packs the values [*first_out, nv): classes[i >> 2] describes value i (absolute positions, also in the index list);
+    // *first_out = 0 without a copier, else the (SLICE_VALS-aligned) number of values the copier took.  A witness that is
+    // not of the packing kind: *n_others_out = SIZE_MAX (what the copier has taken by then stays taken).
     void run(const uint8_t* witness32, size_t nv, int nthreads, uint8_t* classes, uint32_t* idx_out, uint8_t* val_out,
              size_t* n_others_out, const std::function<void(const char*)>& stamp, const std::vector<int>& pin_cpus = {},
-             size_t first = 0) {
+             const RawCopier* copier = nullptr, size_t* first_out = nullptr) {
         *n_others_out = SIZE_MAX;
+        if (first_out) *first_out = 0;
         if (!pool || pool->threads() != nthreads || pool->is_pinned() != !pin_cpus.empty())
             pool.reset(new WorkerPool(nthreads - 1, pin_cpus));
-        const int n_slices = (int)((nv - first + SLICE_VALS - 1) / SLICE_VALS);
-        const size_t max_others = (nv - first) / 8;   // beyond 12.5 % the plain upload is as good
+        const int n_slices = (int)((nv + SLICE_VALS - 1) / SLICE_VALS);
+        const size_t max_others = nv / 8;   // beyond 12.5 % the plain upload is as good
         if ((int)slices.size() < n_slices) slices.resize(n_slices);
         std::atomic<size_t> total{0};
         std::atomic<bool> abort{false};
-        pool->parallel_for(n_slices, [&](int si) {
+        std::atomic<uint64_t> range{(uint64_t)(uint32_t)n_slices};   // lo << 32 | hi: the slices [lo, hi) are nobody's yet
+        auto take_back = [&]() -> int {
+            uint64_t v = range.load(std::memory_order_acquire);
+            for (;;) {
+                const uint32_t lo = (uint32_t)(v >> 32), hi = (uint32_t)v;
+                if (lo >= hi) return -1;
+                if (range.compare_exchange_weak(v, v - 1, std::memory_order_acq_rel)) return (int)hi - 1;
+            }
+        };
+        auto take_front = [&](uint32_t want, uint32_t limit, uint32_t* lo_out) -> uint32_t {
+            uint64_t v = range.load(std::memory_order_acquire);
+            for (;;) {
+                const uint32_t lo = (uint32_t)(v >> 32), hi = (uint32_t)v;
+                if (lo >= hi || lo >= limit) return 0;
+                const uint32_t k = std::min(want, std::min(hi, limit) - lo);
+                if (range.compare_exchange_weak(v, v + ((uint64_t)k << 32), std::memory_order_acq_rel)) {
+                    *lo_out = lo;
+                    return k;
+                }
+            }
+        };
+        const std::function<void(int)> pack_one = [&](int) {
             try {   // (a worker thread must not let an exception escape: std::bad_alloc from the slice's lists ends the attempt)
+                if (abort.load(std::memory_order_relaxed)) return;
+                const int si = take_back();
+                if (si < 0) return;
                 Slice& sl = slices[si];
                 sl.count = 0;
-                if (abort.load(std::memory_order_relaxed)) return;
-                const size_t lo = first + (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
+                const size_t lo = (size_t)si * SLICE_VALS, hi = std::min(nv, lo + SLICE_VALS);
                 const size_t cap = SLICE_VALS / 2;   // a slice denser than 50 % ends the attempt
                 // (the lists grow on demand: sized for 50 % from the start they were 74 MB of zero-filled heap at 2^22, 1.2 GB
                 // at 2^26, for a witness whose slices are 3 % dense)
@@ -387,24 +423,53 @@ struct HostPacker {
                             k++;
                         }
                     }
-                    classes[(i - first) >> 2] = (uint8_t)byte;
+                    classes[i >> 2] = (uint8_t)byte;
                 }
                 sl.count = k;
                 if (total.fetch_add(k) + k > max_others) abort.store(true);
             } catch (...) {
                 abort.store(true);
             }
-        });
+        };
+        // the calling thread feeds the copy engine (pieces of ~4 MB, two in flight) until the two ends meet, then packs too
+        const uint32_t piece = (uint32_t)std::min(8, std::max(1, n_slices / 32));
+        const uint32_t limit = copier ? (uint32_t)(copier->max_vals / SLICE_VALS) : 0u;
+        const std::function<void()> feed = [&] {
+            while (!abort.load(std::memory_order_relaxed)) {
+                if (!copier->ready()) {
+                    if ((uint32_t)(range.load(std::memory_order_acquire) >> 32) >= limit) break;
+                    const uint64_t v = range.load(std::memory_order_acquire);
+                    if ((uint32_t)(v >> 32) >= (uint32_t)v) break;
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                    continue;
+                }
+                uint32_t lo = 0;
+                const uint32_t k = take_front(piece, limit, &lo);
+                if (!k) break;
+                const size_t v0 = (size_t)lo * SLICE_VALS, v1 = std::min(nv, (size_t)(lo + k) * SLICE_VALS);
+                if (!copier->submit(v0, v1 - v0)) {
+                    abort.store(true);
+                    break;
+                }
+            }
+        };
+        pool->parallel_for(n_slices, pack_one, copier && limit ? &feed : nullptr);
+        const uint32_t first_slice = (uint32_t)(range.load() >> 32);   // (after an abort: slices [lo, hi) were never taken)
+        const size_t first = std::min(nv, (size_t)first_slice * SLICE_VALS);
+        if (first_out) *first_out = first;
         stamp("scan");
         if (abort.load()) return;
         size_t n_others = 0;
-        for (int si = 0; si < n_slices; si++) {
+        for (int si = (int)first_slice; si < n_slices; si++) {
             slices[si].offset = n_others;
             n_others += slices[si].count;
         }
         if (n_others > max_others) return;
-        pool->parallel_for(n_slices, [&](int si) {   // the slices' lists, back to back, into the (pinned) staging buffer
-            const Slice& sl = slices[si];
+        const int n_packed = n_slices - (int)first_slice;
+        pool->parallel_for(n_packed, [&](int k) {   // the slices' lists, back to back, into the (pinned) staging buffer
+            const Slice& sl = slices[first_slice + k];
             if (!sl.count) return;
             memcpy(idx_out + sl.offset, sl.idx.data(), sl.count * 4);
             memcpy(val_out + 32 * sl.offset, sl.val.data(), sl.count * 32);
@@ -428,6 +493,7 @@ struct ProveWs {
     uint8_t* stage[2] = {nullptr, nullptr};
     size_t stage_bytes[2] = {0, 0};
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipEvent_t dma_ev[2] = {nullptr, nullptr};   // behind the last two raw pieces of the hand-over in progress
     int stage_next = 0;
     std::vector<int> pin_cpus;   // the GPU's NUMA node (ZG_OPT_PACK_PIN), looked up once
     bool pin_looked_up = false;
@@ -447,6 +513,7 @@ struct ProveWs {
         for (int k = 0; k < 2; k++) {
             if (stage[k]) (void)hipHostFree(stage[k]);
             if (stage_ev[k]) (void)hipEventDestroy(stage_ev[k]);
+            if (dma_ev[k]) (void)hipEventDestroy(dma_ev[k]);
         }
         if (bad_host) (void)hipHostFree(bad_host);
         if (bad_ev) (void)hipEventDestroy(bad_ev);
@@ -2273,6 +2340,7 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
     ZG_HIP(ctx, ws.w.reserve(nv * 32));
     ZG_HIP(ctx, ws.pk_cls.reserve((np + 3) / 4));
     ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (np + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
+    if (np == 0) return ZG_OK;
     hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), np,
                        ws.w.as<Fr>() + first);
     if (n_others) {
@@ -2363,21 +2431,42 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         ws.pin_looked_up = true;
         if (trace) fprintf(stderr, "[za_amd trace] pack workers bound to %zu CPUs of the GPU's NUMA node\n", ws.pin_cpus.size());
     }
-    // While the host threads pack, PCIe idles; while the packed form crosses, the threads idle.  So the head of the array
-    // goes over AS IT IS, queued before the pass starts, and only the rest is packed: with the copy engine at ~57 GB/s
-    // and the pass at ~190 GB/s the two finish together when the head is ~1/5 (ZG_OPT_PACK_RAW_PERMILLE; needs a pinned
-    // witness -- a copy from pageable memory is staged by the calling thread, which is the one that packs).
-    size_t first = 0;
+    // While the host threads pack, PCIe idles; while the packed form crosses, the threads idle.  So the copy engine takes
+    // the array AS IT IS from the front, piece by piece, while the threads pack it from the back, until the two meet
+    // (HostPacker::RawCopier): with the link at ~57 GB/s and the pass at ~190 GB/s the copier ends up with a fifth to a
+    // quarter on a quiet host and with more on a loaded one.  ZG_OPT_PACK_RAW_PERMILLE caps its share (0 = everything
+    // is packed).  Needs a pinned witness: a copy from pageable memory is staged by the calling thread.
+    HostPacker::RawCopier copier;
+    struct {
+        int inflight = 0, oldest = 0;
+        hipError_t err = hipSuccess;
+    } dma;
+    bool use_copier = false;
     if (ctx->opt_pack_raw_permille > 0) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, witness32) == hipSuccess && at.type == hipMemoryTypeHost) {
-            first = (size_t)((double)nv * std::min(ctx->opt_pack_raw_permille, 900) / 1000.0) & ~(HostPacker::SLICE_VALS - 1);
-            if (first) {
-                ZG_HIP(ctx, ws.w.reserve(nv * 32));
-                ZG_HIP(ctx, hipMemcpyAsync(ws.w.p, witness32, first * 32, hipMemcpyHostToDevice, ctx->stream));
-                *first_raw = first;
-                stamp("head queued");
-            }
+            use_copier = true;
+            ZG_HIP(ctx, ws.w.reserve(nv * 32));
+            for (int k = 0; k < 2; k++)
+                if (!ws.dma_ev[k]) ZG_HIP(ctx, hipEventCreateWithFlags(&ws.dma_ev[k], hipEventDisableTiming));
+            copier.max_vals = (size_t)((double)nv * std::min(ctx->opt_pack_raw_permille, 900) / 1000.0);
+            copier.ready = [&]() -> bool {
+                if (dma.inflight < 2) return true;
+                const hipError_t q = hipEventQuery(ws.dma_ev[dma.oldest]);
+                if (q == hipErrorNotReady) return false;
+                if (q != hipSuccess) dma.err = q;   // (submit reports it)
+                dma.inflight--;
+                dma.oldest ^= 1;
+                return true;
+            };
+            copier.submit = [&](size_t v0, size_t n) -> bool {
+                if (dma.err != hipSuccess) return false;
+                dma.err = hipMemcpyAsync((uint8_t*)ws.w.p + v0 * 32, witness32 + v0 * 32, n * 32, hipMemcpyHostToDevice, ctx->stream);
+                if (dma.err != hipSuccess) return false;
+                dma.err = hipEventRecord(ws.dma_ev[(dma.oldest + dma.inflight) & 1], ctx->stream);
+                dma.inflight++;
+                return dma.err == hipSuccess;
+            };
         } else {
             (void)hipGetLastError();   // an unregistered pointer is an error to the attribute query, not to us
         }
@@ -2386,15 +2475,18 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     uint8_t* classes = ws.stage[sk];
     uint32_t* idx_out = reinterpret_cast<uint32_t*>(ws.stage[sk] + ((cls_bytes + 63) & ~(size_t)63));
     uint8_t* val_out = reinterpret_cast<uint8_t*>(idx_out + max_others);
-    size_t n_others = SIZE_MAX;
+    size_t n_others = SIZE_MAX, first = 0;
     ws.packer->run(witness32, nv, nthreads, classes, idx_out, val_out, &n_others, stamp, ctx->opt_pack_pin ? ws.pin_cpus : nowhere,
-                   first);
+                   use_copier ? &copier : nullptr, &first);
+    (void)hipGetLastError();   // (hipEventQuery's "not ready")
+    *first_raw = first;
+    if (dma.err != hipSuccess) return fail(ctx, ZG_E_HIP, "witness hand-over: %s", hipGetErrorString(dma.err));
     if (n_others == SIZE_MAX) {   // not the kind of witness that packs: no point in scanning the next ones either
         ws.pack_skip = 32;
         ws.pack_skip_nv = nv;
         return ZG_OK;
     }
-    ZG_TRY(upload_packed(ctx, nv, classes, idx_out, val_out, n_others, first));
+    ZG_TRY(upload_packed(ctx, nv, classes + first / 4, idx_out, val_out, n_others, first));
     ZG_HIP(ctx, hipEventRecord(ws.stage_ev[sk], ctx->stream));
     ws.stage_next = sk ^ 1;
     stamp("queued");
