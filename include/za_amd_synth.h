@@ -70,6 +70,13 @@ int zg_selftest_curve_dev(zg_ctx* ctx, int group, int lanes, int op, const uint8
  * over all, or one 2^14-value stretch more than half of them) -- then zg_prove uploads the array as it is. */
 int zg_selftest_pack_mt(const uint8_t* witness32, size_t n, int threads, uint8_t* classes, uint32_t* other_index,
                         uint8_t* others32, size_t* n_others);
+/* The same pass sharing the array with a stand-in for the copy engine (HostPacker::RawCopier: the engine takes pieces from the
+ * front while the threads pack from the back, until they meet): pieces are memcpy'd into raw_out; the stand-in accepts a
+ * piece every `ready_every`-th time it is asked and takes at most cap_permille / 1000 of the values.  *first = the values it
+ * took ([0, first) of raw_out are written); classes[i >> 2] describes value i for i >= first, the list holds positions
+ * >= first.  ZG_E_BAD_FORMAT if the pieces were not handed over in order from value 0. */
+int zg_selftest_pack_split(const uint8_t* witness32, size_t n, int threads, int cap_permille, int ready_every, uint8_t* raw_out,
+                           uint8_t* classes, uint32_t* other_index, uint8_t* others32, size_t* n_others, size_t* first);
 /* Parse + validate a bellman Parameters body on the host (no GPU) and check write(read(x)) == x.
  * counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, bytes consumed. */
 int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap);

@@ -351,6 +351,29 @@ def test_host_packer_matches_the_single_threaded_pack(lib_built):
         c1, i1, v1 = za_amd.pack_witness(w.reshape(-1))
         assert k == i1.size and k != SIZE_MAX
         assert bytes(cls) == bytes(c1) and bytes(idx[:k]) == bytes(i1) and bytes(vals[:32 * k]) == bytes(v1)
+    # the array shared with a (stand-in) copy engine that takes pieces from the front while the threads pack from the back:
+    # wherever the two meet, the raw head and the packed tail together are the witness
+    for n, threads, cap, every in (((1 << 19) + 77, 4, 400, 1), (1 << 19, 8, 900, 3), (1 << 18, 2, 250, 50), (1 << 17, 1, 500, 1),
+                                   ((1 << 16) + 2, 8, 1000, 1), (1 << 18, 4, 0, 1)):
+        w = witness(n, 0.03)
+        cls = np.zeros((n + 3) // 4, dtype=np.uint8)
+        idx = np.zeros(max(n // 8, 1), dtype=np.uint32)
+        vals = np.zeros(max(n // 8, 1) * 32, dtype=np.uint8)
+        raw = np.zeros(32 * n, dtype=np.uint8)
+        k, first = C.c_size_t(), C.c_size_t()
+        rc = lib_built.zg_selftest_pack_split(w.ctypes.data_as(C.c_void_p), C.c_size_t(n), C.c_int(threads), C.c_int(cap),
+                                              C.c_int(every), raw.ctypes.data_as(C.c_void_p), cls.ctypes.data_as(C.c_void_p),
+                                              idx.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), C.byref(k),
+                                              C.byref(first))
+        assert rc == 0, (n, threads, cap, every)
+        f, k = first.value, k.value
+        assert f % (1 << 14) == 0 and f <= n * cap // 1000 and f < n, (n, cap, f)
+        assert bytes(raw[:32 * f]) == bytes(w.reshape(-1)[:32 * f]) and not raw[32 * f:].any()
+        c1, i1, v1 = za_amd.pack_witness(w.reshape(-1))
+        keep = i1 >= f
+        assert k == int(keep.sum())
+        assert bytes(cls[f // 4:]) == bytes(c1[f // 4:])
+        assert bytes(idx[:k]) == bytes(i1[keep]) and bytes(vals[:32 * k]) == bytes(v1.reshape(-1, 32)[keep].reshape(-1))
     # more than an eighth of the values are field elements: not packed
     assert pack_mt(witness(1 << 17, 0.2), 4)[3] == SIZE_MAX
     # one stretch of 2^14 values more than half dense (2 % over all): not packed either

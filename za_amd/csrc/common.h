@@ -72,6 +72,8 @@ int live_contexts();   // zg_ctx handles currently alive in this process (prover
 // prover.hip's host-side witness packer on plain memory (tests: zg_selftest_pack_mt in libza_amd_synth.so)
 int host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
                        uint8_t* others32, size_t* n_others);
+int host_pack_split_for_test(const uint8_t* witness32, size_t nv, int threads, int cap_permille, int ready_every, uint8_t* raw_out,
+                             uint8_t* classes, uint32_t* other_index, uint8_t* others32, size_t* n_others, size_t* first);
 
 // kernel classes timed by the profiling facility
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,

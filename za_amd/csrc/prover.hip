@@ -2383,6 +2383,26 @@ int zg::host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uin
     hp.run(witness32, nv, threads, classes, other_index, others32, n_others, [](const char*) {});
     return ZG_OK;
 }
+// ... with a stand-in for the copy engine: submit() copies into raw_out, ready() says yes every `ready_every`-th time it is
+// asked (a slow or a fast engine).  *first = the values that went through it.
+int zg::host_pack_split_for_test(const uint8_t* witness32, size_t nv, int threads, int cap_permille, int ready_every,
+                                 uint8_t* raw_out, uint8_t* classes, uint32_t* other_index, uint8_t* others32, size_t* n_others,
+                                 size_t* first) {
+    HostPacker hp;
+    HostPacker::RawCopier cp;
+    size_t asked = 0, next_v0 = 0;
+    bool in_order = true;
+    cp.max_vals = (size_t)((double)nv * cap_permille / 1000.0);
+    cp.ready = [&] { return ++asked % (size_t)std::max(ready_every, 1) == 0; };
+    cp.submit = [&](size_t v0, size_t n) {
+        in_order &= v0 == next_v0;   // pieces come in order, back to back, from value 0
+        next_v0 = v0 + n;
+        memcpy(raw_out + 32 * v0, witness32 + 32 * v0, 32 * n);
+        return true;
+    };
+    hp.run(witness32, nv, threads, classes, other_index, others32, n_others, [](const char*) {}, {}, &cp, first);
+    return in_order && next_v0 == *first ? ZG_OK : ZG_E_BAD_FORMAT;
+}
 
 static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, bool* done, size_t* bytes_sent, size_t* first_raw) {
     *done = false;

@@ -572,6 +572,16 @@ extern "C" int zg_selftest_pack_mt(const uint8_t* witness32, size_t nv, int thre
 } catch (...) {
     return zg::on_exception(nullptr);
 }
+// ... shared with a stand-in copy engine (HostPacker::RawCopier): what went through it lands in raw_out, *first = how many values
+extern "C" int zg_selftest_pack_split(const uint8_t* witness32, size_t nv, int threads, int cap_permille, int ready_every,
+                                      uint8_t* raw_out, uint8_t* classes, uint32_t* other_index, uint8_t* others32,
+                                      size_t* n_others, size_t* first) try {
+    if (!witness32 || !raw_out || !classes || !other_index || !others32 || !n_others || !first || threads < 1) return ZG_E_INVALID_ARG;
+    return zg::host_pack_split_for_test(witness32, nv, threads, cap_permille, ready_every, raw_out, classes, other_index, others32,
+                                        n_others, first);
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
 // Parse and validate a bellman Parameters body without a GPU.  counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, consumed.
 // err (nullable) receives the parser's message.
 extern "C" int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap) try {
