@@ -7,6 +7,7 @@
     prove-timing  [log_m]   zg_prove (pinned host witness) against zg_prove_dev, with the event-timed phases
     interference  [none|witness]   who slows the transforms inside a proof
     numa          alloc_node run_node   the host packing pass against NUMA placement
+    small-chains  [eddsa|<log_m>]   each multiexp of a small proof alone: the latency chains a 1 ms proof consists of
 """
 import glob, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -195,7 +196,46 @@ def probe_numa(argv):
     print("proofs", " ".join(ts))
     print("alloc node", alloc_node, "run node", run_node, "last proof %.3f ms" % (1e3 * t), ctx.last_timings()["upload_bytes"])
 
-PROBES = {"h": probe_h, "h-sha": probe_h_sha, "witness-jobs": probe_witness_jobs, "g2-ratio": probe_g2_ratio, "ntt": probe_ntt, "prove-timing": probe_prove_timing, "interference": probe_interference, "numa": probe_numa}
+def probe_small_chains(argv):
+    import numpy as np
+    import za_amd
+    from za_amd import synth, workloads
+    what = argv[0] if argv else "eddsa"
+    ctx = za_amd.Context(0)
+    if what == "eddsa":
+        n_in, n_aux, cons, wit = workloads.eddsa_poseidon_verifier()
+        rp, cl, cf = workloads.csr_arrays(cons)
+        R = ctx.r1cs_load(n_in, n_aux, len(cons), rp, cl, cf)
+        wb = np.frombuffer(workloads.witness_bytes(wit), dtype=np.uint8)
+    else:
+        sr = synth.SynthR1CS(int(what), 2, 0.97, 0x5A)
+        R = sr.load(ctx)
+        wb = np.array(sr.witness, copy=True)
+    P = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)[0]
+    d_w = ctx.upload(wb)
+    P.prepare(R, d_w)
+    d_h = ctx.alloc(32 << R.log_m)
+    for _ in range(3):
+        ctx.prove_dev(P, R, d_w, 5, 7)
+    for name, fn in (("R1CS + H (evaluation form)", lambda: ctx.prove_h_eval_dev(R, d_w, d_h)),):
+        ts = []
+        for i in range(24):
+            t0 = time.perf_counter(); fn(); ts.append(1e3 * (time.perf_counter() - t0))
+        print("%-28s median %.3f min %.3f ms" % (name, sorted(ts)[12], min(ts)))
+    for name, mask in (("h", 1 | 0x20), ("l", 2), ("a", 4), ("b_g1", 8), ("b_g2", 16), ("b_g2 + h", 17 | 0x20), ("b_g2 + h + l", 19 | 0x20),
+                       ("b_g2 + h + l + a", 23 | 0x20), ("l + a + b_g1", 14), ("all five", 0x1f | 0x20)):
+        ts = []
+        for i in range(24):
+            t0 = time.perf_counter()
+            ctx.prove_partials_dev(P, R, d_w, d_h, mask)
+            ts.append(1e3 * (time.perf_counter() - t0))
+        print("%-28s median %.3f min %.3f ms" % (name, sorted(ts)[12], min(ts)))
+    ts = []
+    for i in range(24):
+        t0 = time.perf_counter(); ctx.prove_dev(P, R, d_w, 5, 7); ts.append(1e3 * (time.perf_counter() - t0))
+    print("%-28s median %.3f min %.3f ms" % ("zg_prove_dev", sorted(ts)[12], min(ts)))
+
+PROBES = {"small-chains": probe_small_chains, "h": probe_h, "h-sha": probe_h_sha, "witness-jobs": probe_witness_jobs, "g2-ratio": probe_g2_ratio, "ntt": probe_ntt, "prove-timing": probe_prove_timing, "interference": probe_interference, "numa": probe_numa}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in PROBES:

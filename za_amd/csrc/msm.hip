@@ -31,6 +31,7 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <array>
 #include <atomic>
 #include <functional>
 #include <future>
@@ -2179,18 +2180,48 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
                hipEvent_t ev_h) {
     constexpr int NS = Ctx::MSM_SLOTS, HP = Ctx::H_PARTS_MAX;
-    // slots: 0 h part 0 | 1-3 l, a, b_g1 | 4 b_g2 | 5-7 further h parts
-    auto is_h_slot = [](int k) { return k == 0 || (k >= 5 && k <= 7); };
+    // slots: 0-4 the five queries (job_slot below) | 5-7 further h parts
+    // Which of the side streams 0-4 each of h (its first part), l, a, b_g1, b_g2 runs on.  HIP streams are backed by hardware
+    // queues in creation order, the command processor serves the queues through a few pipes, and two queues that meet on
+    // one pipe take TURNS: a chain of small dependent kernels on one of them runs between the kernels of the other, not
+    // beside them (tools/probe.py small-chains: the G2 chain and the h chain of a 7 469-constraint proof, 0.64 and 0.30 ms
+    // alone, took 0.95 ms together on side streams 4 and 0 and 0.68 ms on 3 and 0).  Which streams meet is not documented,
+    // so the assignment was searched: all 120 of them, one process each, on the EdDSA circuit, at 2^14 and at 2^20
+    // (tools/exp/r4_exp31.py, r4_exp33.py; profiles/r04_exp_stream_assignment.txt).  This one is within 1 % of the best at
+    // each size: 2^14 0.97 -> 0.92 ms, EdDSA 1.04 -> 0.97, 2^16 1.79 -> 1.53, 2^18 2.53 -> 2.40, 2^20 4.33 -> 4.13, 2^22
+    // unchanged; the worst ones (h on stream 1, or the G2 chain on stream 2) cost a small proof 30 %.
+    // ZA_AMD_JSLOTS="0,1,2,3,4" (h, l, a, b_g1, b_g2) overrides: an experiment switch.
+    static const std::array<int, 5> job_slot_env = [] {
+        std::array<int, 5> v = {-1, 0, 0, 0, 0};
+        if (const char* e = getenv("ZA_AMD_JSLOTS")) {
+            int a[5];
+            if (sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) == 5) {
+                unsigned seen = 0;
+                for (int k = 0; k < 5; k++) seen |= a[k] >= 0 && a[k] <= 4 ? 1u << a[k] : 0x100u;
+                if (seen == 0x1fu) v = {a[0], a[1], a[2], a[3], a[4]};
+            }
+        }
+        return v;
+    }();
+    // The streams are interchangeable (same priority, scratch memory of any kind), so the assignment is made per call: the
+    // searched one for a whole proof of a lone context; streams 0-4 in order when the h multiexp or the witness multiexps
+    // run on their own (a rank of a sharded proof: its four witness shards alone 1.28 ms in order, 1.62 ms the other way)
+    // and when several contexts share the GPU (three provers: 9.7 against 10.3 ms per proof).
+    static const std::array<int, 5> in_order = {0, 1, 2, 3, 4}, whole_proof = {3, 2, 4, 1, 0};
+    const bool whole = g1[0].n != 0 && (g1[1].n != 0 || g1[2].n != 0 || g1[3].n != 0 || g2.n != 0) && live_contexts() == 1;
+    const std::array<int, 5>& job_slot = job_slot_env[0] >= 0 ? job_slot_env : whole ? whole_proof : in_order;
+    const int h_slot0 = job_slot[0];
+    auto is_h_slot = [h_slot0](int k) { return k == h_slot0 || (k >= 5 && k <= 7); };
     if (!ctx->side_ready) {
         int lo_prio = 0, hi_prio = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
-        // (High priority for the later h parts, so that their sort is not starved by the first part's accumulation:
-        // measured, no difference.)
-        // Witness queries of a mostly-0/1 assignment are short jobs that fit beside the NTT pipeline: high priority.
-        // Full-width witness queries (window tables: four jobs, each as large as the h job) at low priority leave the
-        // NTT pipeline its share -- 2^22 uniform witness 33.8 -> 32.6 ms; no difference for the 0/1 case.  The choice
-        // is made once per context, from the first proof's key.
-        int w_prio = g1[1].fbw_table ? lo_prio : hi_prio, h_prio = lo_prio;
+        // All side streams at the default priority.  Until round 4 the witness streams of a mostly-0/1 assignment ran at
+        // high priority (short jobs beside the transforms).  With the stream assignment above that is worth nothing for a
+        // lone context (2^22, four alternated pairs of processes: 11.60 / 11.84 / 11.95 / 11.85 with, 11.08 / 11.53 / 11.81 /
+        // 10.87 without) and with three contexts on the GPU it produced proofs of 60-470 ms every few runs -- mixed
+        // priorities over 27 streams on 8 hardware queues; equal priorities: 10.0-10.1 ms per proof, every run
+        // (profiles/r04_exp_stream_assignment.txt).  ZA_AMD_WPRIO / ZA_AMD_HPRIO remain as experiment switches.
+        int w_prio = lo_prio, h_prio = lo_prio;
         if (const char* e = getenv("ZA_AMD_WPRIO")) w_prio = atoi(e);
         if (const char* e = getenv("ZA_AMD_HPRIO")) h_prio = atoi(e);
         // (Confining the witness streams to 16-128 of the 256 CUs with hipExtStreamCreateWithCUMask: measured, no gain --
@@ -2225,7 +2256,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     }
     // witness queries
     const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
-    static const int w_slot[4] = {1, 2, 3, 4};
+    const int* w_slot = &job_slot[1];
     std::unique_ptr<MsmJob<Fq>> wj1[3];
     std::unique_ptr<MsmJob<Fq2>> wj2;
     for (int q = 0; q < 3; q++) wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);
@@ -2243,7 +2274,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
                 lo = std::min(n, g1[0].part_bounds[k]);
                 hi = std::min(n, g1[0].part_bounds[k + 1]);
             }
-            const int slot = k == 0 ? 0 : 4 + k;
+            const int slot = k == 0 ? h_slot0 : 4 + k;
             hp[k] = make_range_job<Fq>(ctx, slot, g1[0], lo, hi, &hout[k]);
             if (g1[0].part_gate) {   // the caller's gates go with ITS part count; fewer parts here: wait for all of them
                 if (parts == gates_n) {

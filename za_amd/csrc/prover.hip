@@ -2460,9 +2460,13 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     struct {
         int inflight = 0, oldest = 0;
         hipError_t err = hipSuccess;
+        double due[2] = {0, 0};   // when each piece in flight is expected to have crossed (57 GB/s)
+        double polled = 0;        // the last hipEventQuery
     } dma;
     bool use_copier = false;
-    if (ctx->opt_pack_raw_permille > 0) {
+    // (Only a lone context: with several provers on the GPU the link is the scarce thing and packing everything is better --
+    // three provers, 9.8 ms per proof against 10.1; and their copiers' event polling got in each other's way: see ready().)
+    if (ctx->opt_pack_raw_permille > 0 && live_contexts() == 1) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, witness32) == hipSuccess && at.type == hipMemoryTypeHost) {
             use_copier = true;
@@ -2472,6 +2476,12 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
             copier.max_vals = (size_t)((double)nv * std::min(ctx->opt_pack_raw_permille, 900) / 1000.0);
             copier.ready = [&]() -> bool {
                 if (dma.inflight < 2) return true;
+                // The event is not asked before the piece can have arrived, and then at most every 10 us: a thread that
+                // calls hipEventQuery in a tight loop holds the runtime's locks most of the time, and the other threads
+                // of the process (three provers: their launches) waited for them -- proofs of 150-330 ms were seen.
+                const double now = now_ms();
+                if (now < dma.due[dma.oldest] || now - dma.polled < 0.010) return false;
+                dma.polled = now;
                 const hipError_t q = hipEventQuery(ws.dma_ev[dma.oldest]);
                 if (q == hipErrorNotReady) return false;
                 if (q != hipSuccess) dma.err = q;   // (submit reports it)
@@ -2483,7 +2493,11 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
                 if (dma.err != hipSuccess) return false;
                 dma.err = hipMemcpyAsync((uint8_t*)ws.w.p + v0 * 32, witness32 + v0 * 32, n * 32, hipMemcpyHostToDevice, ctx->stream);
                 if (dma.err != hipSuccess) return false;
-                dma.err = hipEventRecord(ws.dma_ev[(dma.oldest + dma.inflight) & 1], ctx->stream);
+                const int slot = (dma.oldest + dma.inflight) & 1;
+                dma.err = hipEventRecord(ws.dma_ev[slot], ctx->stream);
+                // (pieces cross one after the other: this one is due when the one before it is, plus its own bytes)
+                const double start = dma.inflight ? std::max(dma.due[slot ^ 1], now_ms()) : now_ms();
+                dma.due[slot] = start + (double)n * 32.0 / 57e6;
                 dma.inflight++;
                 return dma.err == hipSuccess;
             };
