@@ -2196,9 +2196,10 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         if (const char* e = getenv("ZA_AMD_JSLOTS")) {
             int a[5];
             if (sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) == 5) {
-                unsigned seen = 0;
-                for (int k = 0; k < 5; k++) seen |= a[k] >= 0 && a[k] <= 4 ? 1u << a[k] : 0x100u;
-                if (seen == 0x1fu) v = {a[0], a[1], a[2], a[3], a[4]};
+                unsigned seen = 0, n_seen = 0;   // (streams 5-7 are also the later h parts': for proofs whose h job is one part)
+                for (int k = 0; k < 5; k++)
+                    if (a[k] >= 0 && a[k] <= 7 && !(seen >> a[k] & 1u)) seen |= 1u << a[k], n_seen++;
+                if (n_seen == 5) v = {a[0], a[1], a[2], a[3], a[4]};
             }
         }
         return v;
