@@ -2382,9 +2382,9 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
     ProveWs& ws = prove_ws(ctx);
     const size_t np = nv - first;
     ZG_HIP(ctx, ws.w.reserve(nv * 32));
+    if (np == 0) return ZG_OK;
     ZG_HIP(ctx, ws.pk_cls.reserve((np + 3) / 4));
     ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (np + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
-    if (np == 0) return ZG_OK;
     hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), np,
                        ws.w.as<Fr>() + first);
     if (n_others) {
@@ -2402,9 +2402,10 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
 // zg_prove's host side for a witness that is mostly zeros and ones (a SHA-256 circuit: > 99 %; config 4: 97 %): the
 // 32 (l + v)-byte upload is the one stretch of a proof in which the GPU idles (2.3 ms of 14 at 2^22), and most of it
 // carries zeros.  A few host threads turn the array into the packed form -- 2 bits per value plus (index, value) of
-// everything else -- at memory speed, and 3 % of the bytes cross PCIe.  Returns false (nothing queued) when the witness
-// is not of that kind: then it is uploaded as it is.  ZA_AMD_PACK_THREADS sets the thread count (0 = never pack).
-// Host time at 2^22 with 8 threads: 0.73 ms scan + 0.07 ms to put the lists back to back + 0.03 ms of queueing.
+// everything else -- at memory speed, and 3 % of the bytes cross PCIe (pack_and_upload: *done = false, nothing or only a
+// raw head queued, when the witness is not of that kind: then the rest is uploaded as it is).  ZG_OPT_PACK_THREADS sets the
+// thread count.  Host time at 2^22 with 16 threads: 0.55-0.75 ms of scanning (a fifth to a quarter of the array goes over
+// as it is meanwhile) + 0.07 ms to put the lists back to back + 0.03 ms of queueing.
 static int host_pack_threads(const Ctx* ctx) {
     if (ctx->opt_pack_threads > 0) return ctx->opt_pack_threads;   // ZG_OPT_PACK_THREADS
     // Measured on the GPU box (256 hardware threads, shared with other jobs; 134 MB witness).  Alone, the pass takes
