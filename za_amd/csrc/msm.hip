@@ -1374,11 +1374,11 @@ __device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ parti
 // level with every lane busy, where one thread per group ran four (and held four points: 311 registers for G1,
 // spills for G2).
 static constexpr uint32_t BITS_THREADS = 128;
-template <class F, class L = typename LazyOf<F>::L, int LP = 1>
-__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
-                                                             const uint32_t* __restrict__ item_off, uint32_t rows_in,
-                                                             uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
-                                                             uint32_t ones_row, uint32_t ones_key, XYZZ<F>* __restrict__ out) {
+template <class F, class L, int LP>
+__device__ __forceinline__ void bits_level_body(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
+                                                const uint32_t* __restrict__ item_off, uint32_t rows_in, uint32_t kw,
+                                                uint32_t len_out, int f, uint32_t heavy_items, uint32_t ones_row,
+                                                uint32_t ones_key, XYZZ<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per point held (LP lanes each)
     const uint32_t tid = threadIdx.x / LP;
@@ -1403,21 +1403,47 @@ __global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>*
         }
         return bucket_sum<L, F>(partial, item_off, child, heavy_items);
     };
-    if (f == 1) {   // uniform; the last level of an odd bit count: two children, lane A does it all
-        if (in_range && q == 0) {
-            XYZZd<L> c0 = fetch(child0);
-            XYZZd<L> c1 = fetch(child0 + 1);
-            if (full) c1.store(outD);
-            c0.add(c1).store(outS);
-        }
-        return;
-    }
-    // lane A: children 0, 1; lane B: children 2, 3
     XYZZd<L> lo = XYZZd<L>::inf(), hi = XYZZd<L>::inf();
-    if (in_range) {
-        const uint32_t ch = child0 + 2u * q;
-        lo = fetch(ch);
-        hi = fetch(ch + 1);
+    if constexpr (LP == 2) {
+        // G2: ONE call site of `fetch`.  Used once, it is inlined (bucket_sum and its addition with it); used four times, as
+        // in the G1 form below, the compiler calls it -- closure, arguments and the returned point through a frame in scratch
+        // memory: 440 B per lane and ~60 reloads per call, every one waited for in a level that is a chain of two dependent
+        // additions.
+        // f == 1 (uniform; the last level of an odd bit count): two children, lane A does it all.  Else lane A: children 0, 1;
+        // lane B: children 2, 3.
+        const bool act = f == 1 ? in_range && q == 0 : in_range;
+        const uint32_t ch = f == 1 ? child0 : child0 + 2u * q;
+        if (act) {
+#pragma clang loop unroll(disable)
+            for (int k = 0; k < 2; k++) {
+                const XYZZd<L> v = fetch(ch + (uint32_t)k);
+                if (k == 0) lo = v;
+                else hi = v;
+            }
+        }
+        if (f == 1) {
+            if (act) {
+                if (full) hi.store(outD);
+                lo.add(hi).store(outS);
+            }
+            return;
+        }
+    } else {
+        if (f == 1) {   // uniform; the last level of an odd bit count: two children, lane A does it all
+            if (in_range && q == 0) {
+                XYZZd<L> c0 = fetch(child0);
+                XYZZd<L> c1 = fetch(child0 + 1);
+                if (full) c1.store(outD);
+                c0.add(c1).store(outS);
+            }
+            return;
+        }
+        // lane A: children 0, 1; lane B: children 2, 3
+        if (in_range) {
+            const uint32_t ch = child0 + 2u * q;
+            lo = fetch(ch);
+            hi = fetch(ch + 1);
+        }
     }
     XYZZd<L> r = lo.add(hi);                       // A: c0 + c1;  B: c2 + c3 (bit 1)
     (q == 0 ? hi : r).store(&lds[tid]);            // A publishes c1, B its sum
@@ -1429,6 +1455,13 @@ __global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>*
     }
 }
 
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
+                                                             const uint32_t* __restrict__ item_off, uint32_t rows_in,
+                                                             uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
+                                                             uint32_t ones_row, uint32_t ones_key, XYZZ<F>* __restrict__ out) {
+    bits_level_body<F, L, LP>(in, partial, item_off, rows_in, kw, len_out, f, heavy_items, ones_row, ones_key, out);
+}
 // One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
 // (RowMeta).  Output: one entry per block, in block order -- again rows of `chunks` entries, so the kernel is
 // applied until every row has length 1.
