@@ -151,8 +151,18 @@ bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_b
             const double t = std::min(64.0, std::max(4.0, std::ceil(std::sqrt(2.0 * mean))));
             // (+ the leaf level's pass over all 2^(c-1) buckets -- four rows of XYZZ points written and read back --
             // in the same unit: about 1e-5 additions' time per bucket)
-            const double depth = std::min(t, mean + 1.0) + 1.25 * mean / t + 2.0 * ((c - 1 + 1) / 2)
-                                 + 1e-5 * (double)(1u << (c - 1));
+            double depth = std::min(t, mean + 1.0) + 1.25 * mean / t + 2.0 * ((c - 1 + 1) / 2)
+                           + 1e-5 * (double)(1u << (c - 1));
+            // The last digit has only `top` significant bits, and with a window table its entries share the bucket set of
+            // all the others: n entries pile onto 2^top buckets.  When that is more than a bucket may hold before it counts
+            // as heavy, ONE workgroup folds each pile (k_heavy_fold: its items over 128 lanes, then a 7-level tree) -- at
+            // n = 2^16 the depth model alone picked c = 18, whose last digit has 2 bits: three buckets of ~16 000 entries,
+            // 0.375 ms of a 1.06 ms chain (c = 17: 16 bits, no pile).
+            const int top = fbw_top_bits(c, nwin);
+            if (top < c - 1) {
+                const double pile_items = (double)n_real / (double)(1u << (top > 0 ? top : 0)) / t;
+                if (pile_items > 2.5 * mean / t) depth += pile_items / 128.0 + 7.0;
+            }
             if (depth < best) {
                 best = depth;
                 bc = c;
