@@ -721,7 +721,8 @@ def main():
                                "R1CS and key resident.  %s; %s"
                                % ("zg_prove" if world == 1 else "sharded proof (za_amd/dist.py), every rank takes the whole witness",
                                   witness_bytes,
-                                  "packed by %d host threads before it crossed PCIe (%d bytes sent in the last step)"
+                                  "shared between the copy engine (from the front, as it is) and %d packing host threads "
+                                  "(from the back) until they meet (%d bytes sent in the last step)"
                                   % (host_pack_threads(), upload_bytes)
                                   if 0 < upload_bytes < witness_bytes else
                                   "sent over PCIe as it is in the last step (packing applies from 2^20 values, to a mostly-0/1 "
