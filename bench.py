@@ -725,7 +725,7 @@ def main():
                                   "(from the back) until they meet (%d bytes sent in the last step)"
                                   % (host_pack_threads(), upload_bytes)
                                   if 0 < upload_bytes < witness_bytes else
-                                  "sent over PCIe as it is in the last step (packing applies from 2^20 values, to a mostly-0/1 "
+                                  "sent over PCIe as it is in the last step (packing applies from 2^18 values, to a mostly-0/1 "
                                   "witness)",
                                   "H in evaluation form (6 transforms; h bases transformed once per key)" if h_eval_form else
                                   "H in coefficient form (bellman's 7 transforms: this key has no transformed h bases)"),

@@ -75,7 +75,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                         pass measures slower than the plain copy on this host the next 32 witnesses go over unpacked.
  *   ZG_OPT_PACK_THREADS   host threads of that pass, the caller's included (default min(16, half the hardware threads);
  *                         0 = the default).
- *   ZG_OPT_PACK_MIN_LOG_N witnesses of fewer than 2^value values are never packed (default 20).
+ *   ZG_OPT_PACK_MIN_LOG_N witnesses of fewer than 2^value values are never packed (default 18).
  *   ZG_OPT_PACK_PIN       1 (default): the pass's worker threads are bound to the CPUs of the GPU's NUMA node, where
  *                         zg_host_alloc's pinned memory lives; 0 = left to the scheduler.
  *   ZG_OPT_H_EVAL         1 (default): keys get their h query in evaluation form (one transform fewer per proof, paid

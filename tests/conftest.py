@@ -35,7 +35,7 @@ def ctx(lib_built):
 def opts(ctx):
     """zg_set_option on the shared context for one test: opts(za_amd.OPT_TABLES, 0); the defaults come back afterwards."""
     import za_amd
-    defaults = {za_amd.OPT_PACK: 1, za_amd.OPT_PACK_THREADS: 0, za_amd.OPT_PACK_MIN_LOG_N: 20, za_amd.OPT_PACK_PIN: 1,
+    defaults = {za_amd.OPT_PACK: 1, za_amd.OPT_PACK_THREADS: 0, za_amd.OPT_PACK_MIN_LOG_N: 18, za_amd.OPT_PACK_PIN: 1,
                 za_amd.OPT_H_EVAL: 1, za_amd.OPT_TABLES: 31, za_amd.OPT_TABLES_MAX_MB: 0, za_amd.OPT_PACK_BUDGET_PERMILLE: 900,
                 za_amd.OPT_PACK_RAW_PERMILLE: 400, za_amd.OPT_COMBINE_EARLY: 1}
     touched = set()

@@ -131,7 +131,7 @@ def test_zg_prove_packs_a_bit_heavy_witness_on_the_host(ctx, opts):
     bytes cross PCIe); a witness of field elements, or one with a dense stretch, is uploaded as it is.  Same proof as
     zg_prove_dev on the raw array and as the C oracle either way."""
     from za_amd import synth
-    opts(za_amd.OPT_PACK_MIN_LOG_N, 16)    # (by default only witnesses of 2^20 values and more are packed)
+    opts(za_amd.OPT_PACK_MIN_LOG_N, 16)    # (by default only witnesses of 2^18 values and more are packed)
     for lg, bits, expect_packed in ((18, 0.97, True), (18, 0.5, False), (17, 1.0, True)):
         sr = synth.SynthR1CS(lg, 3, bits, 0x77 + lg)
         R = sr.load(ctx)

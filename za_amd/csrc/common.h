@@ -34,7 +34,7 @@ struct Ctx {
     // zg_set_option: the witness hand-over and the per-key precomputation (include/za_amd.h)
     int opt_pack = 1;            // 0 never, 1 always for a bit-heavy witness, 2 with the slow-host fallback
     int opt_pack_threads = 0;    // 0 = min(8, hardware threads / 2)
-    int opt_pack_min_log_n = 20;
+    int opt_pack_min_log_n = 18;
     bool opt_pack_pin = true;
     int opt_pack_budget_permille = 900;
     int opt_pack_raw_permille = 400;  // ZG_OPT_PACK_RAW_PERMILLE

@@ -2454,7 +2454,9 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
     *first_raw = 0;
     if (ctx->opt_pack == 0) return ZG_OK;   // ZG_OPT_PACK
     const int nthreads = host_pack_threads(ctx);
-    // below ~2^20 values (32 MB, 0.6 ms of PCIe) waking the threads costs what the pass saves (ZG_OPT_PACK_MIN_LOG_N)
+    // below 2^18 values (8 MB, 0.15 ms of PCIe) waking the threads costs what the pass saves (ZG_OPT_PACK_MIN_LOG_N; the limit was
+    // 2^20 while the pass had to beat the copy on its own: shared with the copy engine it pays earlier -- 2^18: 2.27 -> 1.99 ms,
+    // 2^19: 3.25 -> 2.96, 2^17: 1.42 -> 1.40)
     if (nthreads <= 0 || nv < ((size_t)1 << ctx->opt_pack_min_log_n)) return ZG_OK;
     {   // a cheap look first: 1024 evenly spread values; a witness of field elements is left alone (8 %: below what makes
         // the pass itself give up, so a borderline witness does not flip between the two forms)
