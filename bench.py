@@ -228,15 +228,33 @@ def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live, eval_form=True):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`bench.py --gpus N` without a launcher: N ranks through `python -m torch.distributed.run` as a child process."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", os.environ.get("MASTER_PORT") or str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between the ranks on this image
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus),
-              file=sys.stderr)
-        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` the way the driver runs N = 1: start the N ranks as CHILD processes (one per GPU,
+        # torch.distributed.run over RCCL) before anything here has touched the GPU or imported torch, relay their output
+        # (rank 0 prints the JSON line) and leave with the launcher's exit code.  Never an exec.
+        sys.exit(self_launch(args.gpus))
     import torch
     import za_amd
     from za_amd import synth

@@ -56,3 +56,17 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = _line(p.stdout)
     _check_contract(d, 2)
     assert d["scaling"] == "strong" and "sharded_phases" in d and d["sharded_phases"]["msm_phase_ms"] > 0
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher on the command line and no WORLD_SIZE in the environment: bench.py starts
+    the ranks itself (as child processes, before it touches the GPU) and leaves with their exit code (missing 2)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ZA_BENCH_DEVICE"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--no-cpu-baseline"]
+                       + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-2000:])
+    d = _line(p.stdout)
+    _check_contract(d, 2)
+    assert d["scaling"] == "strong" and d["sharded_phases"]["msm_phase_ms"] > 0
+
