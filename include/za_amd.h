@@ -93,6 +93,30 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
 #define ZG_OPT_PACK_BUDGET_PERMILLE 9   /* ZG_OPT_PACK = 2: the share of the plain copy's time the pass may take (default 900) */
 #define ZG_OPT_COMBINE_EARLY 11        /* 1 (default): the witness part of the combination runs beside the h multiexp; 0: all of it at the end */
 #define ZG_OPT_PACK_RAW_PERMILLE 10     /* largest share of a pinned witness the copy engine may take as it is while the threads pack the rest, in 1/1000 (default 400; 0 = none) */
+/* Schedule switches: what the tests, the fuzzer and the A/B tools force (a deployment leaves the defaults; none of it
+ * changes a proof's bytes).  The library reads no environment variable for any of this -- ZA_AMD_TRACE (host time stamps
+ * to stderr) is the only one it reads at all.
+ *   ZG_OPT_SMALL_LOG_N     multiexps of up to 2^value points run in small-job mode (queued whole, always a window table,
+ *                          digits planned for depth); default 16, 0 = mode off.  Read per proof and when tables are built.
+ *   ZG_OPT_SMALL_W_LOG_N   the same bound for a witness query whose "real" scalars number at most 2^SMALL_LOG_N;
+ *                          default -1 = 600 000 positions (a 1/8 shard of a 2^22 query), 0 = off.
+ *   ZG_OPT_SORT_STAGED     digit sort: -1 (default) chosen per job, 0 = the two-level scatter, 2 = the LDS-staged
+ *                          three-level partition for every large job, 3 = for every job with at least 2^7 buckets.
+ *   ZG_OPT_PART_STAGE_MIN  last-level sort segments of at least this many entries go through the LDS stage
+ *                          (default -1 = 16384; 0 = all of them).
+ *   ZG_OPT_SUBSET_W        positions per subset-sum group, 4 or 8 (default 8).  Read when a key's tables are built.
+ *   ZG_OPT_COMPACT_TABLE   1 (default): compact window table behind the subset sums.  Read when tables are built.
+ *   ZG_OPT_H_PARTS         parts the h multiexp is split into (0 = default: 2 for a lone context from 2^20 points, else 1).
+ *   ZG_OPT_H_PIPE          1: the last transform kernel is launched range by range and every h part is gated on its
+ *                          range alone (default 0: measured, no gain). */
+#define ZG_OPT_SMALL_LOG_N 12
+#define ZG_OPT_SMALL_W_LOG_N 13
+#define ZG_OPT_SORT_STAGED 14
+#define ZG_OPT_PART_STAGE_MIN 15
+#define ZG_OPT_SUBSET_W 16
+#define ZG_OPT_COMPACT_TABLE 17
+#define ZG_OPT_H_PARTS 18
+#define ZG_OPT_H_PIPE 19
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
@@ -289,7 +313,7 @@ int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witne
 /* H in EVALUATION form: d_e_out receives m canonical-LE scalars e[p] = ((A B - C) / Z)(g omega^bitrev(p)) -- the values
  * bellman's create_proof holds just before its last transform (icoset_fft).  zg_prove* multiplies them into the key's
  * TRANSFORMED h bases (built once per key: the same linear map applied to the points), so a proof runs six transforms
- * instead of seven and gives the same group element; ZA_AMD_H_EVAL=0 keeps the coefficient form.  Blocking. */
+ * instead of seven and gives the same group element; zg_set_option(ZG_OPT_H_EVAL, 0) keeps the coefficient form.  Blocking. */
 int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
 /* The sharded form of the same: zg_prove_h_eval_enqueue_dev is zg_prove_h_enqueue_dev for evaluation-form scalars
  * (non-blocking; zg_sync before reading d_e_out), and zg_prove_partials_ex with ZG_MASK_H_EVAL or-ed into its mask takes
@@ -317,10 +341,10 @@ int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
  * prover.rs:173).  A table holds 2^(c*w) * P_i for every digit position w, so a multiexp needs one bucket set
  * instead of one per window; it costs nwin (about 13 at 2^22) times the query's HBM footprint.  d_witness (device,
  * as for zg_prove_dev) sizes the l / a / b tables from its share of 0/1 values; NULL builds the h table only.
- * Call it before sharing `params` between host threads.  Environment: ZA_AMD_FBW=0 disables the tables (any
- * other value is a bit mask of the queries that may have one: 1 h, 2 l, 4 a, 8 b_g1, 16 b_g2),
- * ZA_AMD_FBW_MAX_GB caps them (default 60% of the free HBM); without room the plain per-window schedule is used.
- * Results are identical either way. */
+ * Call it before sharing `params` between host threads.  zg_set_option(ZG_OPT_TABLES, mask) says which queries may have
+ * a table (bit mask: 1 h, 2 l, 4 a, 8 b_g1, 16 b_g2; 0 = none), ZG_OPT_TABLES_MAX_MB caps one table (default: 60 % of the
+ * free HBM); the library reads no environment variable for either.  Without room the plain per-window schedule is
+ * used.  Results are identical either way. */
 int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness);
 /* Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) currently has: kind 0 none, 1 window table (dense
  * assignment), 2 subset-sum table (sums over groups of four positions, for an assignment that is at least 90 % zeros

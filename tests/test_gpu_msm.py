@@ -3,6 +3,8 @@ size, against the discrete-log identity  sum s_i (k_i G) = (sum s_i k_i) G.  Bit
 import numpy as np
 import pytest
 
+import za_amd
+
 from oracle import bn254 as bn
 from oracle import coracle as co
 from tests.util import golden, jac_to_affine_bytes
@@ -88,10 +90,10 @@ def test_g1_against_c_oracle(ctx, n, pattern):
 
 
 @pytest.mark.parametrize("pattern", ["uniform", "bits97", "all_equal"])
-def test_g1_with_every_sort_segment_through_the_lds_stage(ctx, pattern, monkeypatch):
+def test_g1_with_every_sort_segment_through_the_lds_stage(ctx, pattern, opts):
     """k_part_local's staged scatter (normally for segments of 16 K entries and more: 2^24 points and up, where it is
     covered by the full-size tests) forced onto every segment: plain windows, window table and resident bases."""
-    monkeypatch.setenv("ZA_AMD_PART_STAGE_MIN", "0")
+    opts(za_amd.OPT_PART_STAGE_MIN, 0)
     n = (1 << 15) + 77
     rng = np.random.default_rng(77)
     d, host = _bases_from_gpu(ctx, n, 4242)

@@ -920,7 +920,7 @@ def test_table_budget_falls_back_to_the_plain_schedule(ctx, monkeypatch, opts):
 
 @pytest.mark.parametrize("parts", ["2", "3", "4"])
 def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts, opts):
-    """The h multiexp split into dependent parts over consecutive base ranges (ZA_AMD_H_PARTS) against the single
+    """The h multiexp split into dependent parts over consecutive base ranges (ZG_OPT_H_PARTS) against the single
     job, with and without the window table."""
     from za_amd import synth
     lg = 15
@@ -929,14 +929,14 @@ def test_h_job_in_parts_gives_the_same_proof(ctx, monkeypatch, parts, opts):
     m = 1 << lg
     sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
     P = synth.synth_params(ctx, *sizes, 23)
-    monkeypatch.setenv("ZA_AMD_H_PARTS", "1")
+    opts(za_amd.OPT_H_PARTS, 1)
     want = ctx.prove(P, R, sr.witness, 21, 22)
-    monkeypatch.setenv("ZA_AMD_H_PARTS", parts)
+    opts(za_amd.OPT_H_PARTS, int(parts))
     assert ctx.prove(P, R, sr.witness, 21, 22) == want
     # the same with the last transform kernel launched range by range and every part gated on its own range
-    monkeypatch.setenv("ZA_AMD_H_PIPE", "1")
+    opts(za_amd.OPT_H_PIPE, 1)
     assert ctx.prove(P, R, sr.witness, 21, 22) == want
-    monkeypatch.delenv("ZA_AMD_H_PIPE")
+    opts(za_amd.OPT_H_PIPE, 0)
     opts(za_amd.OPT_TABLES, 0)
     P2 = synth.synth_params(ctx, *sizes, 23)
     assert ctx.prove(P2, R, sr.witness, 21, 22) == want
@@ -950,8 +950,8 @@ def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch, opts
     the identity), rows (x + y) * 1 = z pairs of equal points; proof against the C oracle, the plain schedule, and the
     pairing check."""
     import za_amd
-    monkeypatch.setenv("ZA_AMD_SMALL_LOG_N", "0")   # (jobs of this size otherwise take the small-job mode: window tables)
-    monkeypatch.setenv("ZA_AMD_QUAD_W", qw)
+    opts(za_amd.OPT_SMALL_LOG_N, 0)   # (jobs of this size otherwise take the small-job mode: window tables)
+    opts(za_amd.OPT_SUBSET_W, int(qw))
     rng = np.random.default_rng(7)
     w = [1, 1]                       # ONE, one public input (a constant 1)
     cons = []
@@ -987,13 +987,14 @@ def test_subset_sum_tables_with_opposite_and_equal_points(ctx, monkeypatch, opts
     ctx.free(d_w)
 
 
-def test_compact_window_table_over_the_field_element_positions_and_its_fallback(ctx, monkeypatch):
+def test_compact_window_table_over_the_field_element_positions_and_its_fallback(ctx, opts):
     """A bit-heavy query's subset-sum table carries a window table over the positions that held field elements in the
     witness it was built from (their digits then share one bucket set).  Same proof as the C oracle; a LATER witness with a
     field element at a position that was a bit takes the per-window path for that proof (k_classify counts such
-    positions) -- again the oracle's bytes; and the same proofs with the compact rows switched off (ZA_AMD_CW=0)."""
+    positions) -- again the oracle's bytes; and the same proofs with the compact rows switched off (ZG_OPT_COMPACT_TABLE = 0)."""
+    import za_amd
     from za_amd import synth
-    monkeypatch.setenv("ZA_AMD_SMALL_LOG_N", "0")   # (queries of this size otherwise take the small-job mode: window tables)
+    opts(za_amd.OPT_SMALL_LOG_N, 0)   # (queries of this size otherwise take the small-job mode: window tables)
     lg = 15
     sr = synth.SynthR1CS(lg, 2, 0.95, 4242)
     R = sr.load(ctx)
@@ -1014,7 +1015,7 @@ def test_compact_window_table_over_the_field_element_positions_and_its_fallback(
     w2 = w2.reshape(-1)
     proofs = {}
     for cw in ("1", "0"):
-        monkeypatch.setenv("ZA_AMD_CW", cw)
+        opts(za_amd.OPT_COMPACT_TABLE, int(cw))
         P = synth.synth_params(ctx, *sizes, 61)
         d_w = ctx.upload(w1)
         P.prepare(R, d_w)
@@ -1065,7 +1066,7 @@ def test_dense_h_job_with_zero_one_and_extreme_coefficients(ctx, monkeypatch, lg
     if fbw is not None:
         opts(za_amd.OPT_TABLES, int(fbw))
     if parts is not None:
-        monkeypatch.setenv("ZA_AMD_H_PARTS", parts)
+        opts(za_amd.OPT_H_PARTS, int(parts))
     rng = random.Random(1000 + lg)
     m = 1 << lg
     pool = [0, 1, 1, 1, 2, bn.R - 1, bn.R - 2, (1 << 253) + 1, 1 << 20, (1 << 20) - 1]

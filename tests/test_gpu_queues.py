@@ -37,5 +37,5 @@ def test_torch_initialises_hip_first(ctx):
 
 @pytest.mark.parametrize("parts", [3, 4])
 def test_h_multiexp_in_more_parts(ctx, parts):
-    """ZA_AMD_H_PARTS = 3 / 4 (main + 4 witness + 3-4 h streams) on the default queue count; one prover, 2^20."""
+    """ZG_OPT_H_PARTS = 3 / 4 (main + 4 witness + 3-4 h streams) on the default queue count; one prover, 2^20."""
     _run({}, "--provers", "1", "--proofs", "40", "--log-m", "20", "--h-parts", str(parts))

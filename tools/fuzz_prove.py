@@ -23,7 +23,8 @@ while time.time() - t0 < budget:
         m = 1 << lg
         fbw = rng.choice([0, 1, 31])
         ctx.set_option(za_amd.OPT_TABLES, fbw)
-        os.environ["ZA_AMD_H_PARTS"] = rng.choice(["1", "2", "4"])
+        h_parts = rng.choice([1, 2, 4])
+        ctx.set_option(za_amd.OPT_H_PARTS, h_parts)
         p_special = rng.choice([0.2, 0.7, 1.0])
         pool = [0, 1, 1, 2, bn.R - 1, bn.R - 2, 1 << 253, (1 << 20) - 1, 1 << 20]
         h = [rng.choice(pool) if rng.random() < p_special else rng.randrange(bn.R) for _ in range(m - 1)]
@@ -36,7 +37,7 @@ while time.time() - t0 < budget:
         got = ctx.prove(P, R, wb, r, s)
         exp = co.prove(download_params(ctx, P), csr, wb, r, s, threads=16)
         ok = bytes(got) == bytes(exp)
-        print("prescribed H lg %2d special %.1f FBW %-2d parts %s -> %s" % (lg, p_special, fbw, os.environ["ZA_AMD_H_PARTS"], "ok" if ok else "MISMATCH"), flush=True)
+        print("prescribed H lg %2d special %.1f FBW %-2d parts %s -> %s" % (lg, p_special, fbw, h_parts, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             sys.exit(1)
         n_ok += 1
@@ -48,7 +49,8 @@ while time.time() - t0 < budget:
     n_in = rng.choice([1, 2, 3, 7])
     fbw = rng.choice([0, 1, 31, 31, 17, 14])
     ctx.set_option(za_amd.OPT_TABLES, fbw)
-    os.environ["ZA_AMD_H_PARTS"] = rng.choice(["1", "2", "3"])
+    h_parts = rng.choice([1, 2, 3])
+    ctx.set_option(za_amd.OPT_H_PARTS, h_parts)
     sr = synth.SynthR1CS(lg, n_in, bf, seed)
     R = sr.load(ctx)
     m = 1 << lg
@@ -67,7 +69,7 @@ while time.time() - t0 < budget:
     exp = co.prove(download_params(ctx, P), csr, sr.witness, r, s, threads=32)
     kinds = [P.table_info(k)[0] for k in range(5)]
     ok = bytes(got) == bytes(exp)
-    print("lg %2d bits %.2f inputs %d FBW %-2d parts %s tables %s entry %-6s -> %s" % (lg, bf, n_in, fbw, os.environ["ZA_AMD_H_PARTS"], kinds, entry, "ok" if ok else "MISMATCH"), flush=True)
+    print("lg %2d bits %.2f inputs %d FBW %-2d parts %s tables %s entry %-6s -> %s" % (lg, bf, n_in, fbw, h_parts, kinds, entry, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)
     n_ok += 1

@@ -21,10 +21,8 @@ def main():
     ap.add_argument("--bit-fraction", type=float, default=0.97)
     ap.add_argument("--torch-first", action="store_true", help="let torch initialise HIP before zg_init (then "
                     "zg_init's own setenv of GPU_MAX_HW_QUEUES comes too late: the runtime default applies)")
-    ap.add_argument("--h-parts", type=int, default=0, help="ZA_AMD_H_PARTS for the h multiexp (0 = the library's choice)")
+    ap.add_argument("--h-parts", type=int, default=0, help="ZG_OPT_H_PARTS for the h multiexp (0 = the library's choice)")
     args = ap.parse_args()
-    if args.h_parts:
-        os.environ["ZA_AMD_H_PARTS"] = str(args.h_parts)
     if args.torch_first:
         import torch
         torch.zeros(16, device="cuda").sum().item()
@@ -32,6 +30,8 @@ def main():
     import za_amd
     from za_amd import synth
     ctxs = [za_amd.Context(0) for _ in range(args.provers)]
+    for c in ctxs:
+        c.set_option(za_amd.OPT_H_PARTS, args.h_parts)
     ctx = ctxs[0]
     sr = synth.SynthR1CS(args.log_m, 2, args.bit_fraction, 0x5A)
     R = sr.load(ctx)

@@ -1,5 +1,5 @@
 """The phases one rank of a W-way sharded 2^22 proof runs, one after the other on this GPU (bench.py's shard_model alone):
-python tools/shard_model_run.py [W]   -- honours ZA_AMD_SMALL_LOG_N etc."""
+python tools/shard_model_run.py [W]   -- ZA_AMD_OPTIONS="12=0" etc. (test binding) forces schedule options."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

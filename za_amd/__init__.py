@@ -134,6 +134,20 @@ def density_bitmap(flags):
 # zg_set_option (include/za_amd.h)
 OPT_ONE_SHOT, OPT_PACK, OPT_PACK_THREADS, OPT_PACK_MIN_LOG_N, OPT_PACK_PIN, OPT_H_EVAL, OPT_TABLES, OPT_TABLES_MAX_MB, \
     OPT_PACK_BUDGET_PERMILLE, OPT_PACK_RAW_PERMILLE, OPT_COMBINE_EARLY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+# schedule switches (tests, fuzzer, A/B tools)
+OPT_SMALL_LOG_N, OPT_SMALL_W_LOG_N, OPT_SORT_STAGED, OPT_PART_STAGE_MIN, OPT_SUBSET_W, OPT_COMPACT_TABLE, OPT_H_PARTS, \
+    OPT_H_PIPE = 12, 13, 14, 15, 16, 17, 18, 19
+
+
+def _options_from_env():
+    """ZA_AMD_OPTIONS="14=3,15=0": options this BINDING applies to every context it creates (whole test-suite runs with a
+    schedule forced, e.g. the staged digit sort for every job).  The library itself reads no such variable."""
+    out = []
+    for item in os.environ.get("ZA_AMD_OPTIONS", "").split(","):
+        if item.strip():
+            k, v = item.split("=")
+            out.append((int(k), int(v)))
+    return out
 
 
 class Context:
@@ -147,6 +161,8 @@ class Context:
             raise ZaAmdError(rc, self.lib.zg_strerror(rc).decode())
         self.h = h
         self.device = device
+        for opt, val in _options_from_env():
+            self.set_option(opt, val)
 
     def close(self):
         if getattr(self, "h", None):

@@ -33,12 +33,21 @@ struct Ctx {
     bool one_shot = false;       // zg_set_option(ZG_OPT_ONE_SHOT): no per-key precomputation
     // zg_set_option: the witness hand-over and the per-key precomputation (include/za_amd.h)
     int opt_pack = 1;            // 0 never, 1 always for a bit-heavy witness, 2 with the slow-host fallback
-    int opt_pack_threads = 0;    // 0 = min(8, hardware threads / 2)
+    int opt_pack_threads = 0;    // 0 = min(16, hardware threads / 2)
     int opt_pack_min_log_n = 18;
     bool opt_pack_pin = true;
     int opt_pack_budget_permille = 900;
     int opt_pack_raw_permille = 400;  // ZG_OPT_PACK_RAW_PERMILLE
     bool opt_combine_early = true;    // ZG_OPT_COMBINE_EARLY
+    // schedule switches (tests, the fuzzer and A/B tools set them; deployments leave the defaults) -- see include/za_amd.h
+    int opt_small_log_n = 16;         // ZG_OPT_SMALL_LOG_N: dense jobs of up to 2^value points run in small-job mode (0 = off)
+    int opt_small_w_log_n = -1;       // ZG_OPT_SMALL_W_LOG_N: witness jobs; -1 = 600 000 positions ("2^19 and a bit")
+    int opt_sort_staged = -1;         // ZG_OPT_SORT_STAGED: -1 = per job, 0 = two-level scatter, 2 / 3 = staged for every large / every job
+    int64_t opt_part_stage_min = -1;  // ZG_OPT_PART_STAGE_MIN: last-level segments from this many entries go through LDS (-1 = default)
+    int opt_subset_w = 8;             // ZG_OPT_SUBSET_W: positions per subset-sum group (4 | 8), read when a key's tables are built
+    bool opt_compact_table = true;    // ZG_OPT_COMPACT_TABLE: compact window table behind the subset sums, read at table build
+    int opt_h_parts = 0;              // ZG_OPT_H_PARTS: parts of the h multiexp (0 = the scheduler's choice)
+    bool opt_h_pipe = false;          // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev
     std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
@@ -191,8 +200,9 @@ int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_b
 size_t msm_quad_entries(size_t n, int qw);
 bool msm_fbw_plan(size_t n_real, size_t n_table, size_t max_bytes, size_t elem_bytes, int* c_out, int* nwin_out, bool force = false,
                   bool always = false);
-size_t msm_small_n();           // dense jobs up to this size are latency bound (planned for depth, always with a window table)
-size_t msm_small_witness_n();   // witness (non-dense) jobs: queued whole, always with a window table
+size_t msm_small_n(const Ctx* ctx);           // dense jobs up to this size are latency bound (planned for depth, always with a window table)
+size_t msm_small_witness_n(const Ctx* ctx);   // witness (non-dense) jobs: queued whole, always with a window table
+int trace_level();   // ZA_AMD_TRACE (0 = off): host time stamps to stderr -- the one environment variable the library reads
 int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table);
 int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table);
 int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_index, size_t n, uint64_t* zeros,

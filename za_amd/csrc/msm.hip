@@ -48,17 +48,16 @@ static constexpr int MAXWIN = 128;
 // 8-way 2^22 proof: 1.23 -> 1.97 ms when treated as small): 2^16.  A WITNESS job of a bit-heavy circuit has few real
 // scalars and stays a chain of short launches much longer (same shard's witness phase: 3.4 -> 1.8 ms; a 2^18 proof 3.1 ->
 // 2.6 ms; at 2^20 positions per query nothing is gained, at 2^21 it costs 0.8 ms): about 2^19.
-// (ZA_AMD_SMALL_LOG_N / ZA_AMD_SMALL_W_LOG_N override; 0 turns the mode off.  Read per call: tests switch them.)
-static size_t small_from_env(const char* name, int dflt) {
-    int lg = dflt;
-    if (const char* e = getenv(name)) lg = atoi(e);
-    return lg <= 0 ? 0 : (size_t)1 << std::min(lg, 24);
+// (ZG_OPT_SMALL_LOG_N / ZG_OPT_SMALL_W_LOG_N override; 0 turns the mode off.  Per context: tests switch them.)
+size_t msm_small_n(const Ctx* ctx) { return ctx->opt_small_log_n <= 0 ? 0 : (size_t)1 << std::min(ctx->opt_small_log_n, 24); }
+size_t msm_small_witness_n(const Ctx* ctx) {
+    if (ctx->opt_small_log_n <= 0 && ctx->opt_small_w_log_n < 0) return 0;
+    if (ctx->opt_small_w_log_n < 0) return 600000;   // "2^19 and a bit": a 1/8 shard of a 2^22 query is 2^19 + 8 positions
+    return ctx->opt_small_w_log_n == 0 ? 0 : (size_t)1 << std::min(ctx->opt_small_w_log_n, 24);
 }
-size_t msm_small_n() { return small_from_env("ZA_AMD_SMALL_LOG_N", 16); }
-size_t msm_small_witness_n() {
-    if (getenv("ZA_AMD_SMALL_LOG_N") && !getenv("ZA_AMD_SMALL_W_LOG_N") && atoi(getenv("ZA_AMD_SMALL_LOG_N")) <= 0) return 0;
-    if (!getenv("ZA_AMD_SMALL_W_LOG_N")) return 600000;   // "2^19 and a bit": a 1/8 shard of a 2^22 query is 2^19 + 8 positions
-    return small_from_env("ZA_AMD_SMALL_W_LOG_N", 19);
+int trace_level() {
+    static const int lvl = getenv("ZA_AMD_TRACE") ? atoi(getenv("ZA_AMD_TRACE")) : 0;
+    return lvl;
 }
 static constexpr int TREE_LAMBDA = 3;   // tree fan-in 2^3 = 8
 static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (upper limit; see item_sizes)
@@ -1509,8 +1508,7 @@ __global__ void __launch_bounds__(256 * LP) k_rowsum(const XYZZ<F>* __restrict__
 
 // ZA_AMD_TRACE=2: host time stamps inside a job's phase (finds the HIP call a phase blocks in)
 static void trace_point(const char* what) {
-    static const int lvl = getenv("ZA_AMD_TRACE") ? atoi(getenv("ZA_AMD_TRACE")) : 0;
-    if (lvl < 2) return;
+    if (trace_level() < 2) return;
     static const auto t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "[za_amd trace]     %-28s %.3f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -1579,6 +1577,8 @@ struct MsmJob : MsmJobBase {
     bool ones_in_levels = false;          // small jobs: the ones bucket's item sums are a row of the reduction levels
     bool order_items = true;       // items sorted by length before the accumulation (not for small jobs)
     static constexpr uint32_t ITEM_ORDER_MIN = 16384;
+    static constexpr size_t QUAD_ACC_MAX_LANES = 262144;    // four-lane mixed additions: launches of up to this many lanes
+    static constexpr size_t QUAD_LEVEL_MAX_LANES = 32768;   // four-lane additions in the reduction: levels of up to this many logical lanes
     int acc_prof = -1;
     MsmPlan P{};
     uint32_t ones_key = 0, nkeys = 0;
@@ -1647,7 +1647,7 @@ struct MsmJob : MsmJobBase {
             t_ones = T_ONES;
             if (n_ones / T_ONES < target / 2) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, n_ones / (target / 2)));
             heavy_items = HEAVY_ITEMS;
-            if (eager_small || n <= msm_small_n()) {
+            if (eager_small || n <= msm_small_n(ctx)) {
                 // what counts for a small job is the number of dependent additions: T in a thread of k_accumulate, then
                 // up to heavy_items in bucket_sum.  T ~ sqrt(2 * mean load); buckets up to ~2.5 x the mean stay "light".
                 const double mean = (double)entries / (double)P.nkeys;
@@ -1664,12 +1664,12 @@ struct MsmJob : MsmJobBase {
         // part as well: the staged three-level partition (see k_part_staged)
         const int bbits = P.c - 1;
         const size_t max_entries = n_real * (size_t)P.nwin + n_ones;
-        const bool small_job = eager_small || n <= msm_small_n();
+        const bool small_job = eager_small || n <= msm_small_n(ctx);
         // (for jobs in which most points carry their nwin digits: a bit-heavy witness query -- 3 % field elements among
         // zeros and ones -- leaves the staged kernel's tiles nearly empty and is better off with the plain scatter)
         bool staged = !small_job && max_entries >= ((size_t)1 << 20) && bbits >= 7 && max_entries >= n * (size_t)P.nwin / 2;
-        if (const char* e = getenv("ZA_AMD_SORT_STAGED")) {   // 0 = the two-level scatter (A/B); 2 / 3 = staged for every large /
-            const int v = atoi(e);                             // every job with at least 2^7 buckets (tests)
+        if (ctx->opt_sort_staged >= 0) {   // ZG_OPT_SORT_STAGED: 0 = the two-level scatter (A/B); 2 / 3 = staged for every large /
+            const int v = ctx->opt_sort_staged;   // every job with at least 2^7 buckets (tests)
             staged = v == 0 ? false : v == 2 ? (!small_job && bbits >= 7) : v == 3 ? bbits >= 7 : staged;
         }
         int hb, lb, b2 = 0;
@@ -1703,9 +1703,12 @@ struct MsmJob : MsmJobBase {
         // round, thousands of them in flight, instead of a loop of dependent rounds)
         // (... up to 16 K tiles: beyond that the [bin][tile] table costs more than the rounds' latencies, which the many
         // workgroups in flight hide anyway)
-        const uint32_t tp = staged ? std::max(std::max(256u, (PS_CAP / (uint32_t)P.nwin) & ~255u),
-                                              (uint32_t)(((n >> 14) + 255) & ~(size_t)255))
-                                   : n <= msm_small_n() ? PART_TP_SMALL : PART_TP;
+        // (... and no more than fit the kernel's 64 KB of dynamic LDS beside the stage: [tp + 1] prefix words -- a single job
+        // of 2^27 points would ask for 8192-point tiles, 67.7 KB)
+        const uint32_t tp_lds_cap = (uint32_t)((64u * 1024u - PS_CAP * 8u - (4u * nbins + 17u) * 4u) / 4u) & ~255u;
+        const uint32_t tp = staged ? std::min(tp_lds_cap, std::max(std::max(256u, (PS_CAP / (uint32_t)P.nwin) & ~255u),
+                                                                   (uint32_t)(((n >> 14) + 255) & ~(size_t)255)))
+                                   : n <= msm_small_n(ctx) ? PART_TP_SMALL : PART_TP;
         const uint32_t ntiles = (uint32_t)((n + tp - 1) / tp);
         const size_t tab_n = (size_t)nbins * ntiles;
         // last level: lb3 low bits per segment, nbins3 segments (+ the ones bin)
@@ -1747,15 +1750,14 @@ struct MsmJob : MsmJobBase {
             return ZG_OK;
         };
         ZG_TRY(xscan(S.tile_tab.as<uint32_t>(), tab_n));   // the [bin][tile] table
-        // (long segments of the last level go through an LDS stage, see k_part_local; ZA_AMD_PART_STAGE_MIN: the tests
+        // (long segments of the last level go through an LDS stage, see k_part_local; ZG_OPT_PART_STAGE_MIN: the tests
         // force it for all)
         uint32_t stage_min = 2 * PART_STAGE_TILE;
-        if (const char* e = getenv("ZA_AMD_PART_STAGE_MIN")) stage_min = (uint32_t)atol(e);
+        if (ctx->opt_part_stage_min >= 0) stage_min = (uint32_t)ctx->opt_part_stage_min;
         const bool may_stage = max_entries / nbins3 * 2 >= stage_min && lb3 <= 10;   // mean segment within 2x of the threshold
         if (!may_stage) stage_min = 0xffffffffu;
-        // (segments of up to PART_STAGE_TILE entries go through in one pass, see k_part_local; ZA_AMD_PART_SINGLE=0: A/B switch)
-        uint32_t single_max = lb3 <= 10 ? PART_STAGE_TILE : 0u;
-        if (const char* e = getenv("ZA_AMD_PART_SINGLE")) single_max = atoi(e) ? single_max : 0u;
+        // (segments of up to PART_STAGE_TILE entries go through in one pass, see k_part_local)
+        const uint32_t single_max = lb3 <= 10 ? PART_STAGE_TILE : 0u;
         const size_t lds2 = ((size_t)4 << lb3) + 64 +
                             std::max<size_t>(may_stage ? ((size_t)8 << lb3) + PART_STAGE_TILE * 6 : 0,
                                              single_max ? ((size_t)4 << lb3) + (size_t)single_max * 4 : 0);
@@ -1852,10 +1854,7 @@ struct MsmJob : MsmJobBase {
                                               ones_hi - ones_lo, st));
             // order the items by length -- not for a small job: three launches and a memset cost more than the lanes of
             // its few hundred waves waiting for their longest item (it is launch and latency bound, not throughput bound)
-            {
-                static const long omin = getenv("ZA_AMD_ORDER_MIN") ? atol(getenv("ZA_AMD_ORDER_MIN")) : (long)ITEM_ORDER_MIN;
-                order_items = (long)total_items >= omin;
-            }
+            order_items = total_items >= ITEM_ORDER_MIN;
             if (order_items) {
                 ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
                 const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
@@ -1876,24 +1875,20 @@ struct MsmJob : MsmJobBase {
             // G2 runs on lane pairs at every size: a job of few items is a chain of dependent additions, which the pairs
             // halve; a big one is bound by throughput, and there 178 registers per lane (two waves per SIMD) beat the 329
             // of one lane per point (one wave) by more than the operand exchange costs -- dense 2^22 witness: G2
-            // accumulation 18.4 -> 15.8 ms of kernel time, proof 33.5 -> 32.9 ms.  (ZA_AMD_G2_PAIR_ITEMS: A/B switch.)
-            static const long pair_max = getenv("ZA_AMD_G2_PAIR_ITEMS") ? atol(getenv("ZA_AMD_G2_PAIR_ITEMS")) : 0x7fffffffL;
+            // accumulation 18.4 -> 15.8 ms of kernel time, proof 33.5 -> 32.9 ms.
             const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
             const uint32_t* acc_perm = order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr;
             // A small G1 job's accumulation is a chain of T dependent mixed additions per item on a nearly idle GPU: every
             // addition then runs on four lanes (ecd.h add_mixed_quad: four rounds of one product instead of ten serial ones).
-            // ZA_AMD_QUAD_ACC: largest such launch in lanes (0 = off).
+            // Largest such launch: QUAD_ACC_MAX_LANES lanes.
             bool quad_acc = false;
-            if constexpr (IS_G1) {
-                const long qa_max = getenv("ZA_AMD_QUAD_ACC") ? atol(getenv("ZA_AMD_QUAD_ACC")) : 262144;
-                quad_acc = (eager_small || n <= msm_small_n()) && (long)total_items * 4 <= qa_max;
-            }
+            if constexpr (IS_G1) quad_acc = (eager_small || n <= msm_small_n(ctx)) && (size_t)total_items * 4 <= QUAD_ACC_MAX_LANES;
             if (quad_acc) {
                 if constexpr (IS_G1)
                     hipLaunchKernelGGL((k_accumulate<F, FqQL, 4>), dim3((unsigned)(((size_t)total_items * 4 + 255) / 256)), dim3(256), 0, st,
                                        acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                        S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
-            } else if (CLP > 1 && (long)total_items <= pair_max)
+            } else if (CLP > 1)
                 hipLaunchKernelGGL((k_accumulate<F, CL, CLP>), dim3((unsigned)(((size_t)total_items * CLP + 255) / 256)), dim3(256), 0, st,
                                    acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                    S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
@@ -1948,13 +1943,10 @@ struct MsmJob : MsmJobBase {
                 const size_t groups = (size_t)rows * len;
                 XYZZ<F>* outp = S.lvl[l & 1].template as<XYZZ<F>>();
                 // a level of few groups is a chain of dependent additions with most of the GPU idle: G1 then runs every
-                // addition on four lanes (ecd.h FqQL; ZA_AMD_QUAD_LANES: largest such level in logical lanes, 0 = off).
+                // addition on four lanes (ecd.h FqQL; QUAD_LEVEL_MAX_LANES: largest such level in logical lanes).
                 // (The same on four lane pairs for G2 -- eight lanes, ds_swizzle broadcasts -- was measured: no gain.)
                 bool quad = false;
-                if constexpr (IS_G1) {
-                    const long qmax = getenv("ZA_AMD_QUAD_LANES") ? atol(getenv("ZA_AMD_QUAD_LANES")) : 32768;
-                    quad = (long)(groups * 2) <= qmax;
-                }
+                if constexpr (IS_G1) quad = groups * 2 <= QUAD_LEVEL_MAX_LANES;
                 if (quad) {
                     if constexpr (IS_G1)
                         hipLaunchKernelGGL((k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
@@ -2073,7 +2065,7 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<
     };
     std::vector<std::future<int>> finishing;   // (a future of std::async joins in its destructor: early returns are safe)
     // ZA_AMD_TRACE=1: host timestamps (ms since entry) of every phase transition of every job, to stderr
-    static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
+    const bool trace = trace_level() != 0;
     const auto t_entry = std::chrono::steady_clock::now();
     auto stamp = [&](int j, const char* what, double t_begin) {
         if (!trace) return;
@@ -2196,7 +2188,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     std::unique_ptr<MsmJob<F>> j(new MsmJob<F>(ctx, scratch_slot(ctx, slot), ctx->side[slot], (const Affine<F>*)d.bases + lo, sc, ix,
                                                hi - lo, out));
     j->dense = d.dense;
-    j->eager_small = !d.dense && (d.small_hint >= 0 ? d.small_hint != 0 : hi - lo <= msm_small_n());
+    j->eager_small = !d.dense && (d.small_hint >= 0 ? d.small_hint != 0 : hi - lo <= msm_small_n(ctx));
     j->d_cls = d.cls ? (d.index ? d.cls : d.cls + lo) : nullptr;
     if (d.quad_table) {   // (lo is a multiple of the group width)
         j->quad_table = (const Affine<F>*)d.quad_table + lo;
@@ -2230,30 +2222,16 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // beside them (tools/probe.py small-chains: the G2 chain and the h chain of a 7 469-constraint proof, 0.64 and 0.30 ms
     // alone, took 0.95 ms together on side streams 4 and 0 and 0.68 ms on 3 and 0).  Which streams meet is not documented,
     // so the assignment was searched: all 120 of them, one process each, on the EdDSA circuit, at 2^14 and at 2^20
-    // (tools/exp/r4_exp31.py, r4_exp33.py; profiles/r04_exp_stream_assignment.txt).  This one is within 1 % of the best at
+    // (profiles/r04_exp_stream_assignment.txt).  This one is within 1 % of the best at
     // each size: 2^14 0.97 -> 0.92 ms, EdDSA 1.04 -> 0.97, 2^16 1.79 -> 1.53, 2^18 2.53 -> 2.40, 2^20 4.33 -> 4.13, 2^22
     // unchanged; the worst ones (h on stream 1, or the G2 chain on stream 2) cost a small proof 30 %.
-    // ZA_AMD_JSLOTS="0,1,2,3,4" (h, l, a, b_g1, b_g2) overrides: an experiment switch.
-    static const std::array<int, 5> job_slot_env = [] {
-        std::array<int, 5> v = {-1, 0, 0, 0, 0};
-        if (const char* e = getenv("ZA_AMD_JSLOTS")) {
-            int a[5];
-            if (sscanf(e, "%d,%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3], &a[4]) == 5) {
-                unsigned seen = 0, n_seen = 0;   // (streams 5-7 are also the later h parts': for proofs whose h job is one part)
-                for (int k = 0; k < 5; k++)
-                    if (a[k] >= 0 && a[k] <= 7 && !(seen >> a[k] & 1u)) seen |= 1u << a[k], n_seen++;
-                if (n_seen == 5) v = {a[0], a[1], a[2], a[3], a[4]};
-            }
-        }
-        return v;
-    }();
     // The streams are interchangeable (same priority, scratch memory of any kind), so the assignment is made per call: the
     // searched one for a whole proof of a lone context; streams 0-4 in order when the h multiexp or the witness multiexps
     // run on their own (a rank of a sharded proof: its four witness shards alone 1.28 ms in order, 1.62 ms the other way)
     // and when several contexts share the GPU (three provers: 9.7 against 10.3 ms per proof).
     static const std::array<int, 5> in_order = {0, 1, 2, 3, 4}, whole_proof = {3, 2, 4, 1, 0};
     const bool whole = g1[0].n != 0 && (g1[1].n != 0 || g1[2].n != 0 || g1[3].n != 0 || g2.n != 0) && live_contexts() == 1;
-    const std::array<int, 5>& job_slot = job_slot_env[0] >= 0 ? job_slot_env : whole ? whole_proof : in_order;
+    const std::array<int, 5>& job_slot = whole ? whole_proof : in_order;
     const int h_slot0 = job_slot[0];
     auto is_h_slot = [h_slot0](int k) { return k == h_slot0 || (k >= 5 && k <= 7); };
     if (!ctx->side_ready) {
@@ -2264,10 +2242,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         // lone context (2^22, four alternated pairs of processes: 11.60 / 11.84 / 11.95 / 11.85 with, 11.08 / 11.53 / 11.81 /
         // 10.87 without) and with three contexts on the GPU it produced proofs of 60-470 ms every few runs -- mixed
         // priorities over 27 streams on 8 hardware queues; equal priorities: 10.0-10.1 ms per proof, every run
-        // (profiles/r04_exp_stream_assignment.txt).  ZA_AMD_WPRIO / ZA_AMD_HPRIO remain as experiment switches.
-        int w_prio = lo_prio, h_prio = lo_prio;
-        if (const char* e = getenv("ZA_AMD_WPRIO")) w_prio = atoi(e);
-        if (const char* e = getenv("ZA_AMD_HPRIO")) h_prio = atoi(e);
+        // (profiles/r04_exp_stream_assignment.txt).
+        const int w_prio = lo_prio, h_prio = lo_prio;
         // (Confining the witness streams to 16-128 of the 256 CUs with hipExtStreamCreateWithCUMask: measured, no gain --
         // they need few CUs; what they cost the NTT pipeline is memory passes and launches, not compute units.)
         for (int k = 0; k < NS; k++)
@@ -2279,15 +2255,14 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // The h job is split into parts over consecutive base ranges (see MsmJobBase::dep): part 0 on side[0], the
     // others on side[5..].  Two parts take 0.33 ms off a 2^22 proof (three: +0.1 ms); when several contexts share the
     // GPU their proofs already fill each other's sort and reduction phases and the split costs 0.37 ms, so it is
-    // only used by a lone context.  ZA_AMD_H_PARTS overrides the count (1 = one job).
+    // only used by a lone context.  ZG_OPT_H_PARTS overrides the count (1 = one job).
     int parts = 1;
     if (g1[0].dense && g1[0].n >= ((size_t)1 << 20) && live_contexts() == 1) parts = 2;
     if (g1[0].parts > 0) parts = g1[0].parts;
     const int gates_n = g1[0].part_gate ? std::max(g1[0].parts, 1) : 0;
     // (not when the caller gates the parts on events of its own -- zg_msm_resident's scalar chunks: its part count IS
     // the chunking, and a different split would read scalars that have not arrived yet)
-    if (const char* e = getenv("ZA_AMD_H_PARTS"))
-        if (!g1[0].part_gate) parts = atoi(e);
+    if (ctx->opt_h_parts > 0 && !g1[0].part_gate) parts = ctx->opt_h_parts;
     if (parts < 1) parts = 1;
     if (parts > HP) parts = HP;
     if (g1[0].n < (size_t)parts * 4096) parts = 1;

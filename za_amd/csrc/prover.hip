@@ -789,6 +789,32 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             if (value < 0) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_TABLES_MAX_MB is negative");
             ctx->opt_tables_max_mb = (uint64_t)value;
             return ZG_OK;
+        case ZG_OPT_SMALL_LOG_N:
+            if (value < 0 || value > 24) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SMALL_LOG_N: 0 .. 24");
+            ctx->opt_small_log_n = (int)value;
+            return ZG_OK;
+        case ZG_OPT_SMALL_W_LOG_N:
+            if (value < -1 || value > 24) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SMALL_W_LOG_N: -1 .. 24");
+            ctx->opt_small_w_log_n = (int)value;
+            return ZG_OK;
+        case ZG_OPT_SORT_STAGED:
+            if (value != -1 && value != 0 && value != 2 && value != 3) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SORT_STAGED takes -1, 0, 2 or 3");
+            ctx->opt_sort_staged = (int)value;
+            return ZG_OK;
+        case ZG_OPT_PART_STAGE_MIN:
+            if (value < -1 || value > 0xffffffffll) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_PART_STAGE_MIN: -1 .. 2^32 - 1");
+            ctx->opt_part_stage_min = value;
+            return ZG_OK;
+        case ZG_OPT_SUBSET_W:
+            if (value != 4 && value != 8) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SUBSET_W takes 4 or 8");
+            ctx->opt_subset_w = (int)value;
+            return ZG_OK;
+        case ZG_OPT_COMPACT_TABLE: ctx->opt_compact_table = value != 0; return ZG_OK;
+        case ZG_OPT_H_PARTS:
+            if (value < 0 || value > Ctx::H_PARTS_MAX) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_H_PARTS: 0 .. %d", (int)Ctx::H_PARTS_MAX);
+            ctx->opt_h_parts = (int)value;
+            return ZG_OK;
+        case ZG_OPT_H_PIPE: ctx->opt_h_pipe = value != 0; return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -1118,12 +1144,7 @@ extern "C" int zg_msm_resident(zg_ctx* ctx, zg_msm_bases* b, const uint8_t* scal
     // size of the one before still arrives before the part before it is done.
     size_t bounds[5] = {0, n, n, n, n};
     if (parts == 4) {
-        int w[4] = {1, 2, 4, 8};
-        if (const char* e = getenv("ZA_AMD_MSM_CHUNKS")) {   // experiment switch: "a,b,c,d"
-            int t[4];
-            if (sscanf(e, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) == 4 && t[0] > 0 && t[1] > 0 && t[2] > 0 && t[3] > 0)
-                for (int k = 0; k < 4; k++) w[k] = t[k];
-        }
+        const int w[4] = {1, 2, 4, 8};
         const int tot = w[0] + w[1] + w[2] + w[3];
         size_t acc = 0;
         for (int k = 0; k < 3; k++) {
@@ -1794,8 +1815,12 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m, bool retr
     }
     DevBuf built;
     int rc = ZG_OK;
-    if (built.alloc(m * sizeof(G1Affine)) != hipSuccess) rc = ZG_E_HIP;   // no room: the coefficient form is used
-    if (rc == ZG_OK) rc = h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, built.as<G1Affine>());
+    try {   // (whatever ends the build -- an exception included -- must not leave the state at "being built" for ever)
+        if (built.alloc(m * sizeof(G1Affine)) != hipSuccess) rc = ZG_E_HIP;   // no room: the coefficient form is used
+        if (rc == ZG_OK) rc = h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, built.as<G1Affine>());
+    } catch (...) {
+        rc = ZG_E_HIP;
+    }
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     if (rc != ZG_OK) {
         (void)hipGetLastError();
@@ -1823,6 +1848,10 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (k != 0 && !use[k].scalars) continue;   // zg_params_prepare without a witness: only the h table
         if ((t.state == 1 && t.n == n) || t.state == -1) continue;
         if (ctx->one_shot) continue;   // no tables for a key that is used once (their state stays "not tried")
+        // While another context builds the evaluation form of this key's h query, proofs go on in the coefficient form --
+        // WITHOUT its window table: those gigabytes would never be released once zg_prove* has moved to the evaluation
+        // form, and they would shrink the budget of the tables that stay (the state remains "not tried")
+        if (k == 0 && !h_eval_form && p->h_eval_state == 2) continue;
         t.buf.release();
         t.state = -1;
         if (!(ctx->opt_tables & (1u << k))) continue;   // ZG_OPT_TABLES
@@ -1850,14 +1879,13 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         // to ~2^19 positions IF few of its scalars are "real" (a bit-heavy circuit: shard of a 2^22 proof, 3 % of 2^19) --
         // with 183 k field elements (the b queries of the 2^20 Poseidon chain) the mode's short items and wide digits cost
         // throughput: G2 accumulation 1.8 -> 2.6 ms of kernel time, the proof 8.3 -> 8.8 ms
-        const bool small = n <= msm_small_n() || (k != 0 && n <= msm_small_witness_n() && n_real <= msm_small_n());
+        const bool small = n <= msm_small_n(ctx) || (k != 0 && n <= msm_small_witness_n(ctx) && n_real <= msm_small_n(ctx));
         t.small = small;
         if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             // groups of eight positions (255 sums: 2 KB per position) where that fits, else of four (240 B per position);
-            // ZA_AMD_QUAD_W = 4 | 8: experiment switch
-            int qw = 8;
-            if (const char* e = getenv("ZA_AMD_QUAD_W")) qw = atoi(e) == 4 ? 4 : 8;
+            // (ZG_OPT_SUBSET_W = 4 | 8)
+            int qw = ctx->opt_subset_w == 4 ? 4 : 8;
             size_t entries = msm_quad_entries(n, qw);
             if (qw == 8 && (entries * elem > budget || entries >= (1ull << 31))) {
                 qw = 4;
@@ -1866,9 +1894,9 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
             // ... and behind the sums a window table over the positions that hold field elements (3 % of a SHA-like circuit,
             // fixed by the circuit): their digits then share ONE bucket set like a window-table job's -- 16 digits of 16
             // bits instead of 22 per-window digits of 12 -- gathered from a table 3 % the size of a full one (the full table was
-            // measured slower: gathers over an 8 GB footprint).  ZA_AMD_CW=0: experiment switch.
+            // measured slower: gathers over an 8 GB footprint).  ZG_OPT_COMPACT_TABLE = 0 leaves it out.
             int cw_c = 0, cw_nwin = 0;
-            const bool cw_on = !(getenv("ZA_AMD_CW") && atoi(getenv("ZA_AMD_CW")) == 0);
+            const bool cw_on = ctx->opt_compact_table;
             if (cw_on && n_real >= 1024 && budget > entries * elem &&
                 !msm_fbw_plan(n_real, n_real, budget - entries * elem, elem, &cw_c, &cw_nwin))
                 cw_c = cw_nwin = 0;
@@ -2069,7 +2097,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
     if (own_classes) ev_wit = nullptr;   // the class kernel was queued just now: gate on "everything so far"
     ctx->witness_gate_armed = false;
-    if (getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0)
+    if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
@@ -2248,17 +2276,15 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
     // The h multiexp of a large proof runs in parts (msm_batch5); in evaluation form the scalars of part k are final as
     // soon as the last transform kernel has passed them, so that kernel can be launched range by range with part k gated
-    // on its range alone (ZA_AMD_H_PIPE=1).  Measured at 2^22, A/B on one box: no difference (11.93 / 11.76 vs 11.77 /
+    // on its range alone (ZG_OPT_H_PIPE = 1).  Measured at 2^22, A/B on one box: no difference (11.93 / 11.76 vs 11.77 /
     // 11.83 ms) -- the first part's digit sort and the rest of the transform kernel want the same CUs -- so it is off.
     int h_split = 0;
-    if (const char* e = getenv("ZA_AMD_H_PIPE")) {
-        if (atoi(e) != 0 && eval_form && r->log_m >= 14) {
-            h_split = r->log_m >= 20 && live_contexts() == 1 ? 2 : 0;
-            if (const char* pe = getenv("ZA_AMD_H_PARTS")) h_split = std::min(std::max(atoi(pe), 1), (int)Ctx::H_PARTS_MAX);
-            if (h_split == 1) h_split = 0;
-        }
+    if (ctx->opt_h_pipe && eval_form && r->log_m >= 14) {
+        h_split = r->log_m >= 20 && live_contexts() == 1 ? 2 : 0;
+        if (ctx->opt_h_parts > 0) h_split = std::min(ctx->opt_h_parts, (int)Ctx::H_PARTS_MAX);
+        if (h_split == 1) h_split = 0;
     }
-    static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
+    const bool trace = trace_level() != 0;
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: classes queued      +%.3f ms\n", now_ms() - t0);
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split));
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: R1CS + H queued     +%.3f ms\n", now_ms() - t0);
@@ -2349,7 +2375,7 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     void* d_w = nullptr;
     size_t sent = 0;
     ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
-    if (getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0)
+    if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] zg_prove: witness handed over  +%.3f ms\n", now_ms() - t0);
     int rc = zg_prove_dev(ctx, p, r, d_w, r_le, s_le, proof_out);
     ctx->timings[0] = (double)sent;   // bytes uploaded (the copy is not timed separately: it is in [5])
@@ -2465,7 +2491,7 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
         for (size_t k = 0; k < 1024; k++) others += value_class(witness32 + 32 * (k * step)) == 2u;
         if (others > 82) return ZG_OK;
     }
-    static const bool trace = getenv("ZA_AMD_TRACE") && atoi(getenv("ZA_AMD_TRACE")) != 0;
+    const bool trace = trace_level() != 0;
     const double t_begin = trace ? now_ms() : 0;
     auto stamp = [&](const char* what) {
         if (trace) fprintf(stderr, "[za_amd trace] pack %-14s +%.3f ms\n", what, now_ms() - t_begin);
