@@ -117,6 +117,10 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
 #define ZG_OPT_COMPACT_TABLE 17
 #define ZG_OPT_H_PARTS 18
 #define ZG_OPT_H_PIPE 19
+/*   ZG_OPT_SHARE_SORT      1 (default): the witness queries of a proof whose window tables have one plan (the library gives
+ *                          them one where it can) share ONE digit sort over the witness positions; 0 = a sort per query.
+ *                          Read when a key's tables are built (the common plan) and per proof. */
+#define ZG_OPT_SHARE_SORT 20
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
@@ -398,6 +402,10 @@ int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size
 /* ---- timing of the last zg_prove* call on this ctx (milliseconds, host clock):
  * [0] witness bytes uploaded by zg_prove (the copy itself is part of [5]), [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
+/* ---- what the last zg_prove* call (or, for the phase API, everything since the last one) queued on the GPU:
+ * [0] kernel launches, [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
+ * sort in the last batch of multiexps (0 = a sort per query), [2], [3] reserved (0). */
+int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline
  * line.  id: 0 msm_accumulate_g1 (the witness queries' G1 jobs), 1 msm_accumulate_g2, 2 msm_digit_sort,

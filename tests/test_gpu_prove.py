@@ -1225,3 +1225,66 @@ def test_eddsa_poseidon_verifier_circuit_setup_prove_verify(ctx):
     assert za_amd.verify(pbytes, got, [kat["Ax"], kat["Ay"], kat["M"]]) is True
     assert za_amd.verify(pbytes, got, [kat["Ax"], kat["Ay"], kat["M"] + 1]) is False
     P.close(); R.close()
+
+
+@pytest.mark.parametrize("lg,bitf,n_in", [(12, 0.9, 3), (13, 0.0, 2), (17, 0.0, 2), (17, 0.5, 5)])
+def test_witness_queries_share_one_digit_sort(ctx, opts, lg, bitf, n_in):
+    """l, a, b_g1 and b_g2 multiply the same scalars: with window tables of one plan their (position, digit) pairs are sorted
+    ONCE over the witness positions and each query reads the sorted entries through its position map (msm.hip MsmShare) --
+    the a and b queries of the synthetic recipe have ragged densities (b about one half), so entries of variables outside a
+    query's density are skipped.  The shared and the per-query schedules both give the C oracle's bytes: small-job mode
+    (2^12, 2^13), a dense witness beyond it (2^17), and a mixed witness (half bits: subset-sum tables, nothing to share)."""
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, n_in, bitf, 7700 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    assert sizes[3] < sizes[1]            # the b queries do not have full density
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    r, s = 0x5151 + lg, 0x6262 + lg
+    exp = None
+    for share in (1, 0):
+        opts(za_amd.OPT_SHARE_SORT, share)
+        P = synth.synth_params(ctx, *sizes, 90 + lg)      # (the common plan is made when the tables are built)
+        if exp is None:
+            exp = co.prove(download_params(ctx, P), csr, sr.witness, r, s, threads=16)
+        for _ in range(2):
+            assert ctx.prove(P, R, sr.witness, r, s) == exp
+        mask = ctx.last_stats()["shared_sort_mask"]
+        kinds = [P.table_info(k)[0] for k in range(5)]
+        if share == 0:
+            assert mask == 0
+        elif bitf != 0.5:
+            assert mask == 0b11110, (mask, kinds)     # all four witness queries on one sort
+        P.close()
+    sr.close()
+
+
+def test_shared_digit_sort_with_sharded_keys(ctx, opts):
+    """A rank of a sharded proof sorts the variables ITS chunks of the queries span (a chunk of dense positions maps to a
+    variable range through the index lists): three shards, each with the shared sort, against the unsharded proof and
+    against the same shards with a sort per query."""
+    from za_amd import synth
+    lg = 13
+    sr = synth.SynthR1CS(lg, 3, 0.0, 5151)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    P1 = synth.synth_params(ctx, *sizes, 910)
+    d_w = ctx.upload(sr.witness)
+    r, s = 4321, 8765
+    whole = ctx.prove_dev(P1, R, d_w, r, s)
+    world = 3
+    d_h = ctx.alloc(32 * (m + world))
+    ctx.h2d(d_h, np.zeros(32 * (m + world), dtype=np.uint8))
+    ctx.prove_h_dev(R, d_w, d_h)
+    for share in (1, 0):
+        opts(za_amd.OPT_SHARE_SORT, share)
+        parts = []
+        for rank in range(world):
+            Pk = synth.synth_params(ctx, *sizes, 910, rank=rank, world=world)
+            lo, hi = Pk.shard_range(0)
+            parts.append(ctx.prove_partials_dev(Pk, R, d_w, d_h + 32 * lo))
+            assert (ctx.last_stats()["shared_sort_mask"] != 0) == (share == 1)
+        assert ctx.prove_combine(P1, np.concatenate(parts), world, r, s) == whole
+    sr.close()

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
     "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_params_h_eval_info", "zg_witness_to_device", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
-    "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings",
+    "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings", "zg_last_stats",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
@@ -136,7 +136,7 @@ OPT_ONE_SHOT, OPT_PACK, OPT_PACK_THREADS, OPT_PACK_MIN_LOG_N, OPT_PACK_PIN, OPT_
     OPT_PACK_BUDGET_PERMILLE, OPT_PACK_RAW_PERMILLE, OPT_COMBINE_EARLY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 # schedule switches (tests, fuzzer, A/B tools)
 OPT_SMALL_LOG_N, OPT_SMALL_W_LOG_N, OPT_SORT_STAGED, OPT_PART_STAGE_MIN, OPT_SUBSET_W, OPT_COMPACT_TABLE, OPT_H_PARTS, \
-    OPT_H_PIPE = 12, 13, 14, 15, 16, 17, 18, 19
+    OPT_H_PIPE, OPT_SHARE_SORT = 12, 13, 14, 15, 16, 17, 18, 19, 20
 
 
 def _options_from_env():
@@ -465,6 +465,12 @@ class Context:
         t = (C.c_double * 6)()
         self._check(self.lib.zg_last_timings(self.h, t))
         return dict(zip(("upload_bytes", "r1cs_eval_ms", "h_ms", "msm_ms", "combine_ms", "total_ms"), list(t)))
+
+    def last_stats(self):
+        """zg_last_stats: kernel launches of the last zg_prove* call, bit mask of the witness queries that shared a digit sort."""
+        st = (C.c_uint64 * 4)()
+        self._check(self.lib.zg_last_stats(self.h, st))
+        return {"launches": int(st[0]), "shared_sort_mask": int(st[1])}
 
 
 class R1CS:

@@ -48,6 +48,7 @@ struct Ctx {
     bool opt_compact_table = true;    // ZG_OPT_COMPACT_TABLE: compact window table behind the subset sums, read at table build
     int opt_h_parts = 0;              // ZG_OPT_H_PARTS: parts of the h multiexp (0 = the scheduler's choice)
     bool opt_h_pipe = false;          // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
+    bool opt_share_sort = true;       // ZG_OPT_SHARE_SORT: one digit sort for the witness queries that share a window-table plan
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev
     std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
@@ -61,7 +62,8 @@ struct Ctx {
     static constexpr int MSM_SLOTS = 8;   // 5 queries + up to 3 extra parts of the h job (main stream + 8 side streams:
                                           // more would share hardware queues)
     static constexpr int H_PARTS_MAX = 4;
-    struct MsmScratch* msm_scratch[MSM_SLOTS] = {nullptr};
+    struct MsmScratch* msm_scratch[MSM_SLOTS + 1] = {nullptr};   // [MSM_SLOTS]: the shared digit sort of the witness queries
+    hipEvent_t share_ev = nullptr;                                // "the shared sort's item arrays are final"
     hipStream_t side[MSM_SLOTS] = {nullptr};
     hipEvent_t side_ev = nullptr;
     hipEvent_t part_ev[2 * H_PARTS_MAX] = {nullptr};   // (sorted, accumulated) per part of the h job
@@ -71,6 +73,12 @@ struct Ctx {
     hipEvent_t tm_ev[3] = {nullptr, nullptr, nullptr};  // timing of the H pipeline inside zg_prove_dev: start, R1CS evaluation done, H done
     bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
+    // zg_last_stats: kernel launches since the counter was last cleared (zg_prove* clear it on entry; the helper threads
+    // of a proof only run host arithmetic, every launch comes from the calling thread), queries of the last multiexp batch
+    // that shared one digit sort (bit k = query k)
+    uint64_t n_launches = 0;
+    unsigned last_share_mask = 0;
+    bool stats_keep = false;   // zg_prove / zg_prove_packed cleared the counter for the zg_prove_dev they are about to call
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
@@ -124,6 +132,13 @@ struct ProfScope {
         if (_e != hipSuccess)                                                                  \
             return ::zg::fail((ctx), ZG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                               __FILE__, __LINE__);                                             \
+    } while (0)
+
+// every kernel launch of the product path goes through here: zg_last_stats reports the count per proof
+#define ZG_LAUNCH(ctxp, ...)                 \
+    do {                                     \
+        (ctxp)->n_launches++;                \
+        hipLaunchKernelGGL(__VA_ARGS__);     \
     } while (0)
 
 #define ZG_TRY(expr)                \
@@ -214,8 +229,23 @@ int msm_compact_reals_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_sc
 int msm_compact_reals_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
                          uint32_t* d_rank, G2Affine* d_compact, uint64_t* n_real);
 // the five multiexps of create_proof (h, l, a, b_g1 over G1; b_g2 over G2), run concurrently
+// One digit sort for several witness queries (msm.hip ShQuery): l, a, b_g1 and b_g2 multiply the same scalars w_j, so the
+// (position, digit) pairs are sorted once over the witness positions [pos0, pos0 + n) and every query in `mask` (bit k: query
+// k, 1 = l .. 4 = b_g2; each with a window table of THIS plan) accumulates over that list through its own position map.
+struct MsmShare {
+    unsigned mask = 0;
+    const uint32_t* scalars = nullptr;   // the witness from position pos0 on
+    const uint8_t* cls = nullptr;        // its class bytes (MsmDesc::cls) from pos0 on, or NULL
+    size_t n = 0;                        // positions; at most 2^26
+    int c = 0, nwin = 0;                 // the common window-table plan
+    int small = 0;                       // the queries run in small-job mode (all of them do, or none)
+    struct Q {
+        const uint32_t* rank = nullptr;  // [n] position - pos0 -> index in the whole query, ~0 = not in its density; NULL = identity
+        uint32_t sub = 0;                // subtracted from that index: the first one this shard holds (or, for NULL, the position of index 0)
+    } q[5];
+};
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
-               hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr);
+               hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr, const MsmShare* share = nullptr);
 void msm_scratch_free(Ctx* ctx);
 
 // ---- ntt.hip

@@ -19,6 +19,11 @@ struct zg_r1cs {
     uint32_t n_long[3] = {0, 0, 0};
     // dense position -> flat variable index for the a and b queries
     zg::DevBuf a_index, b_index;
+    // the inverse maps: variable -> dense position in the a / b query, ~0 = not in its density (empty = full density: the
+    // identity); host copies of the index lists give a sharded key's variable range
+    zg::DevBuf a_rank, b_rank;
+    std::vector<uint32_t> a_index_host, b_index_host;
+    uint32_t a_first = 0, b_first = 0;
     uint64_t n_a = 0, n_b = 0;
     uint64_t a_aux_total = 0, b_in_total = 0, b_aux_total = 0;
     std::vector<uint32_t> var_of_signal;   // only for circuits loaded from a za proving key
@@ -54,6 +59,9 @@ struct zg_params {
     };
     mutable Fbw fbw[5];
     mutable std::mutex fbw_mu;
+    // the common plan of the witness queries' window tables (ensure_tables): queries with it share one digit sort per proof
+    mutable int w_plan_c = 0, w_plan_nwin = 0;
+    mutable bool w_plan_small = false;
     // The h query in evaluation form (heval.hip): m affine points that go with h_eval_dev's scalars, built once per key
     // (unsharded keys only) together with their own window table.  state as in Fbw.
     // A sharded key (world > 1) holds the positions [h_eval_lo, h_eval_hi) of the m-point array -- chunk `rank` of

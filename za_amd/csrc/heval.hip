@@ -89,10 +89,10 @@ int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log
     ZG_HIP(ctx, work.alloc(m * sizeof(G1XYZZ)));
     G1XYZZ* D = work.as<G1XYZZ>();
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_heval_init, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_h, m - 1, m, gi_lo, gi_hi_int, lo_bits, D);
+    ZG_LAUNCH(ctx, k_heval_init, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_h, m - 1, m, gi_lo, gi_hi_int, lo_bits, D);
     for (int s = (int)log_m - 1; s >= 0; s--)
-        hipLaunchKernelGGL(k_heval_stage, dim3((unsigned)((m / 2 + 255) / 256)), dim3(256), 0, st, D, (int)log_m, s, tw_inv);
-    hipLaunchKernelGGL(k_heval_affine, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, D, m, d_out);
+        ZG_LAUNCH(ctx, k_heval_stage, dim3((unsigned)((m / 2 + 255) / 256)), dim3(256), 0, st, D, (int)log_m, s, tw_inv);
+    ZG_LAUNCH(ctx, k_heval_affine, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, D, m, d_out);
     ZG_HIP(ctx, hipGetLastError());
     ZG_HIP(ctx, hipStreamSynchronize(st));   // `work` is freed on return
     return ZG_OK;

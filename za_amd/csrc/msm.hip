@@ -1253,14 +1253,32 @@ __global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------------ stage 1
 // L / LP: the lazy arithmetic and the lanes per point -- (Fq2PL, 2) runs a G2 point on a lane pair (ecd.h): half the
 // dependent instruction stream per addition, which is what a latency-bound job's chain is made of.
-template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+// Shared digit sort (MsmJobBase::src): the witness queries l, a, b_g1, b_g2 multiply the SAME scalars w_j, so their
+// (position, digit) pairs are sorted ONCE, over the witness positions, and every query accumulates over that one list.  An
+// entry then names (position j, table row w) -- SH_POS_BITS bits of position, the row above them, the sign in bit 31 --
+// and the query maps j to its own dense index: through its rank map (a, b: position -> index in the query, ~0 = the
+// variable is not in the query's density: the entry is skipped) or by an offset (l: the aux variables in order).
+static constexpr int SH_POS_BITS = 26;
+struct ShQuery {
+    const uint32_t* rank;   // [positions of the sort] or NULL (identity)
+    uint32_t sub, nq;       // index = rank[j] - sub, valid below nq (= the query's points and its table's row stride)
+};
+__device__ __forceinline__ uint32_t sh_index(uint32_t e, const ShQuery& q) {
+    const uint32_t j = e & ((1u << SH_POS_BITS) - 1u), w = (e >> SH_POS_BITS) & 31u;
+    uint32_t r = q.rank ? q.rank[j] : j;
+    r -= q.sub;   // (~0 - sub stays above nq: sub + nq < 2^31)
+    return r < q.nq ? w * q.nq + r : 0xffffffffu;
+}
+
+template <class F, class L = typename LazyOf<F>::L, int LP = 1, bool SH = false>
 __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict__ bases,
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ item_off,
                                                     const uint32_t* __restrict__ item_key,
                                                     const uint32_t* __restrict__ perm, uint32_t nkeys,
-                                                    uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial) {
+                                                    uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial,
+                                                    ShQuery shq) {
     uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LP;
     if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
     if (perm) t = perm[t];              // items in order of decreasing length
@@ -1271,7 +1289,44 @@ __global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict_
     uint32_t end = offsets[key + 1];
     if (end > start + Tk) end = start + Tk;
     XYZZd<L> acc = XYZZd<L>::inf();
-    if constexpr (sizeof(F) == sizeof(Fq)) {
+    if constexpr (SH && sizeof(F) == sizeof(Fq) && LP == 1) {
+        // the same software pipeline one stage deeper: entry k + 3 and the rank of entry k + 2 are in flight with the base of
+        // entry k + 1 while point k is added
+        if (start < end) {
+            uint32_t e0 = sorted[start];
+            uint32_t e1 = start + 1 < end ? sorted[start + 1] : 0u;
+            uint32_t e2 = start + 2 < end ? sorted[start + 2] : 0u;
+            uint32_t i0 = sh_index(e0, shq);
+            uint32_t i1 = start + 1 < end ? sh_index(e1, shq) : 0xffffffffu;
+            Affine<F> cur = bases[i0 != 0xffffffffu ? i0 : 0u];
+            for (uint32_t k = start; k < end; k++) {
+                Affine<F> nxt = cur;
+                if (i1 != 0xffffffffu) nxt = bases[i1];
+                const uint32_t i2 = k + 2 < end ? sh_index(e2, shq) : 0xffffffffu;
+                const uint32_t e3 = k + 3 < end ? sorted[k + 3] : 0u;
+                if (i0 != 0xffffffffu) {
+                    AffD<L> p = AffD<L>::load(&cur);
+                    if (e0 >> 31) p = p.negated_lazy();
+                    acc = acc.add_mixed(p);
+                }
+                cur = nxt;
+                i0 = i1;
+                i1 = i2;
+                e0 = e1;
+                e1 = e2;
+                e2 = e3;
+            }
+        }
+    } else if constexpr (SH) {
+        for (uint32_t k = start; k < end; k++) {
+            const uint32_t e = sorted[k];
+            const uint32_t i = sh_index(e, shq);
+            if (i == 0xffffffffu) continue;   // (uniform over the LP lanes of a point: they hold the same entry)
+            AffD<L> p = AffD<L>::load(&bases[i]);
+            if (e >> 31) p = p.negated_lazy();
+            acc = acc.add_mixed(p);
+        }
+    } else if constexpr (sizeof(F) == sizeof(Fq)) {
         // Software pipeline: the gather of point k+1 (index two steps ahead) is in flight while point k is added, so the
         // ~1 us of dependent load latency (sorted[k] -> bases[...]) hides behind the ~5 us mixed addition instead of
         // parking the wave (SQ_WAIT_ANY was 13 % of the wave cycles).  16 more VGPRs; G2 has none to spare.
@@ -1535,6 +1590,22 @@ struct MsmJobBase {
     bool launched = false;   // phase_b has run (its events are recorded)
     bool eager = false;      // phase_a leaves nothing to wait for (dense jobs): phase_b is queued right behind it
     bool witness = false;    // one of the proof's witness multiexps (run_jobs' on_witness fires when the last of them is done)
+    // Shared digit sort (see ShQuery): a job with `src` set runs no sort of its own -- it accumulates over the sorted entries,
+    // bucket offsets and items of `src`, a sort-only job over the witness positions, through its rank map.  The fields below
+    // are what such followers (of either group) read from the sorter once its phases have run on the host.
+    MsmJobBase* src = nullptr;
+    bool sort_only = false;
+    bool c_launched = false;          // phase_c has run on the host: the item arrays are queued, the totals below are set
+    hipEvent_t ev_items = nullptr;    // recorded behind the last kernel that writes the item arrays
+    MsmScratch* Sb = nullptr;         // this job's scratch (the sorter's: sorted / offsets / item_off / item_key / perm)
+    MsmPlan P{};
+    size_t n_pos = 0;                 // points (positions) of this job's own sort
+    uint32_t ones_key = 0, nkeys = 0;
+    uint32_t t_ones = T_ONES, t_pack = 0;   // item sizes (regular | ones << 16) as the kernels take them
+    uint32_t heavy_items = HEAVY_ITEMS;     // buckets of more items go through k_heavy_fold
+    bool order_items = true;          // items sorted by length before the accumulation (not for small jobs)
+    bool eager_small = false;         // (see MsmJob)
+    uint32_t total_items_h = 0, ones_lo_h = 0, ones_hi_h = 0;   // what phase_c launched with
 };
 
 // Which arithmetic the latency-bound kernels of a job run: G1 one lane per point; G2 a lane PAIR per point (ecd.h Fq2PL).
@@ -1556,7 +1627,9 @@ struct MsmJob : MsmJobBase {
     // chain is queued at once like a dense job's -- no classification or totals read-back -- but it keeps the ones
     // bucket (a bit-heavy witness would otherwise pile its ones onto one bucket of window 0), reduced on the device
     // by k_ones_sum from the device-side item range.
-    bool eager_small = false;
+    // (eager_small: in MsmJobBase)
+    ShQuery shq{nullptr, 0u, 0u};     // follower of a shared sort: how this query reads the sorter's entries
+    bool fbw_virtual = false;         // sort-only job: the window-table plan (fbw_c, fbw_nwin, fbw_stride) without a table
     const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
     uint32_t quad_base = 0;   // entry (relative to quad_table) of group 0's sums; 0 = n (the job covers the whole query)
     int quad_w = 4;           // positions per subset-sum group (4 or 8)
@@ -1573,16 +1646,11 @@ struct MsmJob : MsmJobBase {
     int fbw_c = 0, fbw_nwin = 0;
     size_t fbw_stride = 0;
     uint32_t items_bound = 0;      // dense jobs: upper bound used instead of the read-back total
-    uint32_t heavy_items = HEAVY_ITEMS;   // buckets of more items go through k_heavy_fold
     bool ones_in_levels = false;          // small jobs: the ones bucket's item sums are a row of the reduction levels
-    bool order_items = true;       // items sorted by length before the accumulation (not for small jobs)
     static constexpr uint32_t ITEM_ORDER_MIN = 16384;
     static constexpr size_t QUAD_ACC_MAX_LANES = 262144;    // four-lane mixed additions: launches of up to this many lanes
     static constexpr size_t QUAD_LEVEL_MAX_LANES = 32768;   // four-lane additions in the reduction: levels of up to this many logical lanes
     int acc_prof = -1;
-    MsmPlan P{};
-    uint32_t ones_key = 0, nkeys = 0;
-    uint32_t t_ones = T_ONES, t_pack = 0;   // item sizes (regular | ones << 16) as the kernels take them
     int grid = 1;
     const XYZZ<F>* ones_ptr = nullptr;
     int red_nlev = 0, red_f[16], red_bitbase[16];   // bit-plane reduction levels (bits folded per level)
@@ -1594,12 +1662,19 @@ struct MsmJob : MsmJobBase {
            size_t n_, XYZZ<F>* o)
         : ctx(c), S(scratch), d_bases(b), d_scalars(sc), d_index(idx), n(n_), out(o) {
         st = stream;
+        Sb = &scratch;
+        n_pos = n_;
         *out = XYZZ<F>::inf();
         if (n == 0) done = true;
     }
 
     int phase_a() override {
         if (done) return ZG_OK;
+        if (src) {   // nothing to classify or sort: the sorter's phases carry this job
+            eager = src->eager;
+            if (!S.host) ZG_HIP(ctx, hipHostMalloc((void**)&S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
+            return ZG_OK;
+        }
         if (n >= (1ull << 31)) return fail(ctx, ZG_E_INVALID_ARG, "msm: n = %zu exceeds 2^31-1", n);
         if (!S.host) ZG_HIP(ctx, hipHostMalloc((void**)&S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
         grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 4);
@@ -1612,7 +1687,7 @@ struct MsmJob : MsmJobBase {
         }
         ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
         ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
-        hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8,
+        ZG_LAUNCH(ctx, k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8,
                            cw_rank);
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 12, hipMemcpyDeviceToHost, st));
         return ZG_OK;
@@ -1621,6 +1696,19 @@ struct MsmJob : MsmJobBase {
     int phase_b() override {
         if (done) {
             launched = true;
+            return ZG_OK;
+        }
+        if (src) {   // (run_jobs calls this once the sorter's phase_b has run)
+            launched = true;
+            if (src->done) {   // every scalar is zero
+                done = true;
+                return ZG_OK;
+            }
+            if (src->chained) {   // the sorter queued its item arrays too: this job's whole chain follows now
+                chained = true;
+                items_bound = src->total_items_h;
+                return phase_c();
+            }
             return ZG_OK;
         }
         const uint32_t* cls = reinterpret_cast<const uint32_t*>(S.host);
@@ -1633,8 +1721,9 @@ struct MsmJob : MsmJobBase {
             return ZG_OK;
         }
         if (dep && dep->ev_sorted) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_sorted, 0));
-        use_cw = cw_rank && !fbw_table && !dense && !eager_small && cls[2] == 0 && n_real > 0;
-        P = fbw_table ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : use_cw ? plan_fbw_for(cw_c, cw_nwin, n_real) : plan_msm(n_real, n_ones);
+        const bool has_fbw = fbw_table || fbw_virtual;
+        use_cw = cw_rank && !has_fbw && !dense && !eager_small && cls[2] == 0 && n_real > 0;
+        P = has_fbw ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : use_cw ? plan_fbw_for(cw_c, cw_nwin, n_real) : plan_msm(n_real, n_ones);
         {   // Small jobs are latency bound: a thread runs its item's mixed adds one after the other (64 G2 adds are
             // 1.1 ms whatever n is).  Below ~64K items the items are shortened -- down to half the mean bucket load, so
             // that only buckets above twice the mean need the heavy-bucket fold -- and the GPU gets more, shorter threads.
@@ -1732,20 +1821,20 @@ struct MsmJob : MsmJobBase {
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = use_cw ? cw_n : P.kw == 1 ? (uint32_t)fbw_stride : 0u;
         const uint32_t* rank = use_cw ? cw_rank : (const uint32_t*)nullptr;
-        const uint32_t quad_n = quad_table && !fbw_table && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
+        const uint32_t quad_n = quad_table && !has_fbw && !dense ? (quad_base ? quad_base : (uint32_t)n) : 0u;
         const int use_ones_bin = dense ? 0 : 1;   // a dense job's chained phase_c has no ones bucket (see k_part)
-        hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
+        ZG_LAUNCH(ctx, k_part<0>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                            quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr, use_ones_bin,
                            d_cls, quad_w, rank, cw_off);
         // exclusive scan of a u32 table of tn entries in place (+ the total in entry tn)
         auto xscan = [&](uint32_t* tab, size_t tn) -> int {
             const uint32_t nbx = (uint32_t)((tn + 1 + SCAN_TILE - 1) / SCAN_TILE);
             if (tn + 1 <= SCAN_ONE_MAX) {
-                hipLaunchKernelGGL(k_xscan_one, dim3(1), dim3(SCAN_THREADS), 0, st, tab, tn);
+                ZG_LAUNCH(ctx, k_xscan_one, dim3(1), dim3(SCAN_THREADS), 0, st, tab, tn);
             } else {
-                hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
-                hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
-                hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
+                ZG_LAUNCH(ctx, k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
+                ZG_LAUNCH(ctx, k_xscan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nbx);
+                ZG_LAUNCH(ctx, k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, tab, tn, S.bsum.as<uint32_t>());
             }
             return ZG_OK;
         };
@@ -1768,50 +1857,50 @@ struct MsmJob : MsmJobBase {
                 ZG_HIP(ctx, S.tab2.reserve((n2 + 1) * 4));
                 ZG_HIP(ctx, S.abuf2.reserve(max_entries * 8));
             }
-            hipLaunchKernelGGL(k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
+            ZG_LAUNCH(ctx, k_part_staged, dim3(ntiles), dim3(256), lds_s, st, d_scalars, d_index, n, P.c, P.nwin, P.kw,
                                vstride, quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(),
                                S.sorted.as<uint32_t>(), use_ones_bin, d_cls, b2 > 0 ? S.p2m.as<uint32_t>() : (uint32_t*)nullptr, quad_w,
                                rank, cw_off);
             if (b2 > 0) {
-                hipLaunchKernelGGL(k_p2<0>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
+                ZG_LAUNCH(ctx, k_p2<0>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
                                    nb1, b2, 7, S.tab2.as<uint32_t>(), (uint2*)nullptr);
                 ZG_TRY(xscan(S.tab2.as<uint32_t>(), n2));
-                hipLaunchKernelGGL(k_p2<1>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
+                ZG_LAUNCH(ctx, k_p2<1>, dim3((unsigned)maxchunks), dim3(256), 0, st, S.abuf.as<uint2>(), S.p2m.as<uint32_t>(),
                                    nb1, b2, 7, S.tab2.as<uint32_t>(), S.abuf2.as<uint2>());
-                hipLaunchKernelGGL(k_part_local, dim3(nbins3), dim3(1024), lds2, st, S.abuf2.as<uint2>(), (const uint32_t*)nullptr,
+                ZG_LAUNCH(ctx, k_part_local, dim3(nbins3), dim3(1024), lds2, st, S.abuf2.as<uint2>(), (const uint32_t*)nullptr,
                                    0u, nbins3, lb3, stage_min, S.counts.as<uint32_t>(), S.sorted.as<uint32_t>(),
                                    S.p2m.as<uint32_t>(), S.tab2.as<uint32_t>(), nb1, b2, single_max);
             } else {
-                hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
+                ZG_LAUNCH(ctx, k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                                    S.tile_tab.as<uint32_t>(), ntiles, nbins, lb3, stage_min, S.counts.as<uint32_t>(),
                                    S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, single_max);
             }
         } else {
-            hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
+            ZG_LAUNCH(ctx, k_part<1>, dim3(ntiles), dim3(256), lds1, st, d_scalars, d_index, n, P.c, P.nwin, P.kw, vstride,
                                quad_n, hb, lb, ntiles, tp, S.tile_tab.as<uint32_t>(), S.abuf.as<uint2>(), S.sorted.as<uint32_t>(),
                                use_ones_bin, d_cls, quad_w, rank, cw_off);
             // k_part<1> advanced only its LDS copy of the offsets, so tile_tab still holds the segment starts
-            hipLaunchKernelGGL(k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
+            ZG_LAUNCH(ctx, k_part_local, dim3(nbins), dim3(1024), lds2, st, S.abuf.as<uint2>(),
                                S.tile_tab.as<uint32_t>(), ntiles, nbins, lb, stage_min, S.counts.as<uint32_t>(),
                                S.sorted.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0, single_max);
         }
         // bucket offsets and item offsets from the counts; nkeys + 1 entries so entry nkeys gets the totals
         const uint32_t nb = (nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE;
         if ((size_t)nkeys + 1 <= SCAN_ONE_MAX) {
-            hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+            ZG_LAUNCH(ctx, k_scan_one, dim3(1), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
                                S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>());
         } else {
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+            ZG_LAUNCH(ctx, k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
                                S.bsum.as<uint32_t>(), nb);
-            hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
-            hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
+            ZG_LAUNCH(ctx, k_scan_bsums, dim3(1), dim3(256), 0, st, S.bsum.as<uint32_t>(), nb);
+            ZG_LAUNCH(ctx, k_scan_final, dim3(nb), dim3(SCAN_THREADS), 0, st, S.counts.as<uint32_t>(), nkeys, t_pack,
                                S.bsum.as<uint32_t>(), nb, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
                                (uint32_t*)nullptr);
         }
         // the totals come back to the host for the jobs that plan their last phase from them -- a job queued whole only
         // needs them for the profile's unit count
         if (!(dense || eager_small) || ctx->prof_enabled) {
-            hipLaunchKernelGGL(k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
+            ZG_LAUNCH(ctx, k_meta, dim3(1), dim3(64), 0, st, S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(), nkeys,
                                S.meta.as<uint32_t>());
             ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.p, 16, hipMemcpyDeviceToHost, st));
         }
@@ -1831,23 +1920,49 @@ struct MsmJob : MsmJobBase {
         if (done) return ZG_OK;
         if (chained && !items_bound) return ZG_OK;   // already queued by phase_b
         const uint32_t* meta = reinterpret_cast<const uint32_t*>(S.host);
-        const uint32_t total_items = items_bound ? items_bound : meta[1];
-        const uint32_t ones_lo = items_bound ? 0 : meta[2], ones_hi = items_bound ? 0 : meta[3];
+        uint32_t total_items, ones_lo, ones_hi;
+        if (src) {   // the sorter's plan and totals (run_jobs calls this once the sorter's phase_c has run on the host)
+            if (src->done) {
+                done = true;
+                return ZG_OK;
+            }
+            P = src->P;
+            nkeys = src->nkeys;
+            ones_key = src->ones_key;
+            t_ones = src->t_ones;
+            t_pack = src->t_pack;
+            heavy_items = src->heavy_items;
+            order_items = src->order_items;
+            eager_small = src->eager_small;
+            total_items = src->total_items_h;
+            ones_lo = src->ones_lo_h;
+            ones_hi = src->ones_hi_h;
+        } else {
+            total_items = items_bound ? items_bound : meta[1];
+            ones_lo = items_bound ? 0 : meta[2];
+            ones_hi = items_bound ? 0 : meta[3];
+        }
         items_bound = 0;
         if (total_items == 0) {
             done = true;
+            c_launched = true;
             return ZG_OK;
         }
+        MsmScratch& SS = src ? *src->Sb : S;   // whose sorted entries / offsets / items this job accumulates over
+        const size_t n_sort = src ? src->n_pos : n;
         trace_point("phase_c enter");
-        ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
-        ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
+        if (!src) ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
+        if (!sort_only) ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
         trace_point("phase_c reserved items");
-        {
+        // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] claimed per size (k_item_scatter), [1] the heavy-bucket counter
+        ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
+        if (src) {
+            ZG_HIP(ctx, hipMemsetAsync(S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES, 0, 4, st));   // (its own heavy-bucket counter)
+            ZG_HIP(ctx, hipStreamWaitEvent(st, src->ev_items, 0));
+        } else {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
-            // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] claimed per size (k_item_scatter), [1] the heavy-bucket counter
-            ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
             uint32_t* hist = S.ihist.as<uint32_t>();
-            hipLaunchKernelGGL(k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
+            ZG_LAUNCH(ctx, k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
                                nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0, hist, 2 * ITEM_CLASSES + 1);
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
@@ -1858,17 +1973,26 @@ struct MsmJob : MsmJobBase {
             if (order_items) {
                 ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
                 const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
-                hipLaunchKernelGGL(k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
+                ZG_LAUNCH(ctx, k_item_hist, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
                                    S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist);
-                hipLaunchKernelGGL(k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
+                ZG_LAUNCH(ctx, k_item_scatter, dim3(ib), dim3(256), 0, st, S.item_key.as<uint32_t>(),
                                    S.item_off.as<uint32_t>(), S.offsets.as<uint32_t>(), nkeys, t_pack, ones_key, hist,
                                    hist + ITEM_CLASSES, S.perm.as<uint32_t>());
             }
         }
+        total_items_h = total_items;
+        ones_lo_h = ones_lo;
+        ones_hi_h = ones_hi;
+        if (sort_only) {   // the followers (queued on their own streams behind ev_items) do the rest
+            ZG_HIP(ctx, hipGetLastError());
+            ZG_HIP(ctx, hipEventRecord(ev_items, st));
+            c_launched = true;
+            return ZG_OK;
+        }
         {
             if (dep && dep->ev_acc) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_acc, 0));
             ProfScope ps(ctx, IS_G1 ? (dense ? PROF_MSM_ACC_G1_DENSE : PROF_MSM_ACC_G1) : PROF_MSM_ACC_G2, n * ALG_BYTES, st,
-                         chained ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
+                         chained || src ? 0 : meta[0]);  // units: mixed adds (a chained job fills them in at finish())
             acc_prof = ps.idx;
             using CL = typename ChainCfg<F>::L;
             constexpr int CLP = ChainCfg<F>::LP;
@@ -1877,25 +2001,30 @@ struct MsmJob : MsmJobBase {
             // of one lane per point (one wave) by more than the operand exchange costs -- dense 2^22 witness: G2
             // accumulation 18.4 -> 15.8 ms of kernel time, proof 33.5 -> 32.9 ms.
             const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
-            const uint32_t* acc_perm = order_items ? S.perm.as<uint32_t>() : (const uint32_t*)nullptr;
+            const uint32_t* acc_perm = order_items ? SS.perm.as<uint32_t>() : (const uint32_t*)nullptr;
             // A small G1 job's accumulation is a chain of T dependent mixed additions per item on a nearly idle GPU: every
             // addition then runs on four lanes (ecd.h add_mixed_quad: four rounds of one product instead of ten serial ones).
             // Largest such launch: QUAD_ACC_MAX_LANES lanes.
             bool quad_acc = false;
             if constexpr (IS_G1) quad_acc = (eager_small || n <= msm_small_n(ctx)) && (size_t)total_items * 4 <= QUAD_ACC_MAX_LANES;
+            // (SH: this job reads the entries of a shared sort through its rank map, see ShQuery)
+            auto launch_acc = [&](auto kern, unsigned lanes_per_item) {
+                ZG_LAUNCH(ctx, kern, dim3((unsigned)(((size_t)total_items * lanes_per_item + 255) / 256)), dim3(256), 0, st,
+                                   acc_bases, SS.sorted.as<uint32_t>(), SS.offsets.as<uint32_t>(), SS.item_off.as<uint32_t>(),
+                                   SS.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>(), shq);
+            };
             if (quad_acc) {
-                if constexpr (IS_G1)
-                    hipLaunchKernelGGL((k_accumulate<F, FqQL, 4>), dim3((unsigned)(((size_t)total_items * 4 + 255) / 256)), dim3(256), 0, st,
-                                       acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                                       S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
-            } else if (CLP > 1)
-                hipLaunchKernelGGL((k_accumulate<F, CL, CLP>), dim3((unsigned)(((size_t)total_items * CLP + 255) / 256)), dim3(256), 0, st,
-                                   acc_bases, S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                                   S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
-            else
-                hipLaunchKernelGGL((k_accumulate<F>), dim3((total_items + 255) / 256), dim3(256), 0, st, acc_bases,
-                                   S.sorted.as<uint32_t>(), S.offsets.as<uint32_t>(), S.item_off.as<uint32_t>(),
-                                   S.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>());
+                if constexpr (IS_G1) {
+                    if (src) launch_acc(k_accumulate<F, FqQL, 4, true>, 4);
+                    else launch_acc(k_accumulate<F, FqQL, 4, false>, 4);
+                }
+            } else if (CLP > 1) {
+                if (src) launch_acc(k_accumulate<F, CL, CLP, true>, CLP);
+                else launch_acc(k_accumulate<F, CL, CLP, false>, CLP);
+            } else {
+                if (src) launch_acc(k_accumulate<F, typename LazyOf<F>::L, 1, true>, 1);
+                else launch_acc(k_accumulate<F, typename LazyOf<F>::L, 1, false>, 1);
+            }
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
         trace_point("phase_c accumulate queued");
@@ -1909,7 +2038,7 @@ struct MsmJob : MsmJobBase {
             XYZZ<F>* ones_out = nullptr;
             // (a small job's ones bucket has at most n / t_ones + 1 items: if they fit a row of the leaf level they are
             // summed there, see k_bits_level)
-            ones_in_levels = eager_small && P.c >= 2 && n / t_ones + 1 <= P.B;
+            ones_in_levels = eager_small && P.c >= 2 && n_sort / t_ones + 1 <= P.B;
             const bool fold_ones = eager_small && !ones_in_levels;
             if (fold_ones) {
                 ZG_HIP(ctx, S.ones[0].reserve(sizeof(XYZZ<F>)));
@@ -1917,11 +2046,11 @@ struct MsmJob : MsmJobBase {
                 ZG_HIP(ctx, hipMemsetAsync(ones_out, 0, sizeof(XYZZ<F>), st));   // all zero = the identity
             }
             const uint32_t listed = fold_ones ? nkeys : P.nkeys;
-            hipLaunchKernelGGL(k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
+            ZG_LAUNCH(ctx, k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, SS.item_off.as<uint32_t>(),
                                listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist);
-            hipLaunchKernelGGL((k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024), dim3(128 * ChainCfg<F>::LP),
+            ZG_LAUNCH(ctx, (k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024), dim3(128 * ChainCfg<F>::LP),
                                128 * sizeof(XYZZ<F>), st,
-                               S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
+                               S.partial.as<XYZZ<F>>(), SS.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
                                ones_out);
         }
         const int bits = P.c - 1;
@@ -1949,15 +2078,15 @@ struct MsmJob : MsmJobBase {
                 if constexpr (IS_G1) quad = groups * 2 <= QUAD_LEVEL_MAX_LANES;
                 if (quad) {
                     if constexpr (IS_G1)
-                        hipLaunchKernelGGL((k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
+                        ZG_LAUNCH(ctx, (k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
                                            dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, cur, S.partial.as<XYZZ<F>>(),
-                                           S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l], heavy_items,
+                                           SS.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l], heavy_items,
                                            l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
                 } else {
-                    hipLaunchKernelGGL((k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
+                    ZG_LAUNCH(ctx, (k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
                                        dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
                                        dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
-                                       S.partial.as<XYZZ<F>>(), S.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
+                                       S.partial.as<XYZZ<F>>(), SS.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
                                        heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
                 }
                 cur = outp;
@@ -1987,7 +2116,7 @@ struct MsmJob : MsmJobBase {
                 O.rows[0] = 1;
                 O.chunks[0] = (cnt + ROWSUM_CH - 1) / ROWSUM_CH;
                 ZG_HIP(ctx, S.ones[pp].reserve((size_t)O.chunks[0] * sizeof(XYZZ<F>)));
-                hipLaunchKernelGGL((k_rowsum<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(O.chunks[0]),
+                ZG_LAUNCH(ctx, (k_rowsum<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(O.chunks[0]),
                                    dim3(256 * ChainCfg<F>::LP), 256 * sizeof(XYZZ<F>), st, in, O,
                                    S.ones[pp].as<XYZZ<F>>());
                 in = S.ones[pp].template as<XYZZ<F>>();
@@ -2012,8 +2141,12 @@ struct MsmJob : MsmJobBase {
 
     int finish() override {
         if (done) return ZG_OK;
+        if (sort_only) {
+            done = true;
+            return ZG_OK;
+        }
         const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(S.host + 64);
-        if (chained && acc_prof >= 0) {
+        if (chained && acc_prof >= 0 && !src) {
             std::lock_guard<std::mutex> lock(ctx->prof_mu);
             if (acc_prof < (int)ctx->prof_pending.size())
                 ctx->prof_pending[acc_prof].units = reinterpret_cast<const uint32_t*>(S.host)[0];
@@ -2098,7 +2231,7 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<
                 // A dense job's whole chain is known on the host: queue it now, behind the stream's event gate, so the
                 // GPU starts it the moment the NTT pipeline is done -- not when the host gets round to it (a 2^14
                 // proof waited 0.9 ms here while the host was queueing the witness jobs' phases).
-                if (jobs[j]->eager && (!jobs[j]->dep || jobs[j]->dep->launched)) {
+                if (jobs[j]->eager && (!jobs[j]->dep || jobs[j]->dep->launched) && (!jobs[j]->src || jobs[j]->src->launched)) {
                     const double tb2 = tnow();
                     if (trace) (void)hipEventRecord(tev[j][0], jobs[j]->st);
                     ZG_TRY(jobs[j]->phase_b());
@@ -2110,6 +2243,9 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<
             }
             if (state[j] == 3 && launches_pending) continue;
             if (state[j] == 1 && jobs[j]->dep && !jobs[j]->dep->launched) continue;   // parts launch in order
+            // a follower of a shared sort moves when the sorter has: phase_b behind its phase_b, phase_c behind its phase_c
+            if (state[j] == 1 && jobs[j]->src && !jobs[j]->src->launched) continue;
+            if (state[j] == 2 && jobs[j]->src && !(jobs[j]->src->c_launched || jobs[j]->src->done)) continue;
             hipError_t q = hipStreamQuery(jobs[j]->st);
             if (q == hipErrorNotReady) continue;
             if (q != hipSuccess) return fail(ctx, ZG_E_HIP, "stream query failed: %s", hipGetErrorString(q));
@@ -2213,7 +2349,7 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
 }
 
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
-               hipEvent_t ev_h) {
+               hipEvent_t ev_h, const MsmShare* share) {
     constexpr int NS = Ctx::MSM_SLOTS, HP = Ctx::H_PARTS_MAX;
     // slots: 0-4 the five queries (job_slot below) | 5-7 further h parts
     // Which of the side streams 0-4 each of h (its first part), l, a, b_g1, b_g2 runs on.  HIP streams are backed by hardware
@@ -2249,6 +2385,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         for (int k = 0; k < NS; k++)
             ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? h_prio : w_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->share_ev, hipEventDisableTiming));
         for (int k = 0; k < 2 * HP; k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
         ctx->side_ready = true;
     }
@@ -2282,6 +2419,29 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     wj2 = make_range_job<Fq2>(ctx, w_slot[3], *wq[3], 0, wq[3]->n, out2);
     for (int q = 0; q < 3; q++) wj1[q]->witness = true;
     wj2->witness = true;
+    // One digit sort for the witness queries that share a window-table plan (MsmShare): a sort-only job over the witness
+    // positions, on the G2 query's stream (its chain is the longest: no event hop in front of it); the queries follow.
+    std::unique_ptr<MsmJob<Fq>> sorter;
+    G1XYZZ sorter_out;
+    if (share && share->mask && share->n > 0) {
+        sorter.reset(new MsmJob<Fq>(ctx, scratch_slot(ctx, Ctx::MSM_SLOTS), ctx->side[w_slot[3]], nullptr, share->scalars, nullptr,
+                                    share->n, &sorter_out));
+        sorter->sort_only = true;
+        sorter->fbw_virtual = true;
+        sorter->fbw_c = share->c;
+        sorter->fbw_nwin = share->nwin;
+        sorter->fbw_stride = (size_t)1 << SH_POS_BITS;
+        sorter->d_cls = share->cls;
+        sorter->eager_small = share->small != 0;
+        sorter->ev_items = ctx->share_ev;
+        MsmJobBase* fj[4] = {wj1[0].get(), wj1[1].get(), wj1[2].get(), wj2.get()};
+        for (int q = 0; q < 4; q++) {
+            if (!(share->mask >> (q + 1) & 1u) || wq[q]->n == 0) continue;
+            fj[q]->src = sorter.get();
+            const ShQuery sq{share->q[q + 1].rank, share->q[q + 1].sub, (uint32_t)wq[q]->n};
+            if (q < 3) wj1[q]->shq = sq; else wj2->shq = sq;
+        }
+    }
     // h parts
     G1XYZZ hout[HP];
     std::unique_ptr<MsmJob<Fq>> hp[HP];
@@ -2320,6 +2480,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     const bool small = wj2->eager_small && wj1[0]->eager_small && wj1[1]->eager_small && wj1[2]->eager_small;
     if (!small)
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
+    if (sorter) jobs[nj++] = sorter.get();
     jobs[nj++] = wj2.get();
     if (small)   // second: queueing a job takes the host ~80 us, and the NTT pipeline of a small proof is done in 0.3 ms
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
@@ -2353,14 +2514,14 @@ __global__ void __launch_bounds__(256) k_fbw_build(const Affine<F>* __restrict__
 
 int msm_fbw_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, size_t stride, int c, int nwin, G1Affine* d_table) {
     if (n == 0) return ZG_OK;
-    hipLaunchKernelGGL((k_fbw_build<Fq>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride, c,
+    ZG_LAUNCH(ctx, (k_fbw_build<Fq>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride, c,
                        nwin, d_table);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
 int msm_fbw_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, size_t stride, int c, int nwin, G2Affine* d_table) {
     if (n == 0) return ZG_OK;
-    hipLaunchKernelGGL((k_fbw_build<Fq2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride,
+    ZG_LAUNCH(ctx, (k_fbw_build<Fq2>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n, stride,
                        c, nwin, d_table);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -2392,7 +2553,7 @@ static int quad_build(Ctx* ctx, const Affine<F>* d_bases, size_t n, Affine<F>* d
     if (n == 0) return ZG_OK;
     ZG_HIP(ctx, hipMemcpyAsync(d_buf, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, ctx->stream));
     const size_t threads = (n + qw - 1) / qw * (((size_t)1 << qw) - 1);
-    hipLaunchKernelGGL((k_quad_build<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n,
+    ZG_LAUNCH(ctx, (k_quad_build<F>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, n,
                        d_buf + n, qw);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -2410,7 +2571,7 @@ int msm_classify_counts(Ctx* ctx, const uint32_t* d_scalars, const uint32_t* d_i
     ZG_HIP(ctx, cnt.alloc(16));
     ZG_HIP(ctx, hipMemsetAsync(cnt.p, 0, 16, ctx->stream));
     const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 4);
-    hipLaunchKernelGGL(k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, (const uint8_t*)nullptr, n,
+    ZG_LAUNCH(ctx, k_classify, dim3(grid), dim3(256), 0, ctx->stream, d_scalars, d_index, (const uint8_t*)nullptr, n,
                        cnt.as<uint32_t>(), (const uint32_t*)nullptr);
     uint32_t h[2] = {0, 0};
     ZG_HIP(ctx, hipMemcpyAsync(h, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2451,11 +2612,11 @@ static int compact_reals(Ctx* ctx, const Affine<F>* d_bases, const uint32_t* d_s
     ZG_HIP(ctx, fl.alloc((n + 1) * 4));
     ZG_HIP(ctx, bs.alloc((size_t)nbx * 4));
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_real_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_index, n, fl.as<uint32_t>());
-    hipLaunchKernelGGL(k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
-    hipLaunchKernelGGL(k_xscan_bsums, dim3(1), dim3(256), 0, st, bs.as<uint32_t>(), nbx);
-    hipLaunchKernelGGL(k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
-    hipLaunchKernelGGL((k_compact_reals<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, fl.as<uint32_t>(), n,
+    ZG_LAUNCH(ctx, k_real_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, d_index, n, fl.as<uint32_t>());
+    ZG_LAUNCH(ctx, k_xscan_reduce, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
+    ZG_LAUNCH(ctx, k_xscan_bsums, dim3(1), dim3(256), 0, st, bs.as<uint32_t>(), nbx);
+    ZG_LAUNCH(ctx, k_xscan_final, dim3(nbx), dim3(SCAN_THREADS), 0, st, fl.as<uint32_t>(), n, bs.as<uint32_t>());
+    ZG_LAUNCH(ctx, (k_compact_reals<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_bases, fl.as<uint32_t>(), n,
                        d_rank, d_compact);
     uint32_t total = 0;
     ZG_HIP(ctx, hipMemcpyAsync(&total, fl.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, st));
@@ -2474,7 +2635,7 @@ int msm_compact_reals_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_sc
 }
 
 void msm_scratch_free(Ctx* ctx) {
-    for (int k = 0; k < Ctx::MSM_SLOTS; k++) {
+    for (int k = 0; k < Ctx::MSM_SLOTS + 1; k++) {
         if (ctx->msm_scratch[k]) {
             if (ctx->msm_scratch[k]->host) (void)hipHostFree(ctx->msm_scratch[k]->host);
             delete ctx->msm_scratch[k];
@@ -2485,6 +2646,7 @@ void msm_scratch_free(Ctx* ctx) {
         for (int k = 0; k < Ctx::MSM_SLOTS; k++) (void)hipStreamDestroy(ctx->side[k]);
         for (int k = 0; k < 2 * Ctx::H_PARTS_MAX; k++) (void)hipEventDestroy(ctx->part_ev[k]);
         (void)hipEventDestroy(ctx->side_ev);
+        (void)hipEventDestroy(ctx->share_ev);
         ctx->side_ready = false;
     }
 }

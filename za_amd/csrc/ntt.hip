@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_convert(Fp<typename P29::Wide>* __restr
 static int launch_powers(Ctx* ctx, Fr* out, size_t n, const Fr& base, const Fr& scale) {
     uint32_t run = 64;
     size_t threads = (n + run - 1) / run;
-    hipLaunchKernelGGL(k_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
+    ZG_LAUNCH(ctx, k_powers, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
                        host_to_m261(base), host_to_m261(scale), run);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -92,7 +92,7 @@ static int launch_powers(Ctx* ctx, Fr* out, size_t n, const Fr& base, const Fr& 
 static int launch_powers_limbs(Ctx* ctx, FrLimbs* out, size_t n, const Fr& base) {
     uint32_t run = 64;
     size_t threads = (n + run - 1) / run;
-    hipLaunchKernelGGL(k_powers_limbs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
+    ZG_LAUNCH(ctx, k_powers_limbs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, n,
                        host_to_m261(base), run);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -145,7 +145,7 @@ static int get_tables(Ctx* ctx, uint32_t log_m, NttTables** out) {
     if (!rc) rc = launch_powers(ctx, T->gi_hi.as<Fr>(), nhi, g_inv.pow_u64(nlo), T->minv_host);
     if (!rc) rc = launch_powers(ctx, T->gi_hi_canon.as<Fr>(), nhi, g_inv.pow_u64(nlo), T->minv_host);
     if (!rc) {
-        hipLaunchKernelGGL(k_from_mont, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, ctx->stream,
+        ZG_LAUNCH(ctx, k_from_mont, dim3((unsigned)((nhi + 255) / 256)), dim3(256), 0, ctx->stream,
                            T->gi_hi_canon.as<Fr>(), nhi);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, ZG_E_HIP, "k_from_mont launch failed");
     }
@@ -468,7 +468,7 @@ static int run_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, const 
         size_t tiles = ((size_t)1 << log_m) >> (k + j);
         size_t lds_bytes = (size_t)36 << (k + j);   // 9 u32 limbs per element
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);  // units: butterflies
-        hipLaunchKernelGGL((k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, tw, (int)log_m,
+        ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, tw, (int)log_m,
                            s_lo, k, j, contiguous, fz);
         ZG_HIP(ctx, hipGetLastError());
     }
@@ -485,19 +485,19 @@ static int ntt_core(Ctx* ctx, NttTables* T, Fr* d, bool inverse, bool coset) {
     const size_t m = (size_t)1 << log_m;
     hipStream_t st = ctx->stream;
     if (!inverse && coset) {
-        hipLaunchKernelGGL(k_scale_geom, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->g_hi.as<Fr>(), T->g_lo.as<Fr>(),
+        ZG_LAUNCH(ctx, k_scale_geom, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->g_hi.as<Fr>(), T->g_lo.as<Fr>(),
                            T->lo_bits);
     }
     if (log_m > 0) {
         ZG_TRY(dif_passes(ctx, d, inverse ? T->tw_inv.as<FrLimbs>() : T->tw_fwd.as<FrLimbs>(), log_m));
-        hipLaunchKernelGGL(k_bitrev, dim3(blocks_for(m)), dim3(256), 0, st, d, (int)log_m);
+        ZG_LAUNCH(ctx, k_bitrev, dim3(blocks_for(m)), dim3(256), 0, st, d, (int)log_m);
     }
     if (inverse) {
         if (coset)
-            hipLaunchKernelGGL(k_scale_geom, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->gi_hi.as<Fr>(),
+            ZG_LAUNCH(ctx, k_scale_geom, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->gi_hi.as<Fr>(),
                                T->gi_lo.as<Fr>(), T->lo_bits);
         else
-            hipLaunchKernelGGL(k_scale_const, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->minv);
+            ZG_LAUNCH(ctx, k_scale_const, dim3(blocks_for(m)), dim3(256), 0, st, d, m, T->minv);
     }
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -511,7 +511,7 @@ int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out)
     const size_t m = (size_t)1 << log_m;
     ZG_TRY(launch_powers(ctx, d_out, m, tau_host, Fr::one()));
     ZG_TRY(ntt_core(ctx, T, d_out, /*inverse=*/true, /*coset=*/false));
-    hipLaunchKernelGGL(k_from_mont, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, d_out, m);
+    ZG_LAUNCH(ctx, k_from_mont, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, d_out, m);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -519,14 +519,14 @@ int lagrange_at_tau_dev(Ctx* ctx, uint32_t log_m, const Fr& tau_host, Fr* d_out)
 int powers_int_dev(Ctx* ctx, Fr* d_out, size_t n, const Fr& base_host, const Fr& scale_host) {
     if (n == 0) return ZG_OK;
     ZG_TRY(launch_powers(ctx, d_out, n, base_host, scale_host));
-    hipLaunchKernelGGL(k_from_mont, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_out, n);
+    ZG_LAUNCH(ctx, k_from_mont, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_out, n);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
 
 int bitrev_dev(Ctx* ctx, Fr* d_data, uint32_t log_m) {
     if (log_m == 0) return ZG_OK;
-    hipLaunchKernelGGL(k_bitrev, dim3(blocks_for((size_t)1 << log_m)), dim3(256), 0, ctx->stream, d_data, (int)log_m);
+    ZG_LAUNCH(ctx, k_bitrev, dim3(blocks_for((size_t)1 << log_m)), dim3(256), 0, ctx->stream, d_data, (int)log_m);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -535,9 +535,9 @@ int convert_mont_dev(Ctx* ctx, void* d_elems, size_t n, int which, int dir, hipS
     if (n == 0) return ZG_OK;
     if (!st) st = ctx->stream;
     if (which)
-        hipLaunchKernelGGL((k_convert<Fr29>), dim3(blocks_for(n)), dim3(256), 0, st, (Fr*)d_elems, n, dir);
+        ZG_LAUNCH(ctx, (k_convert<Fr29>), dim3(blocks_for(n)), dim3(256), 0, st, (Fr*)d_elems, n, dir);
     else
-        hipLaunchKernelGGL((k_convert<Fq29>), dim3(blocks_for(n)), dim3(256), 0, st, (Fq*)d_elems, n, dir);
+        ZG_LAUNCH(ctx, (k_convert<Fq29>), dim3(blocks_for(n)), dim3(256), 0, st, (Fq*)d_elems, n, dir);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -628,7 +628,7 @@ static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int 
     pass_geometry(log_m, s_lo, k, &j, &contiguous);
     const size_t tiles = ((size_t)1 << log_m) >> (k + j);
     ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);
-    hipLaunchKernelGGL((k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
+    ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
                        (int)log_m, s_lo, k, j, contiguous, no_fuse());
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -649,7 +649,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     const size_t m = (size_t)1 << log_m;
     if (log_m <= (uint32_t)NTT_LOG_TILE) {   // the whole domain is one tile
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)6 * 64 << log_m, nullptr, ((uint64_t)6 * log_m << log_m) >> 1);
-        hipLaunchKernelGGL(k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
+        ZG_LAUNCH(ctx, k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
                            (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out, 0u);
         for (int k = 0; k < nsplit; k++) ZG_HIP(ctx, hipEventRecord(ev_split[k], ctx->stream));
         ZG_HIP(ctx, hipGetLastError());
@@ -665,7 +665,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
             pass_geometry(log_m, P.s_lo[L - 1], P.k[L - 1], &j, &contiguous);
             const size_t tiles = m >> (P.k[L - 1] + j);
             ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)2 * P.k[L - 1] << log_m) >> 1);
-            hipLaunchKernelGGL(k_ntt_mid, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
+            ZG_LAUNCH(ctx, k_ntt_mid, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
                                v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits);
             ZG_HIP(ctx, hipGetLastError());
         }
@@ -683,7 +683,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
             const size_t upto = std::min(m, (size_t)(q + 1) * chunk);
             const size_t t1 = q + 1 == ns ? tiles : std::min(tiles, (upto + tile_elems - 1) / tile_elems);
             if (t1 > t0)
-                hipLaunchKernelGGL(k_ntt_tail3, dim3((unsigned)(t1 - t0)), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream,
+                ZG_LAUNCH(ctx, k_ntt_tail3, dim3((unsigned)(t1 - t0)), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream,
                                    d_a, d_b, d_c, twf, twi, (int)log_m, P.k[0], j, 0, hi, lo, T->lo_bits, T->zinv_int, d_e_out,
                                    (uint32_t)t0);
             if (nsplit > 0) ZG_HIP(ctx, hipEventRecord(ev_split[q], ctx->stream));

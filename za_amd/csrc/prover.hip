@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
 int spmv_dev(Ctx* ctx, const uint64_t* d_ptr, const uint32_t* d_idx, const Fr* d_coeff, const Fr* d_x, uint64_t n_rows,
              Fr* d_out) {
     if (n_rows == 0) return ZG_OK;
-    hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, d_ptr, d_idx,
+    ZG_LAUNCH(ctx, k_r1cs_eval, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, d_ptr, d_idx,
                        d_coeff, d_x, n_rows, d_out, 0);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -815,6 +815,7 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             ctx->opt_h_parts = (int)value;
             return ZG_OK;
         case ZG_OPT_H_PIPE: ctx->opt_h_pipe = value != 0; return ZG_OK;
+        case ZG_OPT_SHARE_SORT: ctx->opt_share_sort = value != 0; return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -858,6 +859,15 @@ extern "C" int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes) t
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(ctx);
+}
+extern "C" int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]) try {
+    if (!ctx || !stats) return ZG_E_INVALID_ARG;
+    stats[0] = ctx->n_launches;
+    stats[1] = ctx->last_share_mask;
+    stats[2] = stats[3] = 0;
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
 }
 extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) try {
     if (!ctx || !ms) return ZG_E_INVALID_ARG;
@@ -1283,6 +1293,25 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
     r->n_a = a_index.size();
     r->n_b = b_index.size();
     hipStream_t st = ctx->stream;
+    {   // the inverse maps (variable -> position in the a / b query, ~0 = not in its density): what a query reads the entries
+        // of a shared digit sort through (msm.hip ShQuery); a query of full density needs none
+        std::vector<uint32_t> rank(nvars);
+        for (int k = 0; k < 2; k++) {
+            const std::vector<uint32_t>& ix = k == 0 ? a_index : b_index;
+            zg::DevBuf& dst = k == 0 ? r->a_rank : r->b_rank;
+            if (ix.size() == nvars) continue;   // the identity
+            std::fill(rank.begin(), rank.end(), 0xffffffffu);
+            for (size_t i = 0; i < ix.size(); i++) rank[ix[i]] = (uint32_t)i;
+            ZG_HIP(ctx, dst.alloc(nvars * 4));
+            ZG_HIP(ctx, hipMemcpyAsync(dst.p, rank.data(), nvars * 4, hipMemcpyHostToDevice, st));
+            ZG_HIP(ctx, hipStreamSynchronize(st));   // (`rank` is reused / freed)
+        }
+        // the variables this process's shard of a query [lo, hi) spans are needed on the host when a sharded key is used
+        r->a_first = a_index.empty() ? 0 : a_index.front();
+        r->b_first = b_index.empty() ? 0 : b_index.front();
+        r->a_index_host = a_index;   // (4 bytes per dense position, like the device copy)
+        r->b_index_host = b_index;
+    }
     ZG_HIP(ctx, r->a_index.alloc(a_index.size() * 4));
     ZG_HIP(ctx, r->b_index.alloc(b_index.size() * 4));
     ZG_HIP(ctx, hipMemcpyAsync(r->a_index.p, a_index.data(), a_index.size() * 4, hipMemcpyHostToDevice, st));
@@ -1298,7 +1327,7 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
             ZG_HIP(ctx, hipMemcpyAsync(r->col[k].p, col[k], nnz * 4, hipMemcpyHostToDevice, st));
             ZG_HIP(ctx, hipMemcpyAsync(r->coeff[k].p, coeff[k], nnz * 32, hipMemcpyHostToDevice, st));
             ZG_HIP(ctx, r->ccls[k].alloc(nnz));
-            hipLaunchKernelGGL(k_coeff_prepare, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
+            ZG_LAUNCH(ctx, k_coeff_prepare, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
                                r->coeff[k].as<Fr>(), (size_t)nnz, r->ccls[k].as<uint8_t>());
         }
     }
@@ -1382,7 +1411,7 @@ static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   /
         ZG_HIP(ctx, hipEventCreateWithFlags(&ws.bad_ev, hipEventDisableTiming));
     }
     ZG_HIP(ctx, hipMemsetAsync(ws.bad.p, 0xff, 8, ctx->stream));   // "nothing wrong" = all ones in both words
-    hipLaunchKernelGGL(k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
+    ZG_LAUNCH(ctx, k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
                        ws.wcls.as<uint8_t>(), ws.bad.as<uint32_t>());
     ZG_HIP(ctx, hipGetLastError());
     ZG_HIP(ctx, hipMemcpyAsync(ws.bad_host, ws.bad.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1419,16 +1448,16 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
         if (!ws.wcls_fresh || ws.wcls_for != (const void*)d_w) ZG_TRY(witness_classes(ctx, r, d_w));
         ws.wcls_fresh = false;
         for (int k = 0; k < 3; k++)
-            hipLaunchKernelGGL(k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
+            ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
                                r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
                                ws.wcls.as<uint8_t>(), r->n_constraints, d_abc[k], (int)r->log_m);
         for (int k = 0; k < 3; k++)
             if (r->n_long[k])
-                hipLaunchKernelGGL(k_r1cs_eval_long, dim3((r->n_long[k] + 3) / 4), dim3(256), 0, st,
+                ZG_LAUNCH(ctx, k_r1cs_eval_long, dim3((r->n_long[k] + 3) / 4), dim3(256), 0, st,
                                    r->long_rows[k].as<uint32_t>(), r->n_long[k], r->row_ptr[k].as<uint64_t>(),
                                    r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
                                    ws.wcls.as<uint8_t>(), d_abc[k], (int)r->log_m);
-        hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
+        ZG_LAUNCH(ctx, k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
                            r->n_constraints, d_abc[0], rev_bits);
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
@@ -1439,11 +1468,11 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
         else
             ZG_HIP(ctx, hipMemsetAsync(d_abc[k] + r->n_constraints, 0, (m - r->n_constraints) * sizeof(Fr), st));
         if (r->n_constraints)
-            hipLaunchKernelGGL(k_r1cs_eval, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, st,
+            ZG_LAUNCH(ctx, k_r1cs_eval, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, st,
                                r->row_ptr[k].as<uint64_t>(), r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), d_w,
                                r->n_constraints, d_abc[k], rev_bits);
     }
-    hipLaunchKernelGGL(k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
+    ZG_LAUNCH(ctx, k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
                        r->n_constraints, d_abc[0], rev_bits);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
@@ -1467,7 +1496,7 @@ extern "C" int zg_r1cs_check(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witne
         abc[k] = d[k].as<Fr>();
     }
     ZG_TRY(r1cs_eval_dev(ctx, r, dw.as<Fr>(), abc, /*bitrev=*/false));
-    hipLaunchKernelGGL(k_r1cs_check, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, ctx->stream, abc[0],
+    ZG_LAUNCH(ctx, k_r1cs_check, dim3((unsigned)((r->n_constraints + 255) / 256)), dim3(256), 0, ctx->stream, abc[0],
                        abc[1], abc[2], r->n_constraints, flag.as<unsigned long long>());
     ZG_HIP(ctx, hipGetLastError());
     unsigned long long h = 0;
@@ -1840,6 +1869,11 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m, bool retr
 static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask, bool h_eval_form = false) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     static const int order[5] = {4, 0, 1, 2, 3};
+    // The witness queries that get a WINDOW table get it with one common plan (c, nwin) where they can, decided when the
+    // first of them is built: queries with the same plan share one digit sort per proof (msm.hip MsmShare).  The plan is
+    // made for the largest of them -- a smaller query then runs with a digit a bit wider than its own optimum.
+    uint64_t w_real[5] = {0, 0, 0, 0, 0};
+    bool w_counted[5] = {false, false, false, false, false};
     for (int oi = 0; oi < 5; oi++) {
         const int k = order[oi];
         auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
@@ -1861,6 +1895,8 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
             uint64_t zeros = 0, ones = 0;
             ZG_TRY(msm_classify_counts(ctx, use[k].scalars, use[k].index, n, &zeros, &ones));
             n_real = n - zeros - ones;
+            w_real[k] = n_real;
+            w_counted[k] = true;
         }
         size_t free_b = 0, total_b = 0;
         ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -1951,6 +1987,40 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (!small && (n_real < 64 || n_real * 2 < n)) continue;
         int c = 0, nwin = 0;
         if (!msm_fbw_plan(small ? n : n_real, n, budget, elem, &c, &nwin, small)) continue;
+        if (k != 0 && ctx->opt_share_sort) {
+            // the common plan of the witness queries' window tables: made with the first one built from the largest query
+            // that will take this path (same mode: small or not), then reused while it fits this query's budget
+            if (p->w_plan_c == 0) {
+                uint64_t big_n = n, big_real = n_real;
+                for (int q = 1; q <= 4; q++) {
+                    if (q == k || !(mask & (1u << q)) || use[q].n == 0 || !use[q].scalars) continue;
+                    uint64_t qr = w_real[q];
+                    if (!w_counted[q]) {
+                        uint64_t z = 0, o = 0;
+                        ZG_TRY(msm_classify_counts(ctx, use[q].scalars, use[q].index, use[q].n, &z, &o));
+                        qr = use[q].n - z - o;
+                        w_real[q] = qr;
+                        w_counted[q] = true;
+                    }
+                    const bool q_small = use[q].n <= msm_small_n(ctx) || (use[q].n <= msm_small_witness_n(ctx) && qr <= msm_small_n(ctx));
+                    const bool q_window = q_small || !((use[q].n - qr) * 10 >= use[q].n * 9 && use[q].n >= 1024 || qr < 64 || qr * 2 < use[q].n);
+                    if (q_small != small || !q_window) continue;
+                    big_n = std::max<uint64_t>(big_n, use[q].n);
+                    big_real = std::max<uint64_t>(big_real, qr);
+                }
+                int cc = 0, cn = 0;
+                if (msm_fbw_plan(small ? big_n : big_real, big_n, budget, sizeof(G2Affine), &cc, &cn, small, /*always=*/true)) {
+                    p->w_plan_c = cc;
+                    p->w_plan_nwin = cn;
+                    p->w_plan_small = small;
+                }
+            }
+            if (p->w_plan_c && p->w_plan_small == small && (double)n * p->w_plan_nwin * (double)elem <= (double)budget &&
+                (double)n * p->w_plan_nwin < 2.0e9) {
+                c = p->w_plan_c;
+                nwin = p->w_plan_nwin;
+            }
+        }
         if (t.buf.alloc((size_t)nwin * n * elem) != hipSuccess) {
             (void)hipGetLastError();
             continue;   // no room: the plain per-window schedule is used
@@ -2093,13 +2163,66 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         }
         if (k < 4) d1[k] = d; else d2 = d;
     }
+    // One digit sort for the witness queries whose window tables have the key's common plan (ensure_tables): they multiply
+    // the same scalars, so their (position, digit) pairs are sorted once, over the variables this shard's queries span, and
+    // each query reads the sorted entries through its position map (msm.hip MsmShare / ShQuery).
+    MsmShare share;
+    if (ctx->opt_share_sort && p->w_plan_c && p->w_plan_nwin <= 32) {
+        const uint64_t nvars = (uint64_t)r->n_inputs + r->n_aux;
+        uint64_t pos0 = nvars, pos1 = 0;
+        unsigned members = 0;
+        int n_members = 0;
+        for (int k = 1; k <= 4; k++) {
+            const auto& t = p->fbw[k];
+            if (!use[k].n || !(mask & (1u << k)) || t.state != 1 || t.kind != 0 || t.n != use[k].n || t.c != p->w_plan_c ||
+                t.nwin != p->w_plan_nwin || t.small != p->w_plan_small)
+                continue;
+            const auto& q = p->q[k];
+            uint64_t v0, v1;   // the variables the shard's positions [q.lo, q.lo + n) map to
+            if (k == 1) {
+                v0 = (uint64_t)r->n_inputs + q.lo;
+                v1 = v0 + use[k].n;
+            } else {
+                const std::vector<uint32_t>& ix = k == 2 ? r->a_index_host : r->b_index_host;
+                if (q.lo + use[k].n > ix.size()) continue;
+                v0 = ix[q.lo];
+                v1 = (uint64_t)ix[q.lo + use[k].n - 1] + 1;
+            }
+            pos0 = std::min(pos0, v0);
+            pos1 = std::max(pos1, v1);
+            members |= 1u << k;
+            n_members++;
+        }
+        if (n_members >= 2 && pos1 > pos0 && pos1 - pos0 <= ((uint64_t)1 << 26)) {
+            share.mask = members;
+            share.scalars = (const uint32_t*)d_witness + 8 * pos0;
+            share.cls = ws.wcls.as<uint8_t>() + pos0;
+            share.n = (size_t)(pos1 - pos0);
+            share.c = p->w_plan_c;
+            share.nwin = p->w_plan_nwin;
+            share.small = p->w_plan_small ? 1 : 0;
+            for (int k = 1; k <= 4; k++) {
+                if (!(members & (1u << k))) continue;
+                const auto& q = p->q[k];
+                if (k == 1) {
+                    share.q[k].rank = nullptr;
+                    share.q[k].sub = (uint32_t)((uint64_t)r->n_inputs + q.lo - pos0);
+                } else {
+                    const DevBuf& rk = k == 2 ? r->a_rank : r->b_rank;
+                    share.q[k].rank = rk.p ? rk.as<uint32_t>() + pos0 : nullptr;
+                    share.q[k].sub = rk.p ? (uint32_t)q.lo : (uint32_t)(q.lo - pos0);   // (full density: variable = position in the query)
+                }
+            }
+        }
+    }
     hipEvent_t ev_wit = ctx->ev_witness;
     if (!ev_wit && ctx->witness_gate_armed && !(mask & 1u)) ev_wit = ctx->gate_w;   // see zg_prove_h_enqueue_dev
     if (own_classes) ev_wit = nullptr;   // the class kernel was queued just now: gate on "everything so far"
     ctx->witness_gate_armed = false;
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
-    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h));
+    ctx->last_share_mask = share.mask;
+    ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h, share.mask ? &share : nullptr));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
@@ -2255,6 +2378,8 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "zg_prove needs an unsharded key (world = 1); use the phase API");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
+    if (!ctx->stats_keep) ctx->n_launches = 0;
+    ctx->stats_keep = false;
     if (ctx->prof_enabled && !ctx->prof_pending.empty()) ZG_TRY(prof_drain(ctx));   // recycle the last proof's events
     ZG_TRY(check_query_sizes(ctx, p, r));
     const size_t m = (size_t)1 << r->log_m;
@@ -2374,6 +2499,8 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     void* d_w = nullptr;
     size_t sent = 0;
+    ctx->n_launches = 0;
+    ctx->stats_keep = true;   // (zg_prove_dev below counts on)
     ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] zg_prove: witness handed over  +%.3f ms\n", now_ms() - t0);
@@ -2411,14 +2538,14 @@ static int upload_packed(zg_ctx* ctx, size_t nv, const uint8_t* classes, const u
     if (np == 0) return ZG_OK;
     ZG_HIP(ctx, ws.pk_cls.reserve((np + 3) / 4));
     ZG_HIP(ctx, hipMemcpyAsync(ws.pk_cls.p, classes, (np + 3) / 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), np,
+    ZG_LAUNCH(ctx, k_unpack_bits, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ws.pk_cls.as<uint8_t>(), np,
                        ws.w.as<Fr>() + first);
     if (n_others) {
         ZG_HIP(ctx, ws.pk_idx.reserve(n_others * 4));
         ZG_HIP(ctx, ws.pk_val.reserve(n_others * 32));
         ZG_HIP(ctx, hipMemcpyAsync(ws.pk_idx.p, other_index, n_others * 4, hipMemcpyHostToDevice, ctx->stream));
         ZG_HIP(ctx, hipMemcpyAsync(ws.pk_val.p, others32, n_others * 32, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_unpack_others, dim3((unsigned)((n_others + 255) / 256)), dim3(256), 0, ctx->stream,
+        ZG_LAUNCH(ctx, k_unpack_others, dim3((unsigned)((n_others + 255) / 256)), dim3(256), 0, ctx->stream,
                            ws.pk_idx.as<uint32_t>(), ws.pk_val.as<Fr>(), n_others, ws.w.as<Fr>());
     }
     ZG_HIP(ctx, hipGetLastError());
@@ -2682,6 +2809,8 @@ extern "C" int zg_prove_packed(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         if ((classes[0] & 3u) != 1u) return fail(ctx, ZG_E_BAD_FORMAT, "packed witness: variable 0 must be ONE");
     }
     ProveWs& ws = prove_ws(ctx);
+    ctx->n_launches = 0;
+    ctx->stats_keep = true;
     ZG_TRY(upload_packed(ctx, nv, classes, other_index, others32, n_others));
     int rc = zg_prove_dev(ctx, p, r, ws.w.p, r_le, s_le, proof_out);
     ctx->timings[0] = (double)((nv + 3) / 4 + n_others * 36);   // bytes uploaded
