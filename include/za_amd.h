@@ -117,10 +117,17 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
 #define ZG_OPT_COMPACT_TABLE 17
 #define ZG_OPT_H_PARTS 18
 #define ZG_OPT_H_PIPE 19
-/*   ZG_OPT_SHARE_SORT      1 (default): the witness queries of a proof whose window tables have one plan (the library gives
- *                          them one where it can) share ONE digit sort over the witness positions; 0 = a sort per query.
- *                          Read when a key's tables are built (the common plan) and per proof. */
+/*   ZG_OPT_SHARE_SORT      the witness queries multiply the same scalars: 1 (default) the b_g1 multiexp runs over the b_g2
+ *                          multiexp's sorted (position, digit) pairs, and the queries of full density whose window tables
+ *                          have one plan (the library gives them one where it can) share ONE digit sort over the witness
+ *                          positions; 2 = that one sort for ALL witness queries with such tables, each reading it through
+ *                          its position map (measured: slower for ragged densities; the tests use it); 0 = a sort per
+ *                          query.  Read when a key's tables are built (the common plan) and per proof. */
 #define ZG_OPT_SHARE_SORT 20
+/*   ZG_OPT_NTT_BATCH_LOG_M domains of up to 2^value rows: every pass of the H pipeline takes the three vectors a, b, c in ONE
+ *                          launch (default 15: measured -3 % at 2^14, no difference at 2^16, +9 % at 2^18; 0 = always one vector per
+ *                          launch). */
+#define ZG_OPT_NTT_BATCH_LOG_M 21
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
@@ -404,7 +411,8 @@ int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 /* ---- what the last zg_prove* call (or, for the phase API, everything since the last one) queued on the GPU:
  * [0] kernel launches, [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
- * sort in the last batch of multiexps (0 = a sort per query), [2], [3] reserved (0). */
+ * sort over the witness positions in the last batch of multiexps (0 = none), [2] 1 if the b_g1 multiexp ran over the b_g2
+ * multiexp's sorted entries (same scalars, same positions, tables of one layout), [3] reserved (0). */
 int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline

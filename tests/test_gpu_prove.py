@@ -1227,14 +1227,18 @@ def test_eddsa_poseidon_verifier_circuit_setup_prove_verify(ctx):
     P.close(); R.close()
 
 
-@pytest.mark.parametrize("lg,bitf,n_in", [(12, 0.9, 3), (13, 0.0, 2), (17, 0.0, 2), (17, 0.5, 5)])
-def test_witness_queries_share_one_digit_sort(ctx, opts, lg, bitf, n_in):
-    """l, a, b_g1 and b_g2 multiply the same scalars: with window tables of one plan their (position, digit) pairs are sorted
-    ONCE over the witness positions and each query reads the sorted entries through its position map (msm.hip MsmShare) --
-    the a and b queries of the synthetic recipe have ragged densities (b about one half), so entries of variables outside a
-    query's density are skipped.  The shared and the per-query schedules both give the C oracle's bytes: small-job mode
-    (2^12, 2^13), a dense witness beyond it (2^17), and a mixed witness (half bits: subset-sum tables, nothing to share)."""
+@pytest.mark.parametrize("lg,bitf,n_in", [(12, 0.9, 3), (13, 0.0, 2), (17, 0.0, 2), (17, 0.5, 5), (15, 0.97, 2)])
+def test_witness_queries_share_digit_sorts(ctx, opts, lg, bitf, n_in):
+    """l, a, b_g1 and b_g2 multiply the same scalars.  ZG_OPT_SHARE_SORT = 1 (default): b_g1 runs over the sorted (position,
+    digit) pairs of b_g2 -- same positions, tables of one layout, whatever their kind (window, subset sums + compact rows,
+    none).  = 2: with window tables of one plan ALL four read ONE sort over the witness positions through their position
+    maps (msm.hip MsmShare) -- the a and b queries of the synthetic recipe have ragged densities (b about one half), so
+    entries of variables outside a query's density are skipped.  = 0: a sort per query.  Every schedule gives the C oracle's
+    bytes: small-job mode (2^12, 2^13), a dense witness beyond it (2^17), a half-bit witness, and a bit-heavy one (2^15 with
+    the small-job mode off: subset sums)."""
     from za_amd import synth
+    if bitf == 0.97:
+        opts(za_amd.OPT_SMALL_LOG_N, 0)
     sr = synth.SynthR1CS(lg, n_in, bitf, 7700 + lg)
     R = sr.load(ctx)
     m = 1 << lg
@@ -1243,19 +1247,22 @@ def test_witness_queries_share_one_digit_sort(ctx, opts, lg, bitf, n_in):
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
     r, s = 0x5151 + lg, 0x6262 + lg
     exp = None
-    for share in (1, 0):
+    for share in (1, 2, 0):
         opts(za_amd.OPT_SHARE_SORT, share)
-        P = synth.synth_params(ctx, *sizes, 90 + lg)      # (the common plan is made when the tables are built)
+        P = synth.synth_params(ctx, *sizes, 90 + lg)      # (the tables' common layout is decided when they are built)
         if exp is None:
             exp = co.prove(download_params(ctx, P), csr, sr.witness, r, s, threads=16)
         for _ in range(2):
             assert ctx.prove(P, R, sr.witness, r, s) == exp
-        mask = ctx.last_stats()["shared_sort_mask"]
+        st = ctx.last_stats()
         kinds = [P.table_info(k)[0] for k in range(5)]
         if share == 0:
-            assert mask == 0
-        elif bitf != 0.5:
-            assert mask == 0b11110, (mask, kinds)     # all four witness queries on one sort
+            assert st["shared_sort_mask"] == 0 and not st["b_g1_behind_b_g2"]
+        elif share == 1:
+            # (not for queries in small-job mode -- latency-bound chains: up to 2^16 field elements among up to ~2^19 positions)
+            assert st["b_g1_behind_b_g2"] == ((lg, bitf) in ((17, 0.0), (15, 0.97))), (st, kinds)
+        elif bitf in (0.9, 0.0):
+            assert st["shared_sort_mask"] == 0b11110, (st, kinds)     # all four witness queries on one sort
         P.close()
     sr.close()
 
@@ -1278,13 +1285,14 @@ def test_shared_digit_sort_with_sharded_keys(ctx, opts):
     d_h = ctx.alloc(32 * (m + world))
     ctx.h2d(d_h, np.zeros(32 * (m + world), dtype=np.uint8))
     ctx.prove_h_dev(R, d_w, d_h)
-    for share in (1, 0):
+    for share in (2, 1, 0):
         opts(za_amd.OPT_SHARE_SORT, share)
         parts = []
         for rank in range(world):
             Pk = synth.synth_params(ctx, *sizes, 910, rank=rank, world=world)
             lo, hi = Pk.shard_range(0)
             parts.append(ctx.prove_partials_dev(Pk, R, d_w, d_h + 32 * lo))
-            assert (ctx.last_stats()["shared_sort_mask"] != 0) == (share == 1)
+            st = ctx.last_stats()
+            assert (st["shared_sort_mask"] != 0) == (share == 2) and not st["b_g1_behind_b_g2"]   # (2^13: small-job mode)
         assert ctx.prove_combine(P1, np.concatenate(parts), world, r, s) == whole
     sr.close()

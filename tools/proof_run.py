@@ -34,4 +34,8 @@ for i in range(n):
     t0 = time.perf_counter()
     proofs.add(bytes(ctx.prove(P, R, pin, 5, 7)))
     ts.append(1e3 * (time.perf_counter() - t0))
-print("ms per proof:", np.round(ts, 3), "median %.3f" % np.median(ts[3:]), ctx.last_timings(), "distinct proofs:", len(proofs))
+try:
+    stats = ctx.last_stats()
+except AttributeError:      # (ZA_AMD_LIB pointing at an older build of the library)
+    stats = {}
+print("ms per proof:", np.round(ts, 3), "median %.3f" % np.median(ts[3:]), ctx.last_timings(), stats, "distinct proofs:", len(proofs))

@@ -48,7 +48,9 @@ struct Ctx {
     bool opt_compact_table = true;    // ZG_OPT_COMPACT_TABLE: compact window table behind the subset sums, read at table build
     int opt_h_parts = 0;              // ZG_OPT_H_PARTS: parts of the h multiexp (0 = the scheduler's choice)
     bool opt_h_pipe = false;          // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
-    bool opt_share_sort = true;       // ZG_OPT_SHARE_SORT: one digit sort for the witness queries that share a window-table plan
+    int opt_ntt_batch_log_m = 15;     // ZG_OPT_NTT_BATCH_LOG_M: up to 2^value rows the H pipeline's passes take a, b, c in one launch
+    int opt_share_sort = 1;           // ZG_OPT_SHARE_SORT: 0 a sort per query; 1 b_g1 behind b_g2, and one sort for the
+                                      // full-density queries of one window-table plan; 2 one sort for all of them (position maps)
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev
     std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
@@ -62,8 +64,9 @@ struct Ctx {
     static constexpr int MSM_SLOTS = 8;   // 5 queries + up to 3 extra parts of the h job (main stream + 8 side streams:
                                           // more would share hardware queues)
     static constexpr int H_PARTS_MAX = 4;
+    struct FinishPool* finish_pool = nullptr;   // msm.hip: the helper threads of the jobs' host passes
     struct MsmScratch* msm_scratch[MSM_SLOTS + 1] = {nullptr};   // [MSM_SLOTS]: the shared digit sort of the witness queries
-    hipEvent_t share_ev = nullptr;                                // "the shared sort's item arrays are final"
+    hipEvent_t share_ev = nullptr, follow_ev = nullptr;           // "the shared sort's / the b_g2 job's item arrays are final"
     hipStream_t side[MSM_SLOTS] = {nullptr};
     hipEvent_t side_ev = nullptr;
     hipEvent_t part_ev[2 * H_PARTS_MAX] = {nullptr};   // (sorted, accumulated) per part of the h job
@@ -78,6 +81,7 @@ struct Ctx {
     // that shared one digit sort (bit k = query k)
     uint64_t n_launches = 0;
     unsigned last_share_mask = 0;
+    bool last_follow_g2 = false;
     bool stats_keep = false;   // zg_prove / zg_prove_packed cleared the counter for the zg_prove_dev they are about to call
 };
 
@@ -209,6 +213,9 @@ struct MsmDesc {
     const uint8_t* cls = nullptr;
     // small-job mode (msm.hip): 1 / 0 = decided with the key's table for this query, -1 = by the job's size
     int small_hint = -1;
+    // (the b_g1 query only) its table is laid out like the b_g2 query's -- same kind, digits, group width, compact rows --
+    // so its job may run over the G2 job's sorted entries instead of sorting the same scalars again
+    bool follow_g2 = false;
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf, int qw);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf, int qw);

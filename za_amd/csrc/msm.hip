@@ -34,6 +34,8 @@
 #include <array>
 #include <atomic>
 #include <functional>
+#include <condition_variable>
+#include <deque>
 #include <future>
 
 #include "common.h"
@@ -940,7 +942,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_xscan_final(uint32_t* __restri
 
 // ---- the same two scans as ONE single-block launch each, for tables of at most SCAN_ONE_MAX entries: a small job is a
 // chain of dependent launches (~5 us each whatever they do), and three launches to scan 2000 words are two too many
+// (16 tiles: the 2^15 + 1 bucket counts of a c = 16 small job, a 257-bin x 64-tile partition table -- 16 trips of one
+// workgroup, ~10 us, against three dependent launches)
 static constexpr size_t SCAN_ONE_MAX = 4 * (size_t)SCAN_TILE;
+// (Four times that for jobs in small-job mode -- the 2^15 + 1 bucket counts of a c = 16 plan in 16 trips of one workgroup
+// instead of three launches -- was measured and is slower: 2^14 proof 0.92 against 0.87 ms.)   // jobs in small-job mode (a chain of launches is what they cost)
 __global__ void __launch_bounds__(SCAN_THREADS) k_xscan_one(uint32_t* __restrict__ v, size_t n) {
     __shared__ uint32_t lds[8];
     uint32_t carry = 0;
@@ -1270,15 +1276,36 @@ __device__ __forceinline__ uint32_t sh_index(uint32_t e, const ShQuery& q) {
     return r < q.nq ? w * q.nq + r : 0xffffffffu;
 }
 
+// Several queries in ONE launch (gridDim.y of them): the followers of a shared sort accumulate over the same items, fold the
+// same heavy buckets and run the same reduction levels -- only the table, the position map and the buffers differ -- so the
+// G1 queries of a small proof make one chain of launches instead of three (the accumulation, the heavy-bucket fold and the
+// levels take the per-query pointers from this table, indexed by blockIdx.y; a job on its own is a batch of one).
+static constexpr int BATCH_MAX = 3;
+template <class F>
+struct BatchQ {
+    const Affine<F>* bases;     // k_accumulate: the query's bases / table
+    XYZZ<F>* partial;           // item sums
+    const XYZZ<F>* lvl_in;      // k_bits_level: this level's input rows (NULL at the leaf level) ...
+    XYZZ<F>* lvl_out;           // ... and output rows
+    XYZZ<F>* ones_out;          // k_heavy_fold: where the folded ones bucket goes (or NULL)
+    ShQuery shq;
+};
+template <class F>
+struct Batch {
+    BatchQ<F> q[BATCH_MAX];
+};
+
 template <class F, class L = typename LazyOf<F>::L, int LP = 1, bool SH = false>
-__global__ void __launch_bounds__(256) k_accumulate(const Affine<F>* __restrict__ bases,
+__global__ void __launch_bounds__(256) k_accumulate(Batch<F> batch,
                                                     const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ offsets,
                                                     const uint32_t* __restrict__ item_off,
                                                     const uint32_t* __restrict__ item_key,
                                                     const uint32_t* __restrict__ perm, uint32_t nkeys,
-                                                    uint32_t T, uint32_t ones_key, XYZZ<F>* __restrict__ partial,
-                                                    ShQuery shq) {
+                                                    uint32_t T, uint32_t ones_key) {
+    const Affine<F>* __restrict__ bases = batch.q[blockIdx.y].bases;
+    XYZZ<F>* __restrict__ partial = batch.q[blockIdx.y].partial;
+    const ShQuery shq = batch.q[blockIdx.y].shq;
     uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LP;
     if (t >= item_off[nkeys]) return;   // the grid may be sized from an upper bound (dense jobs skip the read-back)
     if (perm) t = perm[t];              // items in order of decreasing length
@@ -1374,10 +1401,11 @@ __global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restric
     if (items > heavy_items || (key == force_key && items > 0)) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
 }
 template <class F, class L = typename LazyOf<F>::L, int LP = 1>
-__global__ void __launch_bounds__(128 * LP) k_heavy_fold(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ item_off,
+__global__ void __launch_bounds__(128 * LP) k_heavy_fold(Batch<F> batch, const uint32_t* __restrict__ item_off,
                                                          const uint32_t* __restrict__ heavy_cnt,
-                                                         const uint32_t* __restrict__ heavy_list, uint32_t ones_key,
-                                                         XYZZ<F>* __restrict__ ones_out) {
+                                                         const uint32_t* __restrict__ heavy_list, uint32_t ones_key) {
+    XYZZ<F>* __restrict__ partial = batch.q[blockIdx.y].partial;
+    XYZZ<F>* __restrict__ ones_out = batch.q[blockIdx.y].ones_out;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_h);
     const uint32_t tid = threadIdx.x / LP, bdim = blockDim.x / LP;   // points, not lanes
@@ -1520,11 +1548,11 @@ __device__ __forceinline__ void bits_level_body(const XYZZ<F>* __restrict__ in, 
 }
 
 template <class F, class L = typename LazyOf<F>::L, int LP = 1>
-__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
-                                                             const uint32_t* __restrict__ item_off, uint32_t rows_in,
+__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(Batch<F> batch, const uint32_t* __restrict__ item_off, uint32_t rows_in,
                                                              uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
-                                                             uint32_t ones_row, uint32_t ones_key, XYZZ<F>* __restrict__ out) {
-    bits_level_body<F, L, LP>(in, partial, item_off, rows_in, kw, len_out, f, heavy_items, ones_row, ones_key, out);
+                                                             uint32_t ones_row, uint32_t ones_key) {
+    bits_level_body<F, L, LP>(batch.q[blockIdx.y].lvl_in, batch.q[blockIdx.y].partial, item_off, rows_in, kw, len_out, f, heavy_items,
+                              ones_row, ones_key, batch.q[blockIdx.y].lvl_out);
 }
 // One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
 // (RowMeta).  Output: one entry per block, in block order -- again rows of `chunks` entries, so the kernel is
@@ -1605,6 +1633,7 @@ struct MsmJobBase {
     uint32_t heavy_items = HEAVY_ITEMS;     // buckets of more items go through k_heavy_fold
     bool order_items = true;          // items sorted by length before the accumulation (not for small jobs)
     bool eager_small = false;         // (see MsmJob)
+    bool use_cw_b = false;            // this proof's entries index the compact window table (MsmJob::use_cw)
     uint32_t total_items_h = 0, ones_lo_h = 0, ones_hi_h = 0;   // what phase_c launched with
 };
 
@@ -1629,6 +1658,11 @@ struct MsmJob : MsmJobBase {
     // by k_ones_sum from the device-side item range.
     // (eager_small: in MsmJobBase)
     ShQuery shq{nullptr, 0u, 0u};     // follower of a shared sort: how this query reads the sorter's entries
+    // Followers of one shared sort in small-job mode run as ONE chain of launches (see Batch): the leader queues the
+    // accumulation, the heavy-bucket fold, the levels and the read-backs of its members too, on its own stream
+    MsmJob* leader = nullptr;
+    MsmJob* members[BATCH_MAX - 1] = {nullptr, nullptr};
+    int n_members = 0;
     bool fbw_virtual = false;         // sort-only job: the window-table plan (fbw_c, fbw_nwin, fbw_stride) without a table
     const Affine<F>* quad_table = nullptr;  // [n bases][15 subset sums per 4 positions] (msm_quad_build)
     uint32_t quad_base = 0;   // entry (relative to quad_table) of group 0's sums; 0 = n (the job covers the whole query)
@@ -1723,6 +1757,7 @@ struct MsmJob : MsmJobBase {
         if (dep && dep->ev_sorted) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_sorted, 0));
         const bool has_fbw = fbw_table || fbw_virtual;
         use_cw = cw_rank && !has_fbw && !dense && !eager_small && cls[2] == 0 && n_real > 0;
+        use_cw_b = use_cw;
         P = has_fbw ? plan_fbw_for(fbw_c, fbw_nwin, n_real) : use_cw ? plan_fbw_for(cw_c, cw_nwin, n_real) : plan_msm(n_real, n_ones);
         {   // Small jobs are latency bound: a thread runs its item's mixed adds one after the other (64 G2 adds are
             // 1.1 ms whatever n is).  Below ~64K items the items are shortened -- down to half the mean bucket load, so
@@ -1927,6 +1962,7 @@ struct MsmJob : MsmJobBase {
                 return ZG_OK;
             }
             P = src->P;
+            use_cw = src->use_cw_b;
             nkeys = src->nkeys;
             ones_key = src->ones_key;
             t_ones = src->t_ones;
@@ -1969,7 +2005,8 @@ struct MsmJob : MsmJobBase {
                                               ones_hi - ones_lo, st));
             // order the items by length -- not for a small job: three launches and a memset cost more than the lanes of
             // its few hundred waves waiting for their longest item (it is launch and latency bound, not throughput bound)
-            order_items = total_items >= ITEM_ORDER_MIN;
+            // (`total_items` of such a job is the bound it was queued with, several times the real count)
+            order_items = !eager_small && total_items >= ITEM_ORDER_MIN;
             if (order_items) {
                 ZG_HIP(ctx, S.perm.reserve((size_t)total_items * 4));
                 const unsigned ib = (unsigned)std::min<size_t>((total_items + 255) / 256, (size_t)ctx->num_cu * 8);
@@ -1983,11 +2020,28 @@ struct MsmJob : MsmJobBase {
         total_items_h = total_items;
         ones_lo_h = ones_lo;
         ones_hi_h = ones_hi;
-        if (sort_only) {   // the followers (queued on their own streams behind ev_items) do the rest
+        if (ev_items && !src) {   // this job's sort carries other queries too: they follow on their own streams behind ev_items
             ZG_HIP(ctx, hipGetLastError());
             ZG_HIP(ctx, hipEventRecord(ev_items, st));
             c_launched = true;
-            return ZG_OK;
+        }
+        if (sort_only) return ZG_OK;
+        if (leader) return ZG_OK;   // (queued by the leader of its batch, which also sets what finish() reads)
+        // the batch: this job and its members
+        MsmJob* bj[BATCH_MAX] = {this, members[0], members[1]};
+        const unsigned nb = 1u + (unsigned)n_members;
+        Batch<F> B{};
+        for (unsigned k = 0; k < nb; k++) {
+            MsmJob* j = bj[k];
+            if (k) {   // what the member's own phase_c would have set up
+                j->P = P; j->nkeys = nkeys; j->ones_key = ones_key; j->t_ones = t_ones; j->t_pack = t_pack;
+                j->heavy_items = heavy_items; j->order_items = order_items; j->eager_small = eager_small;
+                ZG_HIP(ctx, j->S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
+                if (!j->S.host) ZG_HIP(ctx, hipHostMalloc((void**)&j->S.host, MsmScratch::HOST_BYTES, hipHostMallocDefault));
+            }
+            B.q[k].bases = j->fbw_table ? j->fbw_table : j->quad_table ? j->quad_table : j->d_bases;
+            B.q[k].partial = j->S.partial.template as<XYZZ<F>>();
+            B.q[k].shq = j->shq;
         }
         {
             if (dep && dep->ev_acc) ZG_HIP(ctx, hipStreamWaitEvent(st, dep->ev_acc, 0));
@@ -2000,7 +2054,6 @@ struct MsmJob : MsmJobBase {
             // halve; a big one is bound by throughput, and there 178 registers per lane (two waves per SIMD) beat the 329
             // of one lane per point (one wave) by more than the operand exchange costs -- dense 2^22 witness: G2
             // accumulation 18.4 -> 15.8 ms of kernel time, proof 33.5 -> 32.9 ms.
-            const Affine<F>* acc_bases = fbw_table ? fbw_table : quad_table ? quad_table : d_bases;
             const uint32_t* acc_perm = order_items ? SS.perm.as<uint32_t>() : (const uint32_t*)nullptr;
             // A small G1 job's accumulation is a chain of T dependent mixed additions per item on a nearly idle GPU: every
             // addition then runs on four lanes (ecd.h add_mixed_quad: four rounds of one product instead of ten serial ones).
@@ -2009,20 +2062,23 @@ struct MsmJob : MsmJobBase {
             if constexpr (IS_G1) quad_acc = (eager_small || n <= msm_small_n(ctx)) && (size_t)total_items * 4 <= QUAD_ACC_MAX_LANES;
             // (SH: this job reads the entries of a shared sort through its rank map, see ShQuery)
             auto launch_acc = [&](auto kern, unsigned lanes_per_item) {
-                ZG_LAUNCH(ctx, kern, dim3((unsigned)(((size_t)total_items * lanes_per_item + 255) / 256)), dim3(256), 0, st,
-                                   acc_bases, SS.sorted.as<uint32_t>(), SS.offsets.as<uint32_t>(), SS.item_off.as<uint32_t>(),
-                                   SS.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key, S.partial.as<XYZZ<F>>(), shq);
+                ZG_LAUNCH(ctx, kern, dim3((unsigned)(((size_t)total_items * lanes_per_item + 255) / 256), nb), dim3(256), 0, st,
+                                   B, SS.sorted.as<uint32_t>(), SS.offsets.as<uint32_t>(), SS.item_off.as<uint32_t>(),
+                                   SS.item_key.as<uint32_t>(), acc_perm, nkeys, t_pack, ones_key);
             };
+            // (a follower of a query over the SAME positions -- b_g1 behind b_g2 -- reads the entries as they are: they index
+            // its own table, laid out like the sorter's)
+            const bool sh = src && shq.nq != 0;
             if (quad_acc) {
                 if constexpr (IS_G1) {
-                    if (src) launch_acc(k_accumulate<F, FqQL, 4, true>, 4);
+                    if (sh) launch_acc(k_accumulate<F, FqQL, 4, true>, 4);
                     else launch_acc(k_accumulate<F, FqQL, 4, false>, 4);
                 }
             } else if (CLP > 1) {
-                if (src) launch_acc(k_accumulate<F, CL, CLP, true>, CLP);
+                if (sh) launch_acc(k_accumulate<F, CL, CLP, true>, CLP);
                 else launch_acc(k_accumulate<F, CL, CLP, false>, CLP);
             } else {
-                if (src) launch_acc(k_accumulate<F, typename LazyOf<F>::L, 1, true>, 1);
+                if (sh) launch_acc(k_accumulate<F, typename LazyOf<F>::L, 1, true>, 1);
                 else launch_acc(k_accumulate<F, typename LazyOf<F>::L, 1, false>, 1);
             }
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
@@ -2035,23 +2091,23 @@ struct MsmJob : MsmJobBase {
             uint32_t* hcnt = S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES;   // zeroed with the histogram above
             uint32_t* hlist = S.heavy.as<uint32_t>();
             // a job queued without read-backs folds its ones bucket here too (listed whenever it holds an item)
-            XYZZ<F>* ones_out = nullptr;
             // (a small job's ones bucket has at most n / t_ones + 1 items: if they fit a row of the leaf level they are
             // summed there, see k_bits_level)
             ones_in_levels = eager_small && P.c >= 2 && n_sort / t_ones + 1 <= P.B;
             const bool fold_ones = eager_small && !ones_in_levels;
             if (fold_ones) {
-                ZG_HIP(ctx, S.ones[0].reserve(sizeof(XYZZ<F>)));
-                ones_out = S.ones[0].template as<XYZZ<F>>();
-                ZG_HIP(ctx, hipMemsetAsync(ones_out, 0, sizeof(XYZZ<F>), st));   // all zero = the identity
+                for (unsigned k = 0; k < nb; k++) {
+                    ZG_HIP(ctx, bj[k]->S.ones[0].reserve(sizeof(XYZZ<F>)));
+                    B.q[k].ones_out = bj[k]->S.ones[0].template as<XYZZ<F>>();
+                    ZG_HIP(ctx, hipMemsetAsync(B.q[k].ones_out, 0, sizeof(XYZZ<F>), st));   // all zero = the identity
+                }
             }
             const uint32_t listed = fold_ones ? nkeys : P.nkeys;
+            // (the list of heavy buckets depends on the items only: one for the whole batch)
             ZG_LAUNCH(ctx, k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, SS.item_off.as<uint32_t>(),
                                listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist);
-            ZG_LAUNCH(ctx, (k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024), dim3(128 * ChainCfg<F>::LP),
-                               128 * sizeof(XYZZ<F>), st,
-                               S.partial.as<XYZZ<F>>(), SS.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
-                               ones_out);
+            ZG_LAUNCH(ctx, (k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024, nb), dim3(128 * ChainCfg<F>::LP),
+                               128 * sizeof(XYZZ<F>), st, B, SS.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u);
         }
         const int bits = P.c - 1;
         red_nlev = 0;
@@ -2061,7 +2117,8 @@ struct MsmJob : MsmJobBase {
         }
         // levels: every row is folded 2^f : 1, S rows append their bit-plane rows (see k_bits_level)
         const uint32_t xrow = ones_in_levels ? 1u : 0u;   // the ones row, right after the S rows
-        for (int k = 0; k < 2; k++) ZG_HIP(ctx, S.lvl[k].reserve(((size_t)P.nkeys + (size_t)xrow * P.B) * sizeof(XYZZ<F>)));
+        for (unsigned q = 0; q < nb; q++)
+            for (int k = 0; k < 2; k++) ZG_HIP(ctx, bj[q]->S.lvl[k].reserve(((size_t)P.nkeys + (size_t)xrow * P.B) * sizeof(XYZZ<F>)));
         const XYZZ<F>* cur = nullptr;
         {
             uint32_t len = P.B, rows = (uint32_t)P.kw + xrow;
@@ -2071,6 +2128,10 @@ struct MsmJob : MsmJobBase {
                 len >>= red_f[l];
                 const size_t groups = (size_t)rows * len;
                 XYZZ<F>* outp = S.lvl[l & 1].template as<XYZZ<F>>();
+                for (unsigned q = 0; q < nb; q++) {
+                    B.q[q].lvl_in = l == 0 ? (const XYZZ<F>*)nullptr : bj[q]->S.lvl[(l - 1) & 1].template as<XYZZ<F>>();
+                    B.q[q].lvl_out = bj[q]->S.lvl[l & 1].template as<XYZZ<F>>();
+                }
                 // a level of few groups is a chain of dependent additions with most of the GPU idle: G1 then runs every
                 // addition on four lanes (ecd.h FqQL; QUAD_LEVEL_MAX_LANES: largest such level in logical lanes).
                 // (The same on four lane pairs for G2 -- eight lanes, ds_swizzle broadcasts -- was measured: no gain.)
@@ -2078,16 +2139,16 @@ struct MsmJob : MsmJobBase {
                 if constexpr (IS_G1) quad = groups * 2 <= QUAD_LEVEL_MAX_LANES;
                 if (quad) {
                     if constexpr (IS_G1)
-                        ZG_LAUNCH(ctx, (k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
-                                           dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, cur, S.partial.as<XYZZ<F>>(),
+                        ZG_LAUNCH(ctx, (k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS), nb),
+                                           dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, B,
                                            SS.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l], heavy_items,
-                                           l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
+                                           l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key);
                 } else {
                     ZG_LAUNCH(ctx, (k_bits_level<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>),
-                                       dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS)),
-                                       dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, cur,
-                                       S.partial.as<XYZZ<F>>(), SS.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
-                                       heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key, outp);
+                                       dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS), nb),
+                                       dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, B,
+                                       SS.item_off.as<uint32_t>(), rows, (uint32_t)P.kw, len, red_f[l],
+                                       heavy_items, l == 0 && xrow ? (uint32_t)P.kw : ~0u, ones_key);
                 }
                 cur = outp;
                 red_rowbase[l] = (uint32_t)rb;   // finish(): rows of level l start here (after the kw S rows)
@@ -2135,6 +2196,22 @@ struct MsmJob : MsmJobBase {
         ZG_HIP(ctx, hipMemcpyAsync(hw, cur, ((size_t)P.kw + xrow + n_t) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
         if (ones_ptr && !ones_in_levels)
             ZG_HIP(ctx, hipMemcpyAsync(hw + P.kw + n_t, ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        for (unsigned q = 1; q < nb; q++) {   // (members exist in small-job mode only: the ones are in the levels or folded)
+            MsmJob* j = bj[q];
+            j->red_nlev = red_nlev;
+            for (int l = 0; l < red_nlev; l++) {
+                j->red_f[l] = red_f[l];
+                j->red_bitbase[l] = red_bitbase[l];
+                j->red_rowbase[l] = red_rowbase[l];
+            }
+            j->ones_in_levels = ones_in_levels;
+            const XYZZ<F>* jcur = j->S.lvl[(red_nlev - 1) & 1].template as<XYZZ<F>>();
+            j->ones_ptr = ones_in_levels ? jcur + P.kw : j->S.ones[0].template as<XYZZ<F>>();
+            XYZZ<F>* jhw = reinterpret_cast<XYZZ<F>*>(j->S.host + 64);
+            ZG_HIP(ctx, hipMemcpyAsync(jhw, jcur, ((size_t)P.kw + xrow + n_t) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+            if (!ones_in_levels)
+                ZG_HIP(ctx, hipMemcpyAsync(jhw + P.kw + n_t, j->ones_ptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+        }
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
@@ -2182,6 +2259,66 @@ struct MsmJob : MsmJobBase {
 // (One host thread per job with blocking waits was measured: 0.6 ms slower per 2^22 proof -- the runtime's launch
 // path serialises the threads, the waits wake late, and the witness accumulations then crowd the first NTT passes.)
 // on_witness: called once, by the thread that finished the last job marked `witness`, if all of them succeeded
+// The host parts of the jobs (finish(): a Horner pass of a few dozen point operations) run beside the polling loop on two
+// helper threads that live as long as the context.  They used to be std::async calls: a thread spawned per job and proof,
+// ~20 us each, one after the other at the very end of a small proof, where its five chains finish within 0.1 ms of each
+// other (0.12 ms of a 0.94 ms proof at 2^14 between the last kernel and the last pass).  While a batch of jobs is in flight
+// the helpers poll their queue (a proof lasts a millisecond or ten); otherwise they sleep on a condition variable.
+struct FinishPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::packaged_task<int()>> q;
+    std::vector<std::thread> workers;
+    std::atomic<int> hot{0};   // run_jobs calls in flight: the workers spin instead of sleeping
+    bool stop = false;
+    FinishPool() {
+        for (int k = 0; k < 2; k++) workers.emplace_back([this] { run(); });
+    }
+    ~FinishPool() {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    void run() {
+        for (;;) {
+            std::packaged_task<int()> task;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                while (q.empty() && !stop) {
+                    if (hot.load(std::memory_order_relaxed) > 0) {
+                        lock.unlock();
+                        std::this_thread::yield();
+                        lock.lock();
+                    } else {
+                        cv.wait(lock);
+                    }
+                }
+                if (q.empty()) return;   // stop
+                task = std::move(q.front());
+                q.pop_front();
+            }
+            task();
+        }
+    }
+    std::future<int> submit(std::function<int()> fn) {
+        std::packaged_task<int()> task(std::move(fn));
+        std::future<int> f = task.get_future();
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            q.push_back(std::move(task));
+        }
+        cv.notify_one();
+        return f;
+    }
+};
+static FinishPool& finish_pool(Ctx* ctx) {
+    if (!ctx->finish_pool) ctx->finish_pool = new FinishPool();
+    return *ctx->finish_pool;
+}
+
 static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<void()>& on_witness = {}) {
     int state[16] = {0};  // 0: launch a, 1: a->b, 2: b->c, 3: c->finish, 4: done
     int remaining = njobs;
@@ -2196,7 +2333,22 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<
         }
         return rc;
     };
-    std::vector<std::future<int>> finishing;   // (a future of std::async joins in its destructor: early returns are safe)
+    // (every future is waited for before this function returns, whatever way it ends: the tasks refer to its locals)
+    struct Finishing {
+        std::vector<std::future<int>> f;
+        FinishPool* pool = nullptr;
+        ~Finishing() {
+            for (auto& x : f)
+                if (x.valid()) x.wait();
+            if (pool) pool->hot.fetch_sub(1);
+        }
+    } finishing_guard;
+    std::vector<std::future<int>>& finishing = finishing_guard.f;
+    if (njobs > 1) {
+        finishing_guard.pool = &finish_pool(ctx);
+        finishing_guard.pool->hot.fetch_add(1);
+        finishing_guard.pool->cv.notify_all();
+    }
     // ZA_AMD_TRACE=1: host timestamps (ms since entry) of every phase transition of every job, to stderr
     const bool trace = trace_level() != 0;
     const auto t_entry = std::chrono::steady_clock::now();
@@ -2263,7 +2415,7 @@ static int run_jobs(Ctx* ctx, MsmJobBase** jobs, int njobs, const std::function<
                 // host passes one after the other (0.35 ms each at 2^14).
                 if (remaining > 1) {
                     MsmJobBase* jb = jobs[j];
-                    finishing.push_back(std::async(std::launch::async, [jb, &finish_job] { return finish_job(jb); }));
+                    finishing.push_back(finish_pool(ctx).submit([jb, &finish_job] { return finish_job(jb); }));
                 } else {
                     ZG_TRY(finish_job(jobs[j]));
                 }
@@ -2386,6 +2538,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
             ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? h_prio : w_prio));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
         ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->share_ev, hipEventDisableTiming));
+        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->follow_ev, hipEventDisableTiming));
         for (int k = 0; k < 2 * HP; k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
         ctx->side_ready = true;
     }
@@ -2421,6 +2574,12 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     wj2->witness = true;
     // One digit sort for the witness queries that share a window-table plan (MsmShare): a sort-only job over the witness
     // positions, on the G2 query's stream (its chain is the longest: no event hop in front of it); the queries follow.
+    // b_g1 and b_g2 multiply the same scalars at the same positions: with tables of one layout (MsmDesc::follow_g2) the G2
+    // job's sorted entries ARE the G1 job's, which then runs no classification and no sort at all
+    if (g1[3].follow_g2 && g1[3].n == g2.n && g2.n != 0 && !(share && (share->mask >> 3 & 3u))) {
+        wj1[2]->src = wj2.get();
+        wj2->ev_items = ctx->follow_ev;
+    }
     std::unique_ptr<MsmJob<Fq>> sorter;
     G1XYZZ sorter_out;
     if (share && share->mask && share->n > 0) {
@@ -2440,6 +2599,20 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
             fj[q]->src = sorter.get();
             const ShQuery sq{share->q[q + 1].rank, share->q[q + 1].sub, (uint32_t)wq[q]->n};
             if (q < 3) wj1[q]->shq = sq; else wj2->shq = sq;
+        }
+        if (share->small) {   // the G1 followers as one chain of launches (Batch), on the first one's stream
+            MsmJob<Fq>* lead = nullptr;
+            for (int q = 0; q < 3; q++) {
+                MsmJob<Fq>* j = wj1[q].get();
+                if (j->src != sorter.get() || j->done) continue;
+                if (!lead) {
+                    lead = j;
+                } else {
+                    j->leader = lead;
+                    j->st = lead->st;
+                    lead->members[lead->n_members++] = j;
+                }
+            }
         }
     }
     // h parts
@@ -2482,9 +2655,14 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
     if (sorter) jobs[nj++] = sorter.get();
     jobs[nj++] = wj2.get();
+    // (b_g1 behind the G2 job's sort: its short chain -- no classification, no sort -- is queued right behind that job's, not
+    // after the other queries': queued last it started 0.3 ms after the entries it reads were ready)
+    const bool b1_follows = wj1[2]->src == wj2.get();
+    if (b1_follows) jobs[nj++] = wj1[2].get();
     if (small)   // second: queueing a job takes the host ~80 us, and the NTT pipeline of a small proof is done in 0.3 ms
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
-    for (int q = 0; q < 3; q++) jobs[nj++] = wj1[q].get();
+    for (int q = 0; q < 3; q++)
+        if (!(q == 2 && b1_follows)) jobs[nj++] = wj1[q].get();
     std::function<void()> on_witness;
     if (ctx->witness_hook) on_witness = [&] { ctx->witness_hook(out1, out2); };
     ZG_TRY(run_jobs(ctx, jobs, nj, on_witness));
@@ -2635,6 +2813,8 @@ int msm_compact_reals_g2(Ctx* ctx, const G2Affine* d_bases, const uint32_t* d_sc
 }
 
 void msm_scratch_free(Ctx* ctx) {
+    delete ctx->finish_pool;
+    ctx->finish_pool = nullptr;
     for (int k = 0; k < Ctx::MSM_SLOTS + 1; k++) {
         if (ctx->msm_scratch[k]) {
             if (ctx->msm_scratch[k]->host) (void)hipHostFree(ctx->msm_scratch[k]->host);
@@ -2647,6 +2827,7 @@ void msm_scratch_free(Ctx* ctx) {
         for (int k = 0; k < 2 * Ctx::H_PARTS_MAX; k++) (void)hipEventDestroy(ctx->part_ev[k]);
         (void)hipEventDestroy(ctx->side_ev);
         (void)hipEventDestroy(ctx->share_ev);
+        (void)hipEventDestroy(ctx->follow_ev);
         ctx->side_ready = false;
     }
 }

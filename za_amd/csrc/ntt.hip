@@ -205,9 +205,14 @@ struct BlockSync {
     __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
+// (data1, data2: two more vectors for the workgroups with blockIdx.y = 1, 2 -- the a, b, c of a small proof's H pipeline as ONE
+// launch per pass: their passes are chains of short launches, and three vectors one after the other make the chain three
+// times as long)
 template <bool DIT>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
-                                                  int k, int j, int contiguous, PassFuse fz) {
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data0, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
+                                                  int k, int j, int contiguous, PassFuse fz, Fr* __restrict__ data1,
+                                                  Fr* __restrict__ data2) {
+    Fr* __restrict__ data = blockIdx.y == 0 ? data0 : blockIdx.y == 1 ? data1 : data2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
     const TileGeom G = TileGeom::make(log_m, s_lo, k, j, contiguous, blockIdx.x);
@@ -263,10 +268,11 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data,
 // The LAST pass of an inverse transform (decimation in time, top stages) and the FIRST pass of the following coset
 // transform (decimation in frequency, the same top stages) work on the same strided tile: one kernel runs both with
 // the coset scaling g^i / m applied in LDS in between -- one load and one store where two passes made two of each.
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_mid(Fr* __restrict__ data, const FrLimbs* __restrict__ tw_inv,
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_mid(Fr* __restrict__ data0, const FrLimbs* __restrict__ tw_inv,
                                                          const FrLimbs* __restrict__ tw_fwd, int log_m, int s_lo, int k, int j,
                                                          int contiguous, const Fr* __restrict__ hi, const Fr* __restrict__ lo,
-                                                         int lo_bits) {
+                                                         int lo_bits, Fr* __restrict__ data1, Fr* __restrict__ data2) {
+    Fr* __restrict__ data = blockIdx.y == 0 ? data0 : blockIdx.y == 1 ? data1 : data2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
     const TileGeom G = TileGeom::make(log_m, s_lo, k, j, contiguous, blockIdx.x);
@@ -469,7 +475,7 @@ static int run_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, const 
         size_t lds_bytes = (size_t)36 << (k + j);   // 9 u32 limbs per element
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);  // units: butterflies
         ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, tw, (int)log_m,
-                           s_lo, k, j, contiguous, fz);
+                           s_lo, k, j, contiguous, fz, (Fr*)nullptr, (Fr*)nullptr);
         ZG_HIP(ctx, hipGetLastError());
     }
     return ZG_OK;
@@ -623,13 +629,14 @@ static void pass_geometry(uint32_t log_m, int s_lo, int k, int* j, int* contiguo
     if (*j < 0) *j = 0;
 }
 template <bool DIT>
-static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int s_lo, int k) {
+static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int s_lo, int k, Fr* d1 = nullptr, Fr* d2 = nullptr) {
     int j, contiguous;
     pass_geometry(log_m, s_lo, k, &j, &contiguous);
     const size_t tiles = ((size_t)1 << log_m) >> (k + j);
-    ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);
-    ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
-                       (int)log_m, s_lo, k, j, contiguous, no_fuse());
+    const unsigned nv = d1 ? 3u : 1u;   // (one vector, or a, b, c together)
+    ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)nv * 64 << log_m, nullptr, ((uint64_t)nv * k << log_m) >> 1);
+    ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles, nv), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
+                       (int)log_m, s_lo, k, j, contiguous, no_fuse(), d1, d2);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -658,18 +665,24 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     const StagePlan P = stage_plan(log_m);
     const int L = P.n;   // >= 2 here
     Fr* v[3] = {d_a, d_b, d_c};
-    for (int q = 0; q < 3; q++) {
-        for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p]));
+    // Up to 2^opt_ntt_batch_log_m rows the passes of a, b and c are ONE launch each (blockIdx.y picks the vector): the
+    // pipeline of a small proof is a chain of short launches on its critical path -- 7 instead of 15 at 2^14.  Beyond, a
+    // pass fills the GPU on its own and the vectors go one after the other (together: measured slower at 2^22).
+    const bool together = (int)log_m <= ctx->opt_ntt_batch_log_m;
+    for (int q = 0; q < (together ? 1 : 3); q++) {
+        Fr *v1 = together ? v[1] : nullptr, *v2 = together ? v[2] : nullptr;
+        const unsigned nv = together ? 3u : 1u;
+        for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p], v1, v2));
         {
             int j, contiguous;
             pass_geometry(log_m, P.s_lo[L - 1], P.k[L - 1], &j, &contiguous);
             const size_t tiles = m >> (P.k[L - 1] + j);
-            ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)2 * P.k[L - 1] << log_m) >> 1);
-            ZG_LAUNCH(ctx, k_ntt_mid, dim3((unsigned)tiles), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
-                               v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits);
+            ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)nv * 64 << log_m, nullptr, ((uint64_t)nv * 2 * P.k[L - 1] << log_m) >> 1);
+            ZG_LAUNCH(ctx, k_ntt_mid, dim3((unsigned)tiles, nv), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
+                               v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits, v1, v2);
             ZG_HIP(ctx, hipGetLastError());
         }
-        for (int p = L - 2; p >= 1; p--) ZG_TRY(run_one_pass<false>(ctx, v[q], twf, log_m, P.s_lo[p], P.k[p]));
+        for (int p = L - 2; p >= 1; p--) ZG_TRY(run_one_pass<false>(ctx, v[q], twf, log_m, P.s_lo[p], P.k[p], v1, v2));
     }
     {
         int j, contiguous;

@@ -815,7 +815,14 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             ctx->opt_h_parts = (int)value;
             return ZG_OK;
         case ZG_OPT_H_PIPE: ctx->opt_h_pipe = value != 0; return ZG_OK;
-        case ZG_OPT_SHARE_SORT: ctx->opt_share_sort = value != 0; return ZG_OK;
+        case ZG_OPT_NTT_BATCH_LOG_M:
+            if (value < 0 || value > 28) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_NTT_BATCH_LOG_M: 0 .. 28");
+            ctx->opt_ntt_batch_log_m = (int)value;
+            return ZG_OK;
+        case ZG_OPT_SHARE_SORT:
+            if (value < 0 || value > 2) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SHARE_SORT takes 0, 1 or 2");
+            ctx->opt_share_sort = (int)value;
+            return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -864,7 +871,8 @@ extern "C" int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]) try {
     if (!ctx || !stats) return ZG_E_INVALID_ARG;
     stats[0] = ctx->n_launches;
     stats[1] = ctx->last_share_mask;
-    stats[2] = stats[3] = 0;
+    stats[2] = ctx->last_follow_g2 ? 1 : 0;
+    stats[3] = 0;
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(nullptr);
@@ -1917,11 +1925,18 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         // throughput: G2 accumulation 1.8 -> 2.6 ms of kernel time, the proof 8.3 -> 8.8 ms
         const bool small = n <= msm_small_n(ctx) || (k != 0 && n <= msm_small_witness_n(ctx) && n_real <= msm_small_n(ctx));
         t.small = small;
+        // The b_g1 query takes the layout of the b_g2 query's table (built just before it: same scalars, same positions) where
+        // it can -- its multiexp then runs over the G2 job's sorted entries (MsmDesc::follow_g2).  A G1 table of the same shape
+        // always fits where the G2 one did.
+        const zg_params::Fbw* twin = k == 3 && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2) && p->fbw[4].state == 1 &&
+                                                 p->fbw[4].n == n && p->fbw[4].small == small
+                                         ? &p->fbw[4] : nullptr;
         if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             // groups of eight positions (255 sums: 2 KB per position) where that fits, else of four (240 B per position);
             // (ZG_OPT_SUBSET_W = 4 | 8)
             int qw = ctx->opt_subset_w == 4 ? 4 : 8;
+            if (twin && twin->kind == 1) qw = twin->qw;
             size_t entries = msm_quad_entries(n, qw);
             if (qw == 8 && (entries * elem > budget || entries >= (1ull << 31))) {
                 qw = 4;
@@ -1937,6 +1952,10 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
                 !msm_fbw_plan(n_real, n_real, budget - entries * elem, elem, &cw_c, &cw_nwin))
                 cw_c = cw_nwin = 0;
             if (!cw_on || n_real < 1024) cw_c = cw_nwin = 0;
+            if (twin && twin->kind == 1 && twin->qw == qw && twin->cw_n == n_real && (twin->cw_nwin == 0 || cw_on)) {
+                cw_c = twin->cw_c;
+                cw_nwin = twin->cw_nwin;
+            }
             const size_t cw_entries = (size_t)cw_nwin * n_real;
             if (entries + cw_entries >= (1ull << 31)) cw_c = cw_nwin = 0;
             const size_t all_entries = entries + (size_t)cw_nwin * n_real;
@@ -1987,7 +2006,9 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (!small && (n_real < 64 || n_real * 2 < n)) continue;
         int c = 0, nwin = 0;
         if (!msm_fbw_plan(small ? n : n_real, n, budget, elem, &c, &nwin, small)) continue;
-        if (k != 0 && ctx->opt_share_sort) {
+        // (not for queries in small-job mode unless mode 2 asks for their shared sort: their digits are planned for the depth
+        // of each query's own chain, and the largest query's plan for all of them cost a 2^18 proof 0.35 ms)
+        if (k != 0 && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2)) {
             // the common plan of the witness queries' window tables: made with the first one built from the largest query
             // that will take this path (same mode: small or not), then reused while it fits this query's budget
             if (p->w_plan_c == 0) {
@@ -2020,6 +2041,10 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
                 c = p->w_plan_c;
                 nwin = p->w_plan_nwin;
             }
+        }
+        if (twin && twin->kind == 0) {
+            c = twin->c;
+            nwin = twin->nwin;
         }
         if (t.buf.alloc((size_t)nwin * n * elem) != hipSuccess) {
             (void)hipGetLastError();
@@ -2163,6 +2188,18 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         }
         if (k < 4) d1[k] = d; else d2 = d;
     }
+    if (ctx->opt_share_sort && use[3].n && use[3].n == use[4].n) {
+        const auto &t1 = p->fbw[3], &t2 = p->fbw[4];
+        const bool tab1 = t1.state == 1 && t1.n == use[3].n, tab2 = t2.state == 1 && t2.n == use[4].n;
+        // (mode 1: not for jobs in small-job mode -- their chains of short launches are bound by latency, not by the work of a
+        // sort, and b_g1 behind b_g2's sort measured 0.25 ms slower at 2^18; mode 2 follows at every size)
+        const bool latency_bound = tab1 && t1.small && ctx->opt_share_sort < 2;
+        d1[3].follow_g2 = latency_bound ? false : (!tab1 && !tab2) ||
+                          (tab1 && tab2 && t1.kind == t2.kind && t1.small == t2.small &&
+                           (t1.kind == 0 ? t1.c == t2.c && t1.nwin == t2.nwin
+                                         : t1.qw == t2.qw && t1.cw_c == t2.cw_c && t1.cw_nwin == t2.cw_nwin && t1.cw_n == t2.cw_n &&
+                                               t1.cw_off == t2.cw_off));
+    }
     // One digit sort for the witness queries whose window tables have the key's common plan (ensure_tables): they multiply
     // the same scalars, so their (position, digit) pairs are sorted once, over the variables this shard's queries span, and
     // each query reads the sorted entries through its position map (msm.hip MsmShare / ShQuery).
@@ -2177,6 +2214,9 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
             if (!use[k].n || !(mask & (1u << k)) || t.state != 1 || t.kind != 0 || t.n != use[k].n || t.c != p->w_plan_c ||
                 t.nwin != p->w_plan_nwin || t.small != p->w_plan_small)
                 continue;
+            // (a query that reads the entries through a rank map pays a gather per entry and walks the entries of variables
+            // outside its density: measured, a sort of its own is cheaper -- mode 2 shares those too, for the tests)
+            if (ctx->opt_share_sort < 2 && k != 1 && (k == 2 ? r->a_rank.p : r->b_rank.p)) continue;
             const auto& q = p->q[k];
             uint64_t v0, v1;   // the variables the shard's positions [q.lo, q.lo + n) map to
             if (k == 1) {
@@ -2222,6 +2262,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ctx->last_share_mask = share.mask;
+    ctx->last_follow_g2 = d1[3].follow_g2 && !(share.mask >> 3 & 3u);
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h, share.mask ? &share : nullptr));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
