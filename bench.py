@@ -172,8 +172,7 @@ def acc_roofline(prof, pmc=None):
         roof["by_job_class"]["blended"] = {"launches": nl, "avg_launch_ms": ms / nl, "achieved": nb / (ms * 1e-3) / 1e9,
                                            "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "both classes are ONE kernel name: this average is the one a rocprofv3 --stats "
-                                                   "summary of the same command shows for k_accumulate<Fq> (profiles/r03_m_*: "
-                                                   "1082.7 us in the csv, 1111.1 us here in the same run)"}
+                                                   "summary of the same command shows for k_accumulate<Fq> (%s)" % blended_note()}
     # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
     roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "peak_measured": VALU_ISSUE_PEAK, "peak_nominal": VALU_ISSUE_NOMINAL,
@@ -184,6 +183,27 @@ def acc_roofline(prof, pmc=None):
         roof["alu_secondary"]["valu_instructions_per_mixed_add"] = pmc["valu_per_add"]
         roof["alu_secondary"]["valu_source"] = pmc["source"]
     return roof
+
+
+def blended_note():
+    """Where the committed rocprofv3 summary of this round puts the same average (profiles/rNN_m_kernel_stats_2p22_default_bench.csv
+    against the events of the run it was taken under, rNN_m_bench_under_rocprof.json) -- read from the files, newest round first."""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_m_kernel_stats_2p22_default_bench.csv")), reverse=True):
+        rnd = os.path.basename(f).split("_")[0]
+        try:
+            tot, calls = 0.0, 0
+            for row in csv.DictReader(open(f)):
+                if "k_accumulate<" in row["Name"] and "FqParams" in row["Name"] and "FqL" in row["Name"]:
+                    tot += float(row["TotalDurationNs"])
+                    calls += int(row["Calls"])
+            under = json.load(open(os.path.join(ROOT, "profiles", "%s_m_bench_under_rocprof.json" % rnd)))
+            ev = under["roofline"]["by_job_class"]["blended"]["avg_launch_ms"] * 1e3
+            return "profiles/%s_m_*: %.1f us in the csv, %.1f us from the events of that same run" % (rnd, tot / calls / 1e3, ev)
+        except Exception:
+            continue
+    return "no committed summary found under profiles/"
 
 
 def host_pack_threads():
@@ -197,7 +217,7 @@ def pmc_for(args):
     were taken on: the default one.  Any other workload gets None -- nothing is pasted across workloads."""
     if not (args.workload == "synthetic" and args.log_m == 22 and abs(args.bit_fraction - 0.97) < 1e-9 and args.seed == 0x5A):
         return None
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)))
             vi = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_valu_instructions.json" % rnd)))
@@ -425,6 +445,7 @@ def main():
             h_ms_acc.append(ctx.last_timings()["h_ms"])   # (a ctypes read of six doubles, outside the step's clock)
     barrier()
     elapsed = time.perf_counter() - t0
+    proof_stats = ctx.last_stats() if world == 1 else None   # of the last timed step: zg_prove counts its own launches
     prof = ctx.profile_get()
     phases = dict(ctx.last_timings())
     upload_bytes = int(upload_sent[0]) if world > 1 else int(phases.get("upload_bytes", 0))
@@ -761,6 +782,11 @@ def main():
             "prove_packed": packed_line,
             "phases_ms_last_step": phases,
             "upload_bytes_last_step": upload_bytes,
+            # kernel launches one zg_prove queues (hand-over kernels, R1CS evaluation, transforms, the five multiexps), and which
+            # witness multiexps shared a digit sort (zg_last_stats; ZG_OPT_SHARE_SORT)
+            "launches_per_proof": proof_stats["launches"] if proof_stats else None,
+            "digit_sort_sharing": {"b_g1_behind_b_g2": proof_stats["b_g1_behind_b_g2"],
+                                   "one_sort_over_witness_positions_mask": proof_stats["shared_sort_mask"]} if proof_stats else None,
             "kernel_ms_per_step": {k: v[0] / n_break for k, v in prof_all.items()},
             "setup_s": t_setup,
             "key_tables": {name: {"kind": ("none", "window", "subset-sum")[P.table_info(k)[0]],

@@ -45,6 +45,7 @@ def test_bench_line_contract_single_gpu():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and "proof bytes equal to the GPU's: True" in c["sample"]
+    assert 20 < d["launches_per_proof"] < 400 and "b_g1_behind_b_g2" in d["digit_sort_sharing"]
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
