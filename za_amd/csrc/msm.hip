@@ -1778,7 +1778,9 @@ struct MsmJob : MsmJobBase {
                 const uint32_t t = (uint32_t)std::min(64.0, std::max(4.0, std::ceil(std::sqrt(2.0 * mean))));
                 P.T = t;
                 heavy_items = (uint32_t)std::max(4.0, std::ceil(2.5 * mean / t));
-                if (eager_small) t_ones = 8;
+                // (the ones bucket's item sums ride through the reduction levels as ONE row of B entries, see phase_c: items just
+                // long enough that n / t_ones + 1 of them fit the row -- 8 points where the row is long enough)
+                if (eager_small) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, (n + P.B - 2) / std::max<size_t>(P.B - 1, 1)));
             }
             t_pack = P.T | (t_ones << 16);
         }

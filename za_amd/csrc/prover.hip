@@ -2005,7 +2005,11 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         // than that (measured at 2^22: b_g2 accumulation 1.5 -> 2.1 ms with 3% real scalars)
         if (!small && (n_real < 64 || n_real * 2 < n)) continue;
         int c = 0, nwin = 0;
-        if (!msm_fbw_plan(small ? n : n_real, n, budget, elem, &c, &nwin, small)) continue;
+        // (a latency-bound witness query is planned from the field elements its witness holds -- a circuit's share of bit
+        // signals is structural -- not from its positions: 8 K field elements among 2^18 positions planned as 2^18 took 20-bit
+        // digits, 2^19 buckets and ten reduction levels where 16 bits and eight levels do; the job's buffers are still sized
+        // for any witness, and one with more field elements only runs with a narrower digit than its optimum)
+        if (!msm_fbw_plan(small ? std::max<uint64_t>(n_real, 1024) : n_real, n, budget, elem, &c, &nwin, small)) continue;
         // (not for queries in small-job mode unless mode 2 asks for their shared sort: their digits are planned for the depth
         // of each query's own chain, and the largest query's plan for all of them cost a 2^18 proof 0.35 ms)
         if (k != 0 && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2)) {
@@ -2030,7 +2034,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
                     big_real = std::max<uint64_t>(big_real, qr);
                 }
                 int cc = 0, cn = 0;
-                if (msm_fbw_plan(small ? big_n : big_real, big_n, budget, sizeof(G2Affine), &cc, &cn, small, /*always=*/true)) {
+                if (msm_fbw_plan(std::max<uint64_t>(big_real, small ? 1024 : 0), big_n, budget, sizeof(G2Affine), &cc, &cn, small, /*always=*/true)) {
                     p->w_plan_c = cc;
                     p->w_plan_nwin = cn;
                     p->w_plan_small = small;
