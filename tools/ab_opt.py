@@ -17,6 +17,8 @@ from za_amd import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("option", type=int)
 ap.add_argument("values")
+if len(sys.argv) > 2 and sys.argv[2][:1] == "-" and sys.argv[2][1:2].isdigit():   # a list that starts with a negative value
+    sys.argv[2] = " " + sys.argv[2]
 ap.add_argument("--log-m", type=int, default=22)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--proofs", type=int, default=8)
@@ -24,7 +26,7 @@ ap.add_argument("--bits", type=float, default=0.97)
 ap.add_argument("--keys", action="store_true")
 ap.add_argument("--preset", default="")
 a = ap.parse_args()
-values = [int(v) for v in a.values.split(",")]
+values = [int(v) for v in a.values.strip().split(",")]
 ctx = za_amd.Context(0)
 for kv in a.preset.split(","):
     if kv:

@@ -1,8 +1,12 @@
 # The other workloads' bench lines (one JSON line each): bash tools/bench_workloads.sh <tag>  -> gpurun_out/<tag>/bench_*.json
 # (SKIP_BIG=1: without the 2^24 / 2^26 configurations, which take ten minutes of set-up)
 tag=${1:-r0x_w}
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$ROOT}
+cd "$GRAFT_REPO_ROOT"
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
-mkdir -p $out
+mkdir -p "$out"
 uptime > $out/uptime.txt
 Q="--no-msm --no-dense --no-sha --shard-model 0 --no-cpu-baseline"
 run() { name=$1; shift; timeout 1500 python bench.py $Q "$@" 2>$out/$name.err | tail -1 > $out/bench_$name.json; }

@@ -11,8 +11,8 @@ does not), uniform SCC / VCC branches stay in the loop; --taken overrides single
 with the path marked, so the assumption can be checked against SQ_INSTS_VALU from the PMC passes
 (profiles/r0N_pmc_valu_instructions.json): static hot-path VALU count ~ measured VALU instructions per wave-level addition.
 
-Classes (VALU unless noted): mad64 = v_mad_u64_u32 (the multiplier), mul = v_mul_lo/hi, sh64 = 64-bit shifts and
-v_lshl_add_u64, alignbit, sh32, logic = and/or/xor/bfe/bfi/and_or..., add = add/sub/addc/add3 (carry chains), cndmask, mov
+Classes (VALU unless noted): mad64 = v_mad_u64_u32 (the multiplier), mul = v_mul_lo/hi, sh64 = 64-bit shifts, add64 =
+v_lshl_add_u64 (a 64-bit add: where clang joins two partial column sums), alignbit, sh32, logic = and/or/xor/bfe/bfi/and_or..., add = add/sub/addc/add3 (carry chains), cndmask, mov
 (incl. accvgpr moves, dpp, readlane), cmp, other_valu; mem = global/flat/scratch/ds/buffer; wait = s_waitcnt/s_nop;
 salu = every other scalar instruction.
 """
@@ -48,7 +48,9 @@ def classify(op):
             return "mad64"
         if op.startswith(("v_mul_lo", "v_mul_hi", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_i32", "v_mad_u32", "v_mad_i32")):
             return "mul"
-        if op.startswith(("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64", "v_lshl_add_u64")):
+        if op.startswith("v_lshl_add_u64"):
+            return "add64"
+        if op.startswith(("v_lshrrev_b64", "v_lshlrev_b64", "v_ashrrev_i64")):
             return "sh64"
         if op.startswith("v_alignbit"):
             return "alignbit"
@@ -72,10 +74,10 @@ def classify(op):
     return "salu"
 
 
-VALU = ("mad64", "mul", "sh64", "alignbit", "sh32", "logic", "add", "cndmask", "mov", "cmp", "other_valu")
+VALU = ("mad64", "mul", "sh64", "add64", "alignbit", "sh32", "logic", "add", "cndmask", "mov", "cmp", "other_valu")
 # issue cost in cycles per wave64 instruction per SIMD (tools/ubench_valu.hip): the multiplier, 64-bit
 # shifts / adds, carry-producing adds, alignbit and mul_lo are "quarter rate" (4), plain VOP2 logic / shifts / moves 2
-SLOW = {"mad64": 4, "mul": 4, "sh64": 4, "alignbit": 4, "add": 4, "sh32": 2, "logic": 2, "cndmask": 2, "mov": 2, "cmp": 2, "other_valu": 4}
+SLOW = {"mad64": 4, "mul": 4, "sh64": 4, "add64": 4, "alignbit": 4, "add": 4, "sh32": 2, "logic": 2, "cndmask": 2, "mov": 2, "cmp": 2, "other_valu": 4}
 
 
 def parse_function(dis, kernel_re):

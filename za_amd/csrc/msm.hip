@@ -1467,14 +1467,14 @@ __device__ __forceinline__ XYZZd<L> bucket_sum(const XYZZ<F>* __restrict__ parti
 // spills for G2).
 static constexpr uint32_t BITS_THREADS = 128;
 template <class F, class L, int LP>
+// (t: this lane group's index in the level, tid: its index in the workgroup -- k_bits_level derives both from the block and
+// thread indices, k_bits_tail walks a level in chunks of one workgroup)
 __device__ __forceinline__ void bits_level_body(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ partial,
                                                 const uint32_t* __restrict__ item_off, uint32_t rows_in, uint32_t kw,
                                                 uint32_t len_out, int f, uint32_t heavy_items, uint32_t ones_row,
-                                                uint32_t ones_key, XYZZ<F>* __restrict__ out) {
+                                                uint32_t ones_key, XYZZ<F>* __restrict__ out, uint32_t t, uint32_t tid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_b);   // one entry per point held (LP lanes each)
-    const uint32_t tid = threadIdx.x / LP;
-    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) / LP;
     const uint32_t g = t >> 1, q = t & 1u;
     const bool in_range = g < rows_in * len_out;
     const uint32_t row = in_range ? g / len_out : 0u, idx = g - row * len_out;
@@ -1552,7 +1552,32 @@ __global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_level(Batch<F> batch
                                                              uint32_t kw, uint32_t len_out, int f, uint32_t heavy_items,
                                                              uint32_t ones_row, uint32_t ones_key) {
     bits_level_body<F, L, LP>(batch.q[blockIdx.y].lvl_in, batch.q[blockIdx.y].partial, item_off, rows_in, kw, len_out, f, heavy_items,
-                              ones_row, ones_key, batch.q[blockIdx.y].lvl_out);
+                              ones_row, ones_key, batch.q[blockIdx.y].lvl_out, (blockIdx.x * blockDim.x + threadIdx.x) / LP,
+                              threadIdx.x / LP);
+}
+// The LAST levels of a reduction have a few dozen groups each: launches of one or two workgroups whose cost is the launch.
+// One workgroup runs them all, level after level (a level in chunks of BITS_THREADS lane groups), with a barrier in between:
+// two or three launches fewer at the end of every multiexp's chain.  Level i reads the buffer level i - 1 wrote (the two
+// buffers alternate: lvl_in is what the first of these levels reads, lvl_out what it writes).
+static constexpr int TAIL_LEVELS_MAX = 4;
+static constexpr uint32_t TAIL_LANES_MAX = 2 * BITS_THREADS;   // a level joins the tail if it has at most this many lane groups
+struct TailLevels {
+    int n;
+    uint32_t rows_in[TAIL_LEVELS_MAX], len_out[TAIL_LEVELS_MAX];
+    int f[TAIL_LEVELS_MAX];
+};
+template <class F, class L = typename LazyOf<F>::L, int LP = 1>
+__global__ void __launch_bounds__(BITS_THREADS * LP) k_bits_tail(Batch<F> batch, const uint32_t* __restrict__ item_off, TailLevels TL,
+                                                            uint32_t kw, uint32_t heavy_items, uint32_t ones_key) {
+    XYZZ<F>* buf[2] = {const_cast<XYZZ<F>*>(batch.q[blockIdx.y].lvl_in), batch.q[blockIdx.y].lvl_out};
+    for (int i = 0; i < TL.n; i++) {
+        const uint32_t lanes = TL.rows_in[i] * TL.len_out[i] * 2u;
+        for (uint32_t base = 0; base < lanes; base += BITS_THREADS) {
+            bits_level_body<F, L, LP>(buf[i & 1], batch.q[blockIdx.y].partial, item_off, TL.rows_in[i], kw, TL.len_out[i], TL.f[i],
+                                      heavy_items, ~0u, ones_key, buf[(i & 1) ^ 1], base + threadIdx.x / LP, threadIdx.x / LP);
+            __syncthreads();   // (the level's rows are written: the next level -- or chunk: the LDS slots -- may go on)
+        }
+    }
 }
 // One block sums up to ROWSUM_CH consecutive entries of one row; rows are grouped in "levels" of equal length
 // (RowMeta).  Output: one entry per block, in block order -- again rows of `chunks` entries, so the kernel is
@@ -2126,6 +2151,7 @@ struct MsmJob : MsmJobBase {
             uint32_t len = P.B, rows = (uint32_t)P.kw + xrow;
             size_t rb = 0;
             int bb = 0;
+            int tail_from = -1;   // first level that k_bits_tail runs (-1: not decided yet, -2: no tail)
             for (int l = 0; l < red_nlev; l++) {
                 len >>= red_f[l];
                 const size_t groups = (size_t)rows * len;
@@ -2139,7 +2165,40 @@ struct MsmJob : MsmJobBase {
                 // (The same on four lane pairs for G2 -- eight lanes, ds_swizzle broadcasts -- was measured: no gain.)
                 bool quad = false;
                 if constexpr (IS_G1) quad = groups * 2 <= QUAD_LEVEL_MAX_LANES;
-                if (quad) {
+                // the tail: from the first level on (never the leaf) behind which every level has at most TAIL_LANES_MAX lane
+                // groups, if there are at least two of them -- one workgroup runs them all (k_bits_tail)
+                if (tail_from < 0 && l >= 1 && red_nlev - l >= 2 && red_nlev - l <= TAIL_LEVELS_MAX && groups * 2 <= TAIL_LANES_MAX) {
+                    tail_from = l;   // (rows x len only shrinks from here on: len falls 4 : 1 while rows grows by 2 kw)
+                    uint32_t tl_len = len, tl_rows = rows;
+                    TailLevels TL{};
+                    for (int k = l; k < red_nlev; k++) {
+                        if (k > l) tl_len >>= red_f[k];
+                        if ((size_t)tl_rows * tl_len * 2 > TAIL_LANES_MAX) tail_from = -2;   // (does not shrink after all: no tail)
+                        TL.rows_in[k - l] = tl_rows;
+                        TL.len_out[k - l] = tl_len;
+                        TL.f[k - l] = red_f[k];
+                        tl_rows += (uint32_t)P.kw * red_f[k];
+                    }
+                    TL.n = red_nlev - l;
+                    if (tail_from == l) {
+                        for (unsigned q = 0; q < nb; q++) {
+                            B.q[q].lvl_in = bj[q]->S.lvl[(l - 1) & 1].template as<XYZZ<F>>();
+                            B.q[q].lvl_out = bj[q]->S.lvl[l & 1].template as<XYZZ<F>>();
+                        }
+                        if (quad) {
+                            if constexpr (IS_G1)
+                                ZG_LAUNCH(ctx, (k_bits_tail<F, FqQL, 4>), dim3(1, nb), dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, B,
+                                          SS.item_off.as<uint32_t>(), TL, (uint32_t)P.kw, heavy_items, ones_key);
+                        } else {
+                            ZG_LAUNCH(ctx, (k_bits_tail<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1, nb),
+                                      dim3(BITS_THREADS * ChainCfg<F>::LP), BITS_THREADS * sizeof(XYZZ<F>), st, B,
+                                      SS.item_off.as<uint32_t>(), TL, (uint32_t)P.kw, heavy_items, ones_key);
+                        }
+                    }
+                }
+                if (tail_from >= 0 && l >= tail_from) {
+                    // (queued with the tail above)
+                } else if (quad) {
                     if constexpr (IS_G1)
                         ZG_LAUNCH(ctx, (k_bits_level<F, FqQL, 4>), dim3((unsigned)((groups * 2 + BITS_THREADS - 1) / BITS_THREADS), nb),
                                            dim3(BITS_THREADS * 4), BITS_THREADS * sizeof(XYZZ<F>), st, B,

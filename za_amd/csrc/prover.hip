@@ -533,10 +533,21 @@ static ProveWs& prove_ws(Ctx* ctx) {
 // of the 32-byte operands, no field multiplication); everything else takes the Montgomery path.
 __device__ __forceinline__ uint32_t rev4(uint32_t x) { return __brev(x) >> 28; }
 static constexpr uint64_t R1CS_LONG_ROW = 32;   // terms; longer rows go to k_r1cs_eval_long
-__global__ void __launch_bounds__(256) k_r1cs_eval_tiled(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                                         const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
-                                                         const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
-                                                         uint64_t n_rows, Fr* __restrict__ out, int log_m) {
+// (the three matrices A, B, C in ONE launch: blockIdx.y picks the matrix -- two launches fewer on a small proof's critical path)
+struct R1csMats {
+    const uint64_t* row_ptr[3];
+    const uint32_t* col[3];
+    const Fr* coeff[3];
+    const uint8_t* ccls[3];
+    Fr* out[3];
+};
+__global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
+                                                         uint64_t n_rows, int log_m) {
+    const uint64_t* __restrict__ row_ptr = M.row_ptr[blockIdx.y];
+    const uint32_t* __restrict__ col = M.col[blockIdx.y];
+    const Fr* __restrict__ coeff = M.coeff[blockIdx.y];
+    const uint8_t* __restrict__ ccls = M.ccls[blockIdx.y];
+    Fr* __restrict__ out = M.out[blockIdx.y];
     __shared__ Fr tile[256];
     const uint32_t t = threadIdx.x, ta = t >> 4, tb = t & 15, mid = blockIdx.x;
     const uint64_t row = ((uint64_t)ta << (log_m - 4)) | ((uint64_t)mid << 4) | tb;
@@ -1455,10 +1466,16 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
         ProveWs& ws = prove_ws(ctx);
         if (!ws.wcls_fresh || ws.wcls_for != (const void*)d_w) ZG_TRY(witness_classes(ctx, r, d_w));
         ws.wcls_fresh = false;
-        for (int k = 0; k < 3; k++)
-            ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8)), dim3(256), 0, st, r->row_ptr[k].as<uint64_t>(),
-                               r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
-                               ws.wcls.as<uint8_t>(), r->n_constraints, d_abc[k], (int)r->log_m);
+        R1csMats M;
+        for (int k = 0; k < 3; k++) {
+            M.row_ptr[k] = r->row_ptr[k].as<uint64_t>();
+            M.col[k] = r->col[k].as<uint32_t>();
+            M.coeff[k] = r->coeff[k].as<Fr>();
+            M.ccls[k] = r->ccls[k].as<uint8_t>();
+            M.out[k] = d_abc[k];
+        }
+        ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8), 3), dim3(256), 0, st, M, d_w, ws.wcls.as<uint8_t>(),
+                           r->n_constraints, (int)r->log_m);
         for (int k = 0; k < 3; k++)
             if (r->n_long[k])
                 ZG_LAUNCH(ctx, k_r1cs_eval_long, dim3((r->n_long[k] + 3) / 4), dim3(256), 0, st,
