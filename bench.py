@@ -445,7 +445,10 @@ def main():
             h_ms_acc.append(ctx.last_timings()["h_ms"])   # (a ctypes read of six doubles, outside the step's clock)
     barrier()
     elapsed = time.perf_counter() - t0
-    proof_stats = ctx.last_stats() if world == 1 else None   # of the last timed step: zg_prove counts its own launches
+    try:
+        proof_stats = ctx.last_stats() if world == 1 else None   # of the last timed step: zg_prove counts its own launches
+    except AttributeError:   # (ZA_AMD_LIB pointing at an older build of the library: A/B runs)
+        proof_stats = None
     prof = ctx.profile_get()
     phases = dict(ctx.last_timings())
     upload_bytes = int(upload_sent[0]) if world > 1 else int(phases.get("upload_bytes", 0))

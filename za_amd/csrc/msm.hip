@@ -1787,15 +1787,21 @@ struct MsmJob : MsmJobBase {
         {   // Small jobs are latency bound: a thread runs its item's mixed adds one after the other (64 G2 adds are
             // 1.1 ms whatever n is).  Below ~64K items the items are shortened -- down to half the mean bucket load, so
             // that only buckets above twice the mean need the heavy-bucket fold -- and the GPU gets more, shorter threads.
-            const size_t entries = n_real * (size_t)P.nwin, target = 65536;
+            // (round 5: the target is what fills k_accumulate's wave slots -- three waves of 64 one-lane items per SIMD in G1,
+            // two waves of lane pairs in G2 -- and an item may go down to a quarter of the mean bucket load.  With 65 536 items
+            // and half the mean, the h job of a 1/8 shard (2^19 points, 2^16 buckets of ~120) ran ONE wave per SIMD: 96 ps per
+            // addition against the 71 ps of a full launch.)
+            const size_t entries = n_real * (size_t)P.nwin, target = IS_G1 ? 3 * 65536 : 65536;
+            heavy_items = HEAVY_ITEMS;
             if (entries / P.T < target) {
                 size_t t2 = std::max<size_t>(8, entries / target);
-                t2 = std::max<size_t>(t2, (entries / P.nkeys + 1) / 2);
+                t2 = std::max<size_t>(t2, (entries / P.nkeys + 3) / 4);
                 if (t2 < P.T) P.T = (uint32_t)t2;
+                // buckets up to ~2.5 x the mean load stay "light": their item sums are added up by the leaf level's lanes
+                heavy_items = (uint32_t)std::max<size_t>(HEAVY_ITEMS, (5 * (entries / P.nkeys + 1) / 2 + P.T - 1) / P.T);
             }
             t_ones = T_ONES;
-            if (n_ones / T_ONES < target / 2) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, n_ones / (target / 2)));
-            heavy_items = HEAVY_ITEMS;
+            if (n_ones / T_ONES < 32768) t_ones = (uint32_t)std::min<size_t>(T_ONES, std::max<size_t>(8, n_ones / 32768));
             if (eager_small || n <= msm_small_n(ctx)) {
                 // what counts for a small job is the number of dependent additions: T in a thread of k_accumulate, then
                 // up to heavy_items in bucket_sum.  T ~ sqrt(2 * mean load); buckets up to ~2.5 x the mean stay "light".
