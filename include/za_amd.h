@@ -125,8 +125,8 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          query.  Read when a key's tables are built (the common plan) and per proof. */
 #define ZG_OPT_SHARE_SORT 20
 /*   ZG_OPT_NTT_BATCH_LOG_M domains of up to 2^value rows: every pass of the H pipeline takes the three vectors a, b, c in ONE
- *                          launch (default 15: measured -3 % at 2^14, no difference at 2^16, +9 % at 2^18; 0 = always one vector per
- *                          launch). */
+ *                          launch (default 21: a bit-heavy 2^18 / 2^19 proof -17 %, 2^20 -6 %, 2^21 -4 %, no difference at 2^22; a dense
+ *                          witness +-1 % at 2^18 - 2^20; 0 = always one vector per launch). */
 #define ZG_OPT_NTT_BATCH_LOG_M 21
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);

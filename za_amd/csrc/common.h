@@ -48,7 +48,7 @@ struct Ctx {
     bool opt_compact_table = true;    // ZG_OPT_COMPACT_TABLE: compact window table behind the subset sums, read at table build
     int opt_h_parts = 0;              // ZG_OPT_H_PARTS: parts of the h multiexp (0 = the scheduler's choice)
     bool opt_h_pipe = false;          // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
-    int opt_ntt_batch_log_m = 15;     // ZG_OPT_NTT_BATCH_LOG_M: up to 2^value rows the H pipeline's passes take a, b, c in one launch
+    int opt_ntt_batch_log_m = 21;     // ZG_OPT_NTT_BATCH_LOG_M: up to 2^value rows the H pipeline's passes take a, b, c in one launch
     int opt_share_sort = 1;           // ZG_OPT_SHARE_SORT: 0 a sort per query; 1 b_g1 behind b_g2, and one sort for the
                                       // full-density queries of one window-table plan; 2 one sort for all of them (position maps)
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2

@@ -665,9 +665,10 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     const StagePlan P = stage_plan(log_m);
     const int L = P.n;   // >= 2 here
     Fr* v[3] = {d_a, d_b, d_c};
-    // Up to 2^opt_ntt_batch_log_m rows the passes of a, b and c are ONE launch each (blockIdx.y picks the vector): the
-    // pipeline of a small proof is a chain of short launches on its critical path -- 7 instead of 15 at 2^14.  Beyond, a
-    // pass fills the GPU on its own and the vectors go one after the other (together: measured slower at 2^22).
+    // Up to 2^opt_ntt_batch_log_m rows (default 2^21) the passes of a, b and c are ONE launch each (blockIdx.y picks the
+    // vector): the pipeline is a chain of launches on the proof's critical path, sharing the command processor with the
+    // witness multiexps' chains -- 7 launches instead of 15 at 2^14, 9 instead of 21 at 2^20 (a 2^18 proof 1.69 -> 1.40 ms, 2^20
+    // 3.64 -> 3.40).  At 2^22 a pass fills the GPU for 0.17 ms on its own and nothing is gained.
     const bool together = (int)log_m <= ctx->opt_ntt_batch_log_m;
     for (int q = 0; q < (together ? 1 : 3); q++) {
         Fr *v1 = together ? v[1] : nullptr, *v2 = together ? v[2] : nullptr;
