@@ -167,6 +167,14 @@ def test_largest_legal_domain_2p27_multiexp_and_transform(ctx):
     got = ctx.msm_resident_dev(H, d_s, n, dense_hint=True)
     assert got[:64] == want and got[64:] == bn.le32(bn.mont(1, bn.Q))
     ctx.msm_bases_free(H)
+    # (i') ONE job over all 2^27 points (the per-call entry point: no parts, no table) with the staged three-level partition
+    # forced -- its level-1 tile is capped by the kernel's 64 KB of dynamic LDS (8192-point tiles would ask for 67.7 KB)
+    import za_amd
+    ctx.set_option(za_amd.OPT_SORT_STAGED, 2)
+    try:
+        assert ctx.msm_g1_dev(d_b, d_s, n)[:64] == want
+    finally:
+        ctx.set_option(za_amd.OPT_SORT_STAGED, -1)
     # (ii) the window table built regardless (negative budget): 12 rows x 2^27 entries = 103 GB, table indices to 1.6e9
     H = ctx.msm_bases_g1_dev(d_b, n, table_budget_gb=-150.0)
     ctx.free(d_b)
