@@ -15,7 +15,7 @@ run poseidon_2p14 --workload poseidon --log-m 14 --steps 100 --warmup 10
 run poseidon_2p20 --workload poseidon --log-m 20 --steps 30 --warmup 5
 run sha256_merkle_d32 --workload sha256 --depth 32 --steps 30 --warmup 5
 run sha256_merkle_d90 --workload sha256 --depth 90 --steps 20 --warmup 5
-if [ -z "$SKIP_BIG" ]; then
+if [ -z "${SKIP_BIG:-}" ]; then
 run uniform_2p24 --log-m 24 --bit-fraction 0 --seed 0x26 --synthetic-key --provers 1 --steps 5 --warmup 2
 run uniform_2p26 --log-m 26 --bit-fraction 0 --seed 0x26 --synthetic-key --provers 1 --steps 3 --warmup 1
 run bits_2p26 --log-m 26 --synthetic-key --provers 1 --steps 3 --warmup 1
