@@ -230,11 +230,12 @@ def pmc_for(args):
     return None
 
 
-def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live, eval_form=True):
+def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live, eval_form=True, c_folded=False):
     """The H pipeline against the HBM roofline: algorithmic 64 B per element per transform."""
-    n_transforms = 6 if eval_form else 7
+    n_transforms = (4 if c_folded else 6) if eval_form else 7
     alg = n_transforms * 64 * m
-    out = {"bound": "hbm", "kernel": ("k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form: %d transforms in %d launches)"
+    out = {"bound": "hbm", "kernel": ("k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form%s: %%d transforms in %%d launches)"
+                                      % (", C rows folded into the l multiexp" if c_folded else "")
                                       if eval_form else "k_ntt_pass (H in coefficient form, bellman's %d transforms, in %d launches)")
            % (n_transforms, passes), "algorithmic_bytes": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "h_pipeline_ms_in_proof": h_ms_live,
@@ -738,7 +739,8 @@ def main():
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         roof = acc_roofline(prof, pmc=pmc_for(args))
         ntt_ms, ntt_n = prof_all["ntt_pass"][0] / n_break, prof_all["ntt_pass"][1] / n_break
-        roof_ntt = ntt_roofline(m, int(round(ntt_n)), ntt_ms, int(round(ntt_n)), h_ms_live, h_eval_form) if world == 1 else None
+        c_folded = bool(proof_stats and proof_stats.get("c_folded"))
+        roof_ntt = ntt_roofline(m, int(round(ntt_n)), ntt_ms, int(round(ntt_n)), h_ms_live, h_eval_form, c_folded) if world == 1 else None
         line = {
             "metric": "Groth16 prove constraints/sec (BN128)", "value": n_constraints * args.steps / elapsed,
             "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -769,6 +771,8 @@ def main():
                                   if 0 < upload_bytes < witness_bytes else
                                   "sent over PCIe as it is in the last step (packing applies from 2^18 values, to a mostly-0/1 "
                                   "witness)",
+                                  "H in evaluation form, the C rows' values folded into the l multiexp (4 transforms; h bases "
+                                  "transformed once per key, twice)" if h_eval_form and c_folded else
                                   "H in evaluation form (6 transforms; h bases transformed once per key)" if h_eval_form else
                                   "H in coefficient form (bellman's 7 transforms: this key has no transformed h bases)"),
                        "n_constraints": n_constraints, "n_aux": n_aux, "nnz": nnz,
@@ -788,12 +792,14 @@ def main():
             # kernel launches one zg_prove queues (hand-over kernels, R1CS evaluation, transforms, the five multiexps), and which
             # witness multiexps shared a digit sort (zg_last_stats; ZG_OPT_SHARE_SORT)
             "launches_per_proof": proof_stats["launches"] if proof_stats else None,
+            "c_rows_folded": c_folded if proof_stats else None,
             "digit_sort_sharing": {"b_g1_behind_b_g2": proof_stats["b_g1_behind_b_g2"],
                                    "one_sort_over_witness_positions_mask": proof_stats["shared_sort_mask"]} if proof_stats else None,
             "kernel_ms_per_step": {k: v[0] / n_break for k, v in prof_all.items()},
             "setup_s": t_setup,
             "key_tables": {name: {"kind": ("none", "window", "subset-sum")[P.table_info(k)[0]],
-                                  "gb": P.table_info(k)[1] / 1e9} for k, name in enumerate(("h", "l", "a", "b_g1", "b_g2"))},
+                                  "gb": P.table_info(k)[1] / 1e9}
+                           for k, name in enumerate(("h", "l", "a", "b_g1", "b_g2", "l_with_c_rows")) if k < 5 or P.table_info(k)[0]},
             "proof_sha": __import__("hashlib").sha256(bytes(proof)).hexdigest()[:16] if proof is not None else None,
         }
         if dist_line:

@@ -128,6 +128,18 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          launch (default 21: a bit-heavy 2^18 / 2^19 proof -17 %, 2^20 -6 %, 2^21 -4 %, no difference at 2^22; a dense
  *                          witness +-1 % at 2^18 - 2^20; 0 = always one vector per launch). */
 #define ZG_OPT_NTT_BATCH_LOG_M 21
+/*   ZG_OPT_C_FOLD          the quotient (a b - c) / Z is linear in c, and c's values on the domain are the C sides of the R1CS
+ *                          rows as evaluated -- for a circuit of bit signals, bits and small integers.  1 (default): for a key
+ *                          with the evaluation form whose first witness gives rows of few non-zero 16-bit digits (at most 3
+ *                          per row on average, rows equal to 2 not counted; decided once per key, with its tables), zg_prove*
+ *                          transform a and b only -- FOUR transforms instead of six -- and the C term enters as 2 m more
+ *                          points of the l multiexp (a second transformed basis and its doubles, built once per key), for
+ *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^24 rows; 2 = for every such key
+ *                          whatever its witness and size (tests); 0 = six transforms.  The proof is the same group element
+ *                          either way; the phase API always takes six.  Measured (config-4 shape, one box, alternated):
+ *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */
+#define ZG_OPT_C_FOLD 22
+#define ZG_OPT_C_FOLD_MIN_LOG_M 23
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
@@ -357,7 +369,8 @@ int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
  * free HBM); the library reads no environment variable for either.  Without room the plain per-window schedule is
  * used.  Results are identical either way. */
 int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness);
-/* Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2) currently has: kind 0 none, 1 window table (dense
+/* Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2; 5 = the l query with the C rows folded in, ZG_OPT_C_FOLD --
+ * a key that has it builds no table for the plain l query) currently has: kind 0 none, 1 window table (dense
  * assignment), 2 subset-sum table (sums over groups of four positions, for an assignment that is at least 90 % zeros
  * and ones: a group of four 0/1 scalars costs one mixed add instead of one per 1; 3.75x the query's footprint), and
  * its size in bytes. */
@@ -412,7 +425,8 @@ int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 /* ---- what the last zg_prove* call (or, for the phase API, everything since the last one) queued on the GPU:
  * [0] kernel launches, [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
  * sort over the witness positions in the last batch of multiexps (0 = none), [2] 1 if the b_g1 multiexp ran over the b_g2
- * multiexp's sorted entries (same scalars, same positions, tables of one layout), [3] reserved (0). */
+ * multiexp's sorted entries (same scalars, same positions, tables of one layout), [3] 1 if the proof ran with four
+ * transforms and its C rows folded into the l multiexp (ZG_OPT_C_FOLD). */
 int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]);
 
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline

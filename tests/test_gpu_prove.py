@@ -1136,7 +1136,7 @@ def test_sha256_merkle_circuit_setup_prove_verify(ctx):
     P.close(); R.close()
 
 
-def test_long_rows_take_the_wave_per_row_evaluator(ctx):
+def test_long_rows_take_the_wave_per_row_evaluator(ctx, opts):
     """Rows with more than 32 terms (k_r1cs_eval_long: one wave per row) next to short ones, in all three matrices, with
     field-element coefficients and values (Montgomery path), +-2^s coefficients on bits (integer path), and lengths
     around the threshold and around the wave size."""
@@ -1167,7 +1167,14 @@ def test_long_rows_take_the_wave_per_row_evaluator(ctx):
     wb = co.witness_bytes(w)
     assert R.check(wb) is None
     P, _ = ctx.setup(R, 21, 22, 23, 24, 25, want_bytes=False)
-    assert ctx.prove(P, R, wb, 8, 9) == co.prove(download_params(ctx, P), csr, wb, 8, 9, threads=4)
+    exp = co.prove(download_params(ctx, P), csr, wb, 8, 9, threads=4)
+    assert ctx.prove(P, R, wb, 8, 9) == exp
+    P.close()
+    # ... and with the C rows leaving the evaluator as scalars of the l multiexp (ZG_OPT_C_FOLD: the long C rows go through
+    # the wave-per-row kernel's other exit)
+    opts(za_amd.OPT_C_FOLD, 2)
+    P, _ = ctx.setup(R, 21, 22, 23, 24, 25, want_bytes=False)
+    assert ctx.prove(P, R, wb, 8, 9) == exp and ctx.last_stats()["c_folded"]
     P.close(); R.close()
 
 
@@ -1295,4 +1302,53 @@ def test_shared_digit_sort_with_sharded_keys(ctx, opts):
             st = ctx.last_stats()
             assert (st["shared_sort_mask"] != 0) == (share == 2) and not st["b_g1_behind_b_g2"]   # (2^13: small-job mode)
         assert ctx.prove_combine(P1, np.concatenate(parts), world, r, s) == whole
+    sr.close()
+
+
+@pytest.mark.parametrize("lg,bitf,n_in", [(10, 0.97, 2), (12, 0.9, 3), (13, 0.0, 2), (16, 0.97, 5), (19, 0.97, 2)])
+def test_c_rows_folded_into_the_l_multiexp(ctx, opts, lg, bitf, n_in):
+    """ZG_OPT_C_FOLD: the quotient (a b - c) / Z is linear in c, so the C term of the h multiexp is a multiexp of the C rows'
+    VALUES (no transform) against a second transformed basis kept behind the l query: four transforms instead of six, one l
+    query of n_aux + m points.  Mode 2 folds for every key, mode 1 where the rows evaluate to bits (decided with the key's
+    first witness), mode 0 never -- the proof bytes are the C oracle's in every mode, from a host witness and from a device
+    witness, for a witness that satisfies the circuit and for one that does not (bellman interpolates (a b - c) / Z on the
+    coset whatever it is; so do both forms here)."""
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, n_in, bitf, 8800 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    r, s = 0x7171 + lg, 0x8282 + lg
+    bad = np.array(sr.witness, copy=True)
+    bad[32 * (sr.n_inputs + 5):32 * (sr.n_inputs + 6)] = 0
+    bad[32 * (sr.n_inputs + 5)] = 3                       # one aux value changed: rows that read it no longer hold
+    exp = exp_bad = None
+    opts(za_amd.OPT_C_FOLD_MIN_LOG_M, 10)
+    for mode in (2, 1, 0):
+        opts(za_amd.OPT_C_FOLD, mode)
+        P = synth.synth_params(ctx, *sizes, 70 + lg)      # (decided per key, when its tables are built)
+        if exp is None:
+            pk = download_params(ctx, P)
+            exp = co.prove(pk, csr, sr.witness, r, s, threads=16)
+            exp_bad = co.prove(pk, csr, bad, r, s, threads=16)
+            assert exp != exp_bad
+        for _ in range(2):
+            assert ctx.prove(P, R, sr.witness, r, s) == exp
+        folded = ctx.last_stats()["c_folded"]
+        if mode == 2:
+            assert folded
+        elif mode == 0:
+            assert not folded
+        elif bitf == 0.0:
+            assert not folded                             # field elements everywhere: six transforms stay
+        elif bitf == 0.97:
+            assert folded                                 # few non-zero digits: XOR rows evaluate to 0 or 2 (90 % bits: borderline)
+        d_w = ctx.upload(sr.witness)
+        assert ctx.prove_dev(P, R, d_w, r, s) == exp
+        assert ctx.last_stats()["c_folded"] == folded
+        assert ctx.prove(P, R, bad, r, s) == exp_bad
+        assert ctx.prove(P, R, sr.witness, r, s) == exp
+        ctx.free(d_w)
+        P.close()
     sr.close()

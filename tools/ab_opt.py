@@ -59,8 +59,7 @@ dev = {v: [] for v in values}
 host = {v: [] for v in values}
 for _ in range(a.rounds):
     for v in values:
-        if not a.keys:
-            ctx.set_option(a.option, v)
+        ctx.set_option(a.option, v)   # (with --keys too: an option may be read both when the tables are built and per proof)
         ctx.prove_dev(keys[v], R, d_w, 5, 7)
         for _ in range(a.proofs):
             t0 = time.perf_counter(); ctx.prove_dev(keys[v], R, d_w, 5, 7); dev[v].append(1e3 * (time.perf_counter() - t0))

@@ -17,7 +17,10 @@ ctx = za_amd.Context(0)
 t0, n_ok = time.time(), 0
 from oracle import bn254 as bn
 from oracle.circuits import prescribed_h_r1cs
+ctx.set_option(za_amd.OPT_C_FOLD_MIN_LOG_M, 8)
 while time.time() - t0 < budget:
+    c_fold = rng.choice([0, 1, 2, 2])      # four transforms with the C rows folded into the l multiexp: never / by the rows' values / always
+    ctx.set_option(za_amd.OPT_C_FOLD, c_fold)
     if rng.random() < 0.3:
         lg = rng.choice([1, 2, 3, 5, 8, 10, 12, 13])
         m = 1 << lg
@@ -37,7 +40,7 @@ while time.time() - t0 < budget:
         got = ctx.prove(P, R, wb, r, s)
         exp = co.prove(download_params(ctx, P), csr, wb, r, s, threads=16)
         ok = bytes(got) == bytes(exp)
-        print("prescribed H lg %2d special %.1f FBW %-2d parts %s -> %s" % (lg, p_special, fbw, h_parts, "ok" if ok else "MISMATCH"), flush=True)
+        print("prescribed H lg %2d special %.1f FBW %-2d parts %s c_fold %d%s -> %s" % (lg, p_special, fbw, h_parts, c_fold, "*" if ctx.last_stats()["c_folded"] else " ", "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             sys.exit(1)
         n_ok += 1
@@ -69,7 +72,7 @@ while time.time() - t0 < budget:
     exp = co.prove(download_params(ctx, P), csr, sr.witness, r, s, threads=32)
     kinds = [P.table_info(k)[0] for k in range(5)]
     ok = bytes(got) == bytes(exp)
-    print("lg %2d bits %.2f inputs %d FBW %-2d parts %s tables %s entry %-6s -> %s" % (lg, bf, n_in, fbw, h_parts, kinds, entry, "ok" if ok else "MISMATCH"), flush=True)
+    print("lg %2d bits %.2f inputs %d FBW %-2d parts %s c_fold %d%s tables %s entry %-6s -> %s" % (lg, bf, n_in, fbw, h_parts, c_fold, "*" if ctx.last_stats()["c_folded"] else " ", kinds, entry, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)
     n_ok += 1

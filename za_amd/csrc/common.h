@@ -51,6 +51,9 @@ struct Ctx {
     int opt_ntt_batch_log_m = 21;     // ZG_OPT_NTT_BATCH_LOG_M: up to 2^value rows the H pipeline's passes take a, b, c in one launch
     int opt_share_sort = 1;           // ZG_OPT_SHARE_SORT: 0 a sort per query; 1 b_g1 behind b_g2, and one sort for the
                                       // full-density queries of one window-table plan; 2 one sort for all of them (position maps)
+    int opt_c_fold = 1;               // ZG_OPT_C_FOLD: 0 six transforms; 1 four where the C rows evaluate to bits (decided per key, when
+                                      // its tables are built); 2 four for every key that has the evaluation form (tests)
+    int opt_c_fold_min_log_m = 20;    // ZG_OPT_C_FOLD_MIN_LOG_M: mode 1 only from domains of 2^value rows
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev
     std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
@@ -82,6 +85,7 @@ struct Ctx {
     uint64_t n_launches = 0;
     unsigned last_share_mask = 0;
     bool last_follow_g2 = false;
+    bool last_c_fold = false;
     bool stats_keep = false;   // zg_prove / zg_prove_packed cleared the counter for the zg_prove_dev they are about to call
 };
 
@@ -216,6 +220,9 @@ struct MsmDesc {
     // (the b_g1 query only) its table is laid out like the b_g2 query's -- same kind, digits, group width, compact rows --
     // so its job may run over the G2 job's sorted entries instead of sorting the same scalars again
     bool follow_g2 = false;
+    // optional (witness queries): the job's stream also waits for this event (the l query with the C rows folded in reads
+    // scalars that the R1CS evaluation writes)
+    hipEvent_t gate = nullptr;
 };
 int msm_quad_build_g1(Ctx* ctx, const G1Affine* d_bases, size_t n, G1Affine* d_buf, int qw);
 int msm_quad_build_g2(Ctx* ctx, const G2Affine* d_bases, size_t n, G2Affine* d_buf, int qw);
@@ -264,10 +271,14 @@ int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out)
 // a key's h_eval bases (heval.hip).  Six transforms in 4 L - 3 launches.  a, b, c as for h_poly_dev; clobbered.
 int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit = 0, const hipEvent_t* ev_split = nullptr);
 struct FrLimbs;
-int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits);
+int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits,
+                         Fr* cfold_int = nullptr);
 // heval.hip: d_out[p] (m affine points, device form) = sum_i omega^(-i bitrev(p)) (g^-i / m) H_i over the first m - 1
 // points of the h query -- the bases that go with h_eval_dev's scalars.  One-time work per key.
-int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log_m, G1Affine* d_out);
+// c_fold: d_out[j] (NATURAL order) = -(1 / (m Z(g))) sum_i omega^(-i j) H_i -- the bases that go with the C rows' values
+// when the C term of the quotient is folded into the l multiexp (h_eval_dev with d_c == NULL) -- and d_out[m + j] = 2 d_out[j]:
+// 2 m points
+int h_eval_bases_build(Ctx* ctx, const G1Affine* d_h, uint64_t n_h, uint32_t log_m, G1Affine* d_out, bool c_fold = false);
 // prover.hip: give a SHARDED key its slice of the evaluation-form h bases from the whole query (device form, on this
 // device); no-op (state -1) when the query length is not 2^k - 1 or ZG_OPT_H_EVAL is 0
 int params_h_eval_slice(Ctx* ctx, const struct ::zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full);

@@ -71,6 +71,14 @@ struct zg_params {
     mutable int h_eval_state = 0;
     mutable uint64_t h_eval_lo = 0, h_eval_hi = 0;
     mutable Fbw fbw_he;
+    // "C folded" (prover.hip ensure_c_fold; unsharded keys with the evaluation form): the l query followed by the m bases
+    // that go with the C rows' values and their doubles (heval.hip c_fold) as ONE query of lc_n_l + 2 m points, and its table.  States as
+    // h_eval_state.
+    mutable zg::DevBuf lc;
+    mutable int lc_state = 0;
+    mutable uint32_t lc_log_m = 0;
+    mutable uint64_t lc_n_l = 0;
+    mutable Fbw fbw_lc;
 };
 
 

@@ -2634,6 +2634,8 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     // witness queries
     const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
     const int* w_slot = &job_slot[1];
+    for (int q = 0; q < 4; q++)
+        if (wq[q]->gate && wq[q]->n) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[w_slot[q]], wq[q]->gate, 0));
     std::unique_ptr<MsmJob<Fq>> wj1[3];
     std::unique_ptr<MsmJob<Fq2>> wj2;
     for (int q = 0; q < 3; q++) wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);

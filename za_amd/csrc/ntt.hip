@@ -35,6 +35,7 @@ struct NttTables {
     Fr zinv;                            // 1/(g^m - 1)  (M261, for kernels)
     Fr minv_host;                       // 1/m in the host's 2^256 form
     Fr zinv_int;                        // 1/(g^m - 1) as a plain integer (k_ntt_tail3 / k_h_quotient leave Montgomery form with it)
+    Fr cfold_int;                       // -1 / (m (g^m - 1)) as a plain integer: the scale of the folded C bases (heval.hip)
     int lo_bits = 0;
 };
 
@@ -125,6 +126,7 @@ static int get_tables(Ctx* ctx, uint32_t log_m, NttTables** out) {
     T->minv = host_to_m261(T->minv_host);
     T->zinv = host_to_m261((g.pow_u64(m) - Fr::one()).inv());
     T->zinv_int = (g.pow_u64(m) - Fr::one()).inv().from_mont();
+    T->cfold_int = (Fr::zero() - (g.pow_u64(m) - Fr::one()).inv() * T->minv_host).from_mont();
     const size_t half = m > 1 ? m / 2 : 1;
     int rc = ZG_OK;
     auto A = [&](DevBuf& b, size_t n) {
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_tail3(const Fr* __restri
     const uint32_t tile_elems = G.elems();
     const size_t lomask = ((size_t)1 << lo_bits) - 1;
 #pragma unroll 1
-    for (int v = 0; v < 3; v++) {
+    for (int v = c ? 0 : 1; v < 3; v++) {   // (c == NULL: the C term is folded into the l multiexp, see h_eval_dev)
         const Fr* d = v == 0 ? c : v == 1 ? b : a;
         if (tile_elems == 4u * NTT_THREADS) {
             Fr raw[4];
@@ -351,7 +353,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_tail3(const Fr* __restri
         const size_t g = G.hbase + li;
         const FrD ab = T.get(li).reduce() * FrD::load_red(&b[g]);
         // an M261 residue times a plain integer is the plain product: (a b - c) / Z leaves Montgomery form here
-        (FrD::sub<3>(ab, FrD::load_red(&c[g])) * z).canonical().store(&out[g]);
+        if (c)
+            (FrD::sub<3>(ab, FrD::load_red(&c[g])) * z).canonical().store(&out[g]);
+        else
+            (ab * z).canonical().store(&out[g]);
     }
 }
 
@@ -633,7 +638,7 @@ static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int 
     int j, contiguous;
     pass_geometry(log_m, s_lo, k, &j, &contiguous);
     const size_t tiles = ((size_t)1 << log_m) >> (k + j);
-    const unsigned nv = d1 ? 3u : 1u;   // (one vector, or a, b, c together)
+    const unsigned nv = d2 ? 3u : d1 ? 2u : 1u;   // (one vector, or a, b (, c) together)
     ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)nv * 64 << log_m, nullptr, ((uint64_t)nv * k << log_m) >> 1);
     ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles, nv), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
                        (int)log_m, s_lo, k, j, contiguous, no_fuse(), d1, d2);
@@ -643,6 +648,11 @@ static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int 
 
 // a, b, c: device form (M261, reduce()d), row i at index bitrev(i), zero padded; clobbered.  d_e_out: m plain integers,
 // e[p] = the quotient's value at g * omega^bitrev(p) -- the scalars that go with the key's h_eval bases.
+// d_c == NULL ("C folded", prover.hip ensure_c_fold): FOUR transforms.  The quotient is linear in c,
+//     sum_p e[p] H_eval[p] = sum_p (a b / Z)[p] H_eval[p]  -  (1 / Z) sum_p c(g omega^bitrev(p)) H_eval[p],
+// and the second sum is sum_j c_j [ (1/m) sum_i omega^(-i j) H_i ] over c's VALUES ON THE DOMAIN (the R1CS rows as they
+// are evaluated: no transform at all) against a second per-key transformed basis (heval.hip, c_fold) -- so e = a b / Z
+// here and the caller adds the multiexp of the rows' c values, which for a circuit of bit signals are bits themselves.
 // nsplit > 0: the last kernel runs in nsplit launches over consecutive ranges of e -- range k covers the positions
 // below min(m, (k + 1) * ceil(m / nsplit)) -- with ev_split[k] recorded behind launch k: part k of the h multiexp starts
 // its digit sort while the rest of e is still being computed.
@@ -655,7 +665,8 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     const Fr *hi = T->g_hi_minv.as<Fr>(), *lo = T->g_lo.as<Fr>();
     const size_t m = (size_t)1 << log_m;
     if (log_m <= (uint32_t)NTT_LOG_TILE) {   // the whole domain is one tile
-        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)6 * 64 << log_m, nullptr, ((uint64_t)6 * log_m << log_m) >> 1);
+        const uint64_t nt = d_c ? 6 : 4;
+        ProfScope ps(ctx, PROF_NTT_PASS, nt * 64 << log_m, nullptr, (nt * log_m << log_m) >> 1);
         ZG_LAUNCH(ctx, k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
                            (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out, 0u);
         for (int k = 0; k < nsplit; k++) ZG_HIP(ctx, hipEventRecord(ev_split[k], ctx->stream));
@@ -670,9 +681,10 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     // witness multiexps' chains -- 7 launches instead of 15 at 2^14, 9 instead of 21 at 2^20 (a 2^18 proof 1.69 -> 1.40 ms, 2^20
     // 3.64 -> 3.40).  At 2^22 a pass fills the GPU for 0.17 ms on its own and nothing is gained.
     const bool together = (int)log_m <= ctx->opt_ntt_batch_log_m;
-    for (int q = 0; q < (together ? 1 : 3); q++) {
-        Fr *v1 = together ? v[1] : nullptr, *v2 = together ? v[2] : nullptr;
-        const unsigned nv = together ? 3u : 1u;
+    const int n_vec = d_c ? 3 : 2;
+    for (int q = 0; q < (together ? 1 : n_vec); q++) {
+        Fr *v1 = together ? v[1] : nullptr, *v2 = together ? v[2] : nullptr;   // (v[2] == NULL: a and b only)
+        const unsigned nv = together ? (unsigned)n_vec : 1u;
         for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p], v1, v2));
         {
             int j, contiguous;
@@ -689,7 +701,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
         int j, contiguous;
         pass_geometry(log_m, 0, P.k[0], &j, &contiguous);
         const size_t tiles = m >> (P.k[0] + j);
-        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)4 * 32 << log_m, nullptr, ((uint64_t)3 * P.k[0] << log_m) >> 1);
+        ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)(n_vec + 1) * 32 << log_m, nullptr, ((uint64_t)n_vec * P.k[0] << log_m) >> 1);
         const int ns = nsplit > 0 ? nsplit : 1;
         const size_t chunk = (m + ns - 1) / ns, tile_elems = (size_t)1 << (P.k[0] + j);
         size_t t0 = 0;
@@ -709,9 +721,11 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
 }
 
 // What heval.hip needs of the tables: omega^-i in limb form (i < m/2) and the two-level tables of g^-i / m
-int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits) {
+int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits,
+                         Fr* cfold_int) {
     NttTables* T;
     ZG_TRY(get_tables(ctx, log_m, &T));
+    if (cfold_int) *cfold_int = T->cfold_int;
     *tw_inv = T->tw_inv.as<FrLimbs>();
     *gi_lo = T->gi_lo.as<Fr>();
     *gi_hi_int = T->gi_hi_canon.as<Fr>();

@@ -167,6 +167,24 @@ __global__ void k_input_rows(const Fr* __restrict__ w, uint32_t n_inputs, uint64
     FrD::to_mont(FrD::load_canon(&w[i])).reduce().store(&a[dst]);
 }
 
+// sum over v[0..n) of the non-zero 16-bit digits of each value: what a multiexp of these scalars costs in additions (zero
+// digits are skipped), whatever their classes are -- a row whose C side evaluates to 2 is "anything else" by class and one
+// addition by cost
+__global__ void __launch_bounds__(256) k_count_digits16(const Fr* __restrict__ v, size_t n, unsigned long long* __restrict__ out) {
+    __shared__ uint32_t part[4];
+    uint32_t cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Fr x = v[i];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cnt += ((x.l[q] & 0xffffu) != 0) + ((x.l[q] >> 16) != 0);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)part[0] + part[1] + part[2] + part[3]);
+}
+
 // first row with a*b != c (mod r): atomicMin over the row index
 __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
                                                     uint64_t n_rows, unsigned long long* __restrict__ first_bad) {
@@ -482,6 +500,7 @@ struct HostPacker {
 
 struct ProveWs {
     DevBuf abc[3], h, wcls, w;
+    DevBuf w_lc;   // "C folded", witness in the caller's memory: [aux part of the witness | the C rows' values] (c_fold_buffers)
     // zg_prove's host-side packing (see there): the packer (pool + per-slice lists) and the pinned staging of the packed form
     std::unique_ptr<HostPacker> packer;
     double pack_ema_ms = 0;   // running average of the packing pass's host time
@@ -540,7 +559,26 @@ struct R1csMats {
     const Fr* coeff[3];
     const uint8_t* ccls[3];
     Fr* out[3];
+    // "C folded" (ensure_c_fold): matrix 2's rows leave as plain integers in ROW order with their class bytes (0 / 1 /
+    // other, as k_witness_classes) -- scalars of a multiexp, not input of a transform -- and out[2] is not written.
+    // 2 m values: row j at [j], except that a row evaluating to 2 is written as 0 there and as 1 at [m + j] (the doubled
+    // bases, heval.hip)
+    Fr* c_nat = nullptr;
+    uint8_t* c_cls = nullptr;
 };
+__device__ __forceinline__ void store_folded_c(Fr* __restrict__ c_nat, uint8_t* __restrict__ c_cls, uint64_t row, uint64_t m, Fr cv) {
+    const bool small = (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0 && cv.l[0] <= 2;
+    const bool two = small && cv.l[0] == 2;
+    Fr hi = Fr::zero();
+    if (two) {
+        cv.l[0] = 0;
+        hi.l[0] = 1;
+    }
+    c_nat[row] = cv;
+    c_cls[row] = small ? (uint8_t)cv.l[0] : (uint8_t)2;
+    c_nat[m + row] = hi;
+    c_cls[m + row] = two ? (uint8_t)1 : (uint8_t)0;
+}
 __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
                                                          uint64_t n_rows, int log_m) {
     const uint64_t* __restrict__ row_ptr = M.row_ptr[blockIdx.y];
@@ -597,6 +635,12 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* _
             acc = FrD::sub<2>(acc, FrD::to_mont(FrD::load_canon(&v)));
         }
     }
+    if (blockIdx.y == 2 && M.c_nat) {   // (uniform over the workgroup)
+        Fr cv;
+        acc.reduce().from_mont().store(&cv);
+        store_folded_c(M.c_nat, M.c_cls, row, (uint64_t)1 << log_m, cv);
+        return;
+    }
     acc.reduce().store(&tile[t]);
     __syncthreads();
     const uint32_t src = (rev4(t & 15) << 4) | rev4(t >> 4);
@@ -612,7 +656,8 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
                                                         const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                         const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
                                                         const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
-                                                        Fr* __restrict__ out, int log_m) {
+                                                        Fr* __restrict__ out, int log_m, Fr* __restrict__ c_nat,
+                                                        uint8_t* __restrict__ c_cls) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_long) return;
     const uint64_t row = rows[wave];
@@ -665,7 +710,11 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
 #endif
         acc = (acc + o).reduce();
     }
-    if (lane == 0) {
+    if (lane == 0 && c_nat) {   // (R1csMats::c_nat)
+        Fr cv;
+        acc.from_mont().store(&cv);
+        store_folded_c(c_nat, c_cls, row, (uint64_t)1 << log_m, cv);
+    } else if (lane == 0) {
         // the tiled kernel's destination: row = (ta, mid, tb) -> (ta, bitrev(mid), tb) with ta / tb swapped and reversed
         const uint32_t ta = (uint32_t)(row >> (log_m - 4)), tb = (uint32_t)(row & 15);
         const uint32_t mid = (uint32_t)((row >> 4) & (((uint64_t)1 << (log_m - 8)) - 1));
@@ -834,6 +883,14 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             if (value < 0 || value > 2) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_SHARE_SORT takes 0, 1 or 2");
             ctx->opt_share_sort = (int)value;
             return ZG_OK;
+        case ZG_OPT_C_FOLD:
+            if (value < 0 || value > 2) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_C_FOLD takes 0, 1 or 2");
+            ctx->opt_c_fold = (int)value;
+            return ZG_OK;
+        case ZG_OPT_C_FOLD_MIN_LOG_M:
+            if (value < 0 || value > 28) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_C_FOLD_MIN_LOG_M: 0 .. 28");
+            ctx->opt_c_fold_min_log_m = (int)value;
+            return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -883,7 +940,7 @@ extern "C" int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]) try {
     stats[0] = ctx->n_launches;
     stats[1] = ctx->last_share_mask;
     stats[2] = ctx->last_follow_g2 ? 1 : 0;
-    stats[3] = 0;
+    stats[3] = ctx->last_c_fold ? 1 : 0;
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(nullptr);
@@ -1423,7 +1480,7 @@ extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) try {
 static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   // queued on ctx->stream
     ProveWs& ws = prove_ws(ctx);
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
-    ZG_HIP(ctx, ws.wcls.reserve(nv));
+    ZG_HIP(ctx, ws.wcls.reserve(nv + ((size_t)2 << r->log_m)));   // (behind the witness: the classes of the C rows' values, c_fold_buffers)
     if (!ws.bad_host) {
         ZG_HIP(ctx, ws.bad.reserve(8));
         ZG_HIP(ctx, hipHostMalloc((void**)&ws.bad_host, 8, hipHostMallocDefault));
@@ -1455,7 +1512,9 @@ static int witness_verdict(zg_ctx* ctx) {
 
 // d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
 // stored at index bitrev(i) (what h_poly_dev consumes)
-static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev) {
+// c_nat / c_cls (both or neither; needs the tiled path: bitrev, log_m >= 8, at least one constraint): see R1csMats
+static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev, Fr* c_nat = nullptr,
+                         uint8_t* c_cls = nullptr) {
     const size_t m = (size_t)1 << r->log_m;
     hipStream_t st = ctx->stream;
     const int rev_bits = bitrev ? (int)r->log_m : 0;
@@ -1474,6 +1533,8 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
             M.ccls[k] = r->ccls[k].as<uint8_t>();
             M.out[k] = d_abc[k];
         }
+        M.c_nat = c_nat;
+        M.c_cls = c_cls;
         ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8), 3), dim3(256), 0, st, M, d_w, ws.wcls.as<uint8_t>(),
                            r->n_constraints, (int)r->log_m);
         for (int k = 0; k < 3; k++)
@@ -1481,12 +1542,14 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
                 ZG_LAUNCH(ctx, k_r1cs_eval_long, dim3((r->n_long[k] + 3) / 4), dim3(256), 0, st,
                                    r->long_rows[k].as<uint32_t>(), r->n_long[k], r->row_ptr[k].as<uint64_t>(),
                                    r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
-                                   ws.wcls.as<uint8_t>(), d_abc[k], (int)r->log_m);
+                                   ws.wcls.as<uint8_t>(), d_abc[k], (int)r->log_m, k == 2 ? c_nat : nullptr,
+                                   k == 2 ? c_cls : nullptr);
         ZG_LAUNCH(ctx, k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
                            r->n_constraints, d_abc[0], rev_bits);
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
     }
+    if (c_nat) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows need the tiled evaluator");
     for (int k = 0; k < 3; k++) {
         if (bitrev || r->n_constraints == 0)
             ZG_HIP(ctx, hipMemsetAsync(d_abc[k], 0, m * sizeof(Fr), st));   // padding is scattered
@@ -1696,16 +1759,23 @@ static int gate_events(zg_ctx* ctx) {
 }
 
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
+// c_nat / c_cls (evaluation form only): the C rows' values leave as multiexp scalars (R1csMats::c_nat) and the pipeline
+// transforms a and b only (h_eval_dev with d_c == NULL)
 static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr,
-                           bool eval_form = false, int h_split = 0) {
+                           bool eval_form = false, int h_split = 0, Fr* c_nat = nullptr, uint8_t* c_cls = nullptr) {
     const size_t m = (size_t)1 << r->log_m;
     ProveWs& ws = prove_ws(ctx);
     Fr* abc[3];
     for (int k = 0; k < 3; k++) {
+        if (k == 2 && c_nat) {
+            abc[k] = nullptr;
+            continue;
+        }
         ZG_HIP(ctx, ws.abc[k].reserve(m * sizeof(Fr)));
         abc[k] = ws.abc[k].as<Fr>();
     }
-    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0));
+    if (c_nat && !eval_form) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows without the evaluation form");
+    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0, c_nat, c_cls));
     if (ev_eval_done) ZG_HIP(ctx, hipEventRecord(ev_eval_done, ctx->stream));
     if (eval_form) return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out, h_split, h_split ? ctx->h_split_ev : nullptr);
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
@@ -1891,7 +1961,9 @@ static int ensure_h_eval(Ctx* ctx, const zg_params* p, uint32_t log_m, bool retr
     return ZG_OK;
 }
 
-static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask, bool h_eval_form = false) {
+// lc_form: use[1] is the l query with the C rows' bases behind it (ensure_c_fold) and its table is zg_params::fbw_lc
+static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], unsigned mask, bool h_eval_form = false,
+                         bool lc_form = false) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     static const int order[5] = {4, 0, 1, 2, 3};
     // The witness queries that get a WINDOW table get it with one common plan (c, nwin) where they can, decided when the
@@ -1901,7 +1973,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
     bool w_counted[5] = {false, false, false, false, false};
     for (int oi = 0; oi < 5; oi++) {
         const int k = order[oi];
-        auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
+        auto& t = k == 0 && h_eval_form ? p->fbw_he : k == 1 && lc_form ? p->fbw_lc : p->fbw[k];
         const uint64_t n = use[k].n;
         if (!(mask & (1u << k)) || n == 0) continue;
         if (k != 0 && !use[k].scalars) continue;   // zg_params_prepare without a witness: only the h table
@@ -1948,7 +2020,8 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         const zg_params::Fbw* twin = k == 3 && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2) && p->fbw[4].state == 1 &&
                                                  p->fbw[4].n == n && p->fbw[4].small == small
                                          ? &p->fbw[4] : nullptr;
-        if (!small && k != 0 && (n - n_real) * 10 >= n * 9 && n >= 1024) {
+        // (the folded l query from 60 %: rows that evaluate to small integers are "anything else" by class, and cheap)
+        if (!small && k != 0 && (n - n_real) * 10 >= n * (k == 1 && lc_form ? 6 : 9) && n >= 1024) {
             // a mostly-0/1 assignment: subset sums over groups of four positions halve the additions of its 1s
             // groups of eight positions (255 sums: 2 KB per position) where that fits, else of four (240 B per position);
             // (ZG_OPT_SUBSET_W = 4 | 8)
@@ -2029,7 +2102,7 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         if (!msm_fbw_plan(small ? std::max<uint64_t>(n_real, 1024) : n_real, n, budget, elem, &c, &nwin, small)) continue;
         // (not for queries in small-job mode unless mode 2 asks for their shared sort: their digits are planned for the depth
         // of each query's own chain, and the largest query's plan for all of them cost a 2^18 proof 0.35 ms)
-        if (k != 0 && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2)) {
+        if (k != 0 && !(k == 1 && lc_form) && ctx->opt_share_sort && (!small || ctx->opt_share_sort >= 2)) {
             // the common plan of the witness queries' window tables: made with the first one built from the largest query
             // that will take this path (same mode: small or not), then reused while it fits this query's budget
             if (p->w_plan_c == 0) {
@@ -2119,10 +2192,161 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
     return ZG_OK;
 }
 
-extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) try {
-    if (!p || which < 0 || which > 4 || !kind || !bytes) return ZG_E_INVALID_ARG;
+// ---- "C folded": four transforms per proof instead of six (ZG_OPT_C_FOLD; ntt.hip h_eval_dev, heval.hip c_fold)
+// The C term of the quotient enters the proof as  sum_j c_j C_j  over the values c_j of the R1CS rows' C sides -- and C's two
+// transforms go.  l and the h term are only ever ADDED in a proof (bellman: g_c = ... + h + l), so the m bases C_j are kept
+// behind the l query as ONE query of n_l + 2 m points: no sixth multiexp, no sixth chain of launches.  Its scalars are the
+// aux part of the witness followed by the c_j, its class bytes likewise (both contiguous: c_fold_buffers); the second m
+// points are the doubled bases, for the rows that evaluate to 2 (R1csMats::c_nat).  Worth it where
+// the c_j are bits -- the subset-sum table makes their multiexp one addition per eight rows -- which is decided once per
+// key, from the witness its tables are first built for (as the tables' own plans are).  Unsharded keys, zg_prove* only: the
+// phase API keeps six transforms (its h scalars and its l partial are documented quantities).
+// mode 1's sizes: from ZG_OPT_C_FOLD_MIN_LOG_M (below 2^20 the folded l job's longer chain costs more than two transforms of
+// a short pipeline save) to 2^24 (beyond it the job's sort buffers, sized for 3 x the positions, are not what the tables'
+// budget was planned with: not measured, so not taken)
+static constexpr int C_FOLD_MAX_LOG_M = 24;
+static bool c_fold_size_ok(const Ctx* ctx, uint32_t log_m) {
+    return ctx->opt_c_fold >= 2 || ((int)log_m >= ctx->opt_c_fold_min_log_m && (int)log_m <= C_FOLD_MAX_LOG_M);
+}
+static uint64_t c_fold_n_l(const zg_params* p, const zg_r1cs* r) {
+    const auto& q = p->q[1];
+    const uint64_t hi = std::min<uint64_t>(q.hi, r->n_aux);
+    return hi > q.lo ? hi - q.lo : 0;
+}
+static bool c_fold_ready(const zg_params* p, const zg_r1cs* r) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
-    const auto& t = which == 0 && p->fbw_he.state == 1 ? p->fbw_he : p->fbw[which];
+    return p->lc_state == 1 && p->lc_log_m == r->log_m && p->lc_n_l == c_fold_n_l(p, r) && p->h_eval_state == 1 &&
+           p->h_eval_log_m == r->log_m;
+}
+// The folded query's scalars and class bytes for this witness: [aux values | c rows] and [aux classes | c classes].
+// In the context's own witness buffer (zg_prove: it is allocated with room for the rows) nothing is copied; a caller's
+// device witness has its aux part copied once (134 MB at 2^22: 0.06 ms on the context's stream).
+struct CFoldBufs {
+    const uint32_t* scalars = nullptr;   // n_l + 2 m values
+    const uint8_t* cls = nullptr;
+    Fr* c_nat = nullptr;
+    uint8_t* c_cls = nullptr;
+};
+static int c_fold_buffers(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, uint64_t n_l, CFoldBufs* out) {
+    ProveWs& ws = prove_ws(ctx);
+    const size_t m = (size_t)1 << r->log_m, nv = (size_t)r->n_inputs + r->n_aux;
+    if (n_l != r->n_aux) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows need the whole l query");
+    ZG_HIP(ctx, ws.wcls.reserve(nv + 2 * m));
+    Fr* base;
+    if (d_witness == ws.w.p && ws.w.bytes >= (nv + 2 * m) * 32) {
+        base = ws.w.as<Fr>() + r->n_inputs;
+    } else {
+        ZG_HIP(ctx, ws.w_lc.reserve((n_l + 2 * m) * 32));
+        base = ws.w_lc.as<Fr>();
+        if (n_l)
+            ZG_HIP(ctx, hipMemcpyAsync(base, (const Fr*)d_witness + r->n_inputs, n_l * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    out->scalars = (const uint32_t*)base;
+    out->c_nat = base + n_l;
+    out->cls = ws.wcls.as<uint8_t>() + r->n_inputs;
+    out->c_cls = ws.wcls.as<uint8_t>() + nv;
+    return ZG_OK;
+}
+// States of zg_params::lc_state as h_eval_state (0 not tried, 2 being built, 1 built and immutable, -1 not for this key).
+// Blocking (a group transform of the h query and a table: ~2 s at 2^22), once per key, outside fbw_mu.
+static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, bool retry = false) {
+    if (p->world != 1 || !ctx->opt_c_fold || !d_witness) return ZG_OK;
+    const uint32_t log_m = r->log_m;
+    const uint64_t m = (uint64_t)1 << log_m, n_l = c_fold_n_l(p, r);
+    {
+        std::lock_guard<std::mutex> lock(p->fbw_mu);
+        if (p->lc_state == 1 || p->lc_state == 2) return ZG_OK;
+        if (p->lc_state == -1 && !retry) return ZG_OK;
+        if (ctx->one_shot) return ZG_OK;
+        if (p->h_eval_state == 0 || p->h_eval_state == 2) return ZG_OK;   // not yet known: ask again with the next proof
+        const bool can = p->h_eval_state == 1 && p->h_eval_log_m == log_m && log_m >= 8 && r->n_constraints != 0 &&
+                         n_l == r->n_aux && n_l + 2 * m < ((uint64_t)1 << 31) && p->q[0].total >= m - 1;
+        if (!can || !c_fold_size_ok(ctx, log_m)) {
+            if (!can) p->lc_state = -1;   // (a size limit of mode 1 is the context's, not the key's: the state stays)
+            return ZG_OK;
+        }
+        p->lc_state = 2;
+    }
+    DevBuf built;
+    bool ok = false;
+    int rc = ZG_OK;
+    try {
+        do {
+            // the C rows for THIS witness: is their multiexp a bit job?
+            CFoldBufs cb;
+            if ((rc = c_fold_buffers(ctx, r, d_witness, n_l, &cb)) != ZG_OK) break;
+            ProveWs& ws = prove_ws(ctx);
+            Fr* abc[3] = {nullptr, nullptr, nullptr};
+            for (int k = 0; k < 2 && rc == ZG_OK; k++) {
+                if (ws.abc[k].reserve(m * sizeof(Fr)) != hipSuccess) rc = ZG_E_HIP;
+                abc[k] = ws.abc[k].as<Fr>();
+            }
+            if (rc != ZG_OK) break;
+            if ((rc = r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/true, cb.c_nat, cb.c_cls)) != ZG_OK) break;
+            uint64_t zeros = 0, ones = 0;
+            if ((rc = msm_classify_counts(ctx, cb.scalars, nullptr, n_l + 2 * m, &zeros, &ones)) != ZG_OK) break;
+            // What the rows cost as a multiexp: their non-zero 16-bit digits (an addition each; rows equal to 2 are ones on
+            // the doubled bases and not counted).  Two transforms of m elements are worth ~3.4 additions per row (1.0 ms
+            // against 71 ps per addition at 2^22); folded up to 3 digits per row -- a bit-level circuit has 0.3 - 0.8 (AND
+            // rows: bits; XOR rows as (2a) b = a + b - c: 0 or 2; adder rows: a word), the config-4 recipe at 90 % bits 1.8 (2^22:
+            // 11.66 -> 10.88 ms folded), a circuit of field elements (Poseidon) 16 (2^20: 7.5 -> 8.4 ms folded).
+            DevBuf cnt;
+            unsigned long long nz = 0;
+            if (cnt.alloc(8) != hipSuccess || hipMemsetAsync(cnt.p, 0, 8, ctx->stream) != hipSuccess) break;
+            ZG_LAUNCH(ctx, k_count_digits16, dim3((unsigned)std::min<uint64_t>((m + 255) / 256, 4096)), dim3(256), 0, ctx->stream, cb.c_nat,
+                      (size_t)m, (unsigned long long*)cnt.p);
+            if (hipMemcpyAsync(&nz, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                break;
+            if (trace_level() != 0)
+                fprintf(stderr, "[za_amd trace] c_fold: %llu zeros, %llu ones among %llu aux values + 2 x %llu rows; the rows hold %llu digits\n",
+                        (unsigned long long)zeros, (unsigned long long)ones, (unsigned long long)n_l, (unsigned long long)m, nz);
+            if (ctx->opt_c_fold == 1 && nz > m * 3) break;   // field elements: six transforms stay
+            if (built.alloc((n_l + 2 * m) * sizeof(G1Affine)) != hipSuccess) break;
+            if (n_l && hipMemcpyAsync(built.p, p->q[1].buf.p, n_l * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                break;
+            if ((rc = h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, built.as<G1Affine>() + n_l, /*c_fold=*/true)) != ZG_OK)
+                break;
+            QueryUse u[5] = {};
+            u[1] = QueryUse{built.p, cb.scalars, nullptr, n_l + 2 * m, cb.cls};
+            {
+                std::lock_guard<std::mutex> lock(p->fbw_mu);
+                p->fbw_lc.buf.release();
+                p->fbw_lc.rank.release();
+                p->fbw_lc.state = 0;
+            }
+            if ((rc = ensure_tables(ctx, p, u, 2u, false, /*lc_form=*/true)) != ZG_OK) break;
+            ok = true;   // (with whatever table the folded query got, or none: ensure_tables' rules and budget)
+            if (trace_level() != 0)
+                fprintf(stderr, "[za_amd trace] c_fold: table state %d kind %d (%zu bytes)\n", p->fbw_lc.state, p->fbw_lc.kind, p->fbw_lc.buf.bytes);
+        } while (false);
+    } catch (...) {
+        rc = ZG_E_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (trace_level() != 0) fprintf(stderr, "[za_amd trace] c_fold: rc %d ok %d (%s)\n", rc, (int)ok, ctx->last_error.c_str());
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    if (rc != ZG_OK || !ok) {   // a fallback to six transforms, never an error
+        (void)hipGetLastError();
+        ctx->last_error.clear();
+        p->fbw_lc.buf.release();
+        p->fbw_lc.rank.release();
+        p->fbw_lc.state = 0;
+        p->lc_state = -1;
+        return ZG_OK;
+    }
+    std::swap(p->lc.p, built.p);
+    std::swap(p->lc.bytes, built.bytes);
+    p->lc_log_m = log_m;
+    p->lc_n_l = n_l;
+    p->lc_state = 1;
+    return ZG_OK;
+}
+
+extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) try {
+    if (!p || which < 0 || which > 5 || !kind || !bytes) return ZG_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    const auto& t = which == 5 ? p->fbw_lc : which == 0 && p->fbw_he.state == 1 ? p->fbw_he : p->fbw[which];
     *kind = t.state == 1 ? (t.kind == 1 ? 2 : 1) : 0;
     *bytes = t.state == 1 ? t.buf.bytes : 0;
     return ZG_OK;
@@ -2141,15 +2365,20 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     ZG_TRY(ensure_h_eval(ctx, p, r->log_m, /*retry=*/true));
     const bool eval_form = h_eval_ready(p, r->log_m);
     if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, p->h_eval_hi - p->h_eval_lo};   // (a sharded key: its slice)
-    return ensure_tables(ctx, p, use, 0x1f, eval_form);
+    ZG_TRY(ensure_tables(ctx, p, use, 0x1f, eval_form));
+    if (eval_form && d_witness) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness, /*retry=*/true));
+    return ZG_OK;
 } catch (...) {
     return zg::on_exception(ctx);
 }
 
 // h_eval_form: d_h_shard holds h_eval_dev's m scalars and the h multiexp runs over the key's h_eval bases
 // h_split > 0: the scalars arrive in that many ranges (ctx->h_split_ev, see h_eval_dev) and the h job runs in as many parts
+// c_fold: the l query is the key's folded one (zg_params::lc) over c_fold->scalars, gated on c_fold_ev (the R1CS evaluation
+// that writes the C rows' values); the "l" partial then holds l + the C term and the "h" partial the a b / Z term
 static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const void* d_h_shard,
-                               unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES], bool h_eval_form, int h_split = 0) {
+                               unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES], bool h_eval_form, int h_split = 0,
+                               const CFoldBufs* c_fold = nullptr, hipEvent_t c_fold_ev = nullptr) {
     if (!ctx || !p || !r || !partials) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
     ZG_HIP(ctx, hipSetDevice(ctx->device));
@@ -2176,21 +2405,23 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         use[0] = QueryUse{p->h_eval.p, (const uint32_t*)d_h_shard, nullptr, p->h_eval_hi - p->h_eval_lo};
     }
     if (use[0].n && !d_h_shard) return fail(ctx, ZG_E_INVALID_ARG, "d_h_shard is NULL");
-    ZG_TRY(ensure_tables(ctx, p, use, mask, h_eval_form));
+    if (c_fold) use[1] = QueryUse{p->lc.p, c_fold->scalars, nullptr, p->lc_n_l + ((uint64_t)2 << r->log_m), c_fold->cls};
+    ZG_TRY(ensure_tables(ctx, p, use, mask, h_eval_form, c_fold != nullptr));
     MsmDesc d1[4], d2;
     for (int k = 0; k < 5; k++) {
         MsmDesc d{use[k].bases, use[k].scalars, use[k].index, (size_t)use[k].n, /*dense=*/k == 0};
         d.cls = k == 0 ? nullptr : use[k].cls;
         if (k != 0) {
-            const auto& tk = p->fbw[k];
+            const auto& tk = k == 1 && c_fold ? p->fbw_lc : p->fbw[k];
             if (tk.state == 1 && tk.n == use[k].n) d.small_hint = tk.small ? 1 : 0;
         }
+        if (k == 1 && c_fold) d.gate = c_fold_ev;
         if (k == 0 && h_split > 0) {
             d.parts = h_split;
             d.part_gate = ctx->h_split_ev;
             d.part_gate_only = true;
         }
-        const auto& t = k == 0 && h_eval_form ? p->fbw_he : p->fbw[k];
+        const auto& t = k == 0 && h_eval_form ? p->fbw_he : k == 1 && c_fold ? p->fbw_lc : p->fbw[k];
         if (use[k].n && t.state == 1 && t.n == use[k].n && t.kind == 1) {
             d.quad_table = t.buf.p;
             d.quad_w = t.qw;
@@ -2225,15 +2456,24 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     // the same scalars, so their (position, digit) pairs are sorted once, over the variables this shard's queries span, and
     // each query reads the sorted entries through its position map (msm.hip MsmShare / ShQuery).
     MsmShare share;
-    if (ctx->opt_share_sort && p->w_plan_c && p->w_plan_nwin <= 32) {
+    int w_plan_c = 0, w_plan_nwin = 0;
+    bool w_plan_small = false;
+    {   // (the plan is written by ensure_tables under the key's lock: another context may be building tables right now)
+        std::lock_guard<std::mutex> lock(p->fbw_mu);
+        w_plan_c = p->w_plan_c;
+        w_plan_nwin = p->w_plan_nwin;
+        w_plan_small = p->w_plan_small;
+    }
+    if (ctx->opt_share_sort && w_plan_c && w_plan_nwin <= 32) {
         const uint64_t nvars = (uint64_t)r->n_inputs + r->n_aux;
         uint64_t pos0 = nvars, pos1 = 0;
         unsigned members = 0;
         int n_members = 0;
         for (int k = 1; k <= 4; k++) {
             const auto& t = p->fbw[k];
-            if (!use[k].n || !(mask & (1u << k)) || t.state != 1 || t.kind != 0 || t.n != use[k].n || t.c != p->w_plan_c ||
-                t.nwin != p->w_plan_nwin || t.small != p->w_plan_small)
+            if (k == 1 && c_fold) continue;   // (the folded l query spans the C rows too: a sort of its own)
+            if (!use[k].n || !(mask & (1u << k)) || t.state != 1 || t.kind != 0 || t.n != use[k].n || t.c != w_plan_c ||
+                t.nwin != w_plan_nwin || t.small != w_plan_small)
                 continue;
             // (a query that reads the entries through a rank map pays a gather per entry and walks the entries of variables
             // outside its density: measured, a sort of its own is cheaper -- mode 2 shares those too, for the tests)
@@ -2259,9 +2499,9 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
             share.scalars = (const uint32_t*)d_witness + 8 * pos0;
             share.cls = ws.wcls.as<uint8_t>() + pos0;
             share.n = (size_t)(pos1 - pos0);
-            share.c = p->w_plan_c;
-            share.nwin = p->w_plan_nwin;
-            share.small = p->w_plan_small ? 1 : 0;
+            share.c = w_plan_c;
+            share.nwin = w_plan_nwin;
+            share.small = w_plan_small ? 1 : 0;
             for (int k = 1; k <= 4; k++) {
                 if (!(members & (1u << k))) continue;
                 const auto& q = p->q[k];
@@ -2284,6 +2524,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ctx->last_share_mask = share.mask;
     ctx->last_follow_g2 = d1[3].follow_g2 && !(share.mask >> 3 & 3u);
+    ctx->last_c_fold = c_fold != nullptr;
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h, share.mask ? &share : nullptr));
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
@@ -2457,6 +2698,12 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     // H in evaluation form where the key has (or can get) its transformed h bases: six transforms instead of seven
     ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
     const bool eval_form = h_eval_ready(p, r->log_m);
+    // ... and four instead of six where the C rows' values are bits (ensure_c_fold): they leave the evaluator as scalars of
+    // the l multiexp
+    if (eval_form) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness));
+    const bool c_fold = eval_form && ctx->opt_c_fold && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
+    CFoldBufs cfb;
+    if (c_fold) ZG_TRY(c_fold_buffers(ctx, r, d_witness, c_fold_n_l(p, r), &cfb));
     ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
@@ -2473,7 +2720,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     }
     const bool trace = trace_level() != 0;
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: classes queued      +%.3f ms\n", now_ms() - t0);
-    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split));
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split, cfb.c_nat, cfb.c_cls));
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: R1CS + H queued     +%.3f ms\n", now_ms() - t0);
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
@@ -2512,7 +2759,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
             }
         };
     }
-    int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form, h_split);
+    int rc_p = prove_partials_impl(ctx, p, r, d_witness, dh.p, 0x1f, partials, eval_form, h_split, c_fold ? &cfb : nullptr, ctx->tm_ev[1]);
     ctx->witness_hook = nullptr;
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: multiexps done      +%.3f ms\n", now_ms() - t0);
     ctx->ev_witness = ctx->ev_h = nullptr;
@@ -2563,6 +2810,8 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     size_t sent = 0;
     ctx->n_launches = 0;
     ctx->stats_keep = true;   // (zg_prove_dev below counts on)
+    // (a key with its C rows folded into the l query: their values are written behind the witness, c_fold_buffers)
+    if (ctx->opt_c_fold && c_fold_ready(p, r)) ZG_HIP(ctx, prove_ws(ctx).w.reserve((nv + ((size_t)2 << r->log_m)) * 32));
     ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] zg_prove: witness handed over  +%.3f ms\n", now_ms() - t0);
