@@ -134,7 +134,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          per row on average, rows equal to 2 not counted; decided once per key, with its tables), zg_prove*
  *                          transform a and b only -- FOUR transforms instead of six -- and the C term enters as 2 m more
  *                          points of the l multiexp (a second transformed basis and its doubles, built once per key), for
- *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^24 rows; 2 = for every such key
+ *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^26 rows; 2 = for every such key
  *                          whatever its witness and size (tests); 0 = six transforms.  The proof is the same group element
  *                          either way; the phase API always takes six.  Measured (config-4 shape, one box, alternated):
  *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */

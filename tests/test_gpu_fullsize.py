@@ -9,7 +9,7 @@ import pytest
 from oracle import bn254 as bn
 from oracle import coracle as co
 from oracle import groth16 as g
-from tests.util import download_params
+from tests.util import download_params, table_kinds
 from za_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -27,8 +27,9 @@ def test_config4_at_2p22_matches_the_c_oracle(ctx):
     P, _ = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=False)
     r, s = 0x1234567, 0x7654321
     got = ctx.prove(P, R, sr.witness, r, s)
-    kinds = [P.table_info(k)[0] for k in range(5)]
+    kinds = table_kinds(P)
     assert kinds[0] == 1 and kinds[1] == 2, kinds        # h: window table; l: subset-sum table (bit-heavy witness)
+    assert ctx.last_stats()["c_folded"] == (dict(za_amd._options_from_env()).get(za_amd.OPT_C_FOLD, 1) != 0)   # the default at 2^22
     mp = download_params(ctx, P)
     csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
     assert co.prove(mp, csr, sr.witness, r, s, threads=THREADS) == got
@@ -58,7 +59,7 @@ def test_config5_shape_uniform_witness_at_2p24_matches_discrete_log_expectation(
     P = synth.synth_params(ctx, m - 1, sr.n_aux, n_a, n_b, seed)
     r, s = 0xABCDEF01, 0x10FEDCBA
     got = ctx.prove(P, R, sr.witness, r, s)
-    assert [P.table_info(k)[0] for k in range(5)] == [1, 1, 1, 1, 1]
+    assert table_kinds(P) == [1, 1, 1, 1, 1]
     assert got == _dlog_expectation(ctx, sr, R, lg, seed, r, s)
     P.close(); R.close(); sr.close()
 

@@ -60,3 +60,16 @@ def download_params(ctx, P):
         arrs.append(a[: tot * elem])
     return co.MontParams(vk5[0:64].tobytes(), vk5[64:128].tobytes(), vk5[128:256].tobytes(), vk5[256:320].tobytes(),
                          vk5[320:448].tobytes(), *arrs)
+
+
+def table_infos(P):
+    """(kind, bytes) per query (h, l, a, b_g1, b_g2).  A key whose C rows are folded into the l multiexp (ZG_OPT_C_FOLD) has
+    no table for the plain l query: the folded query's table (which = 5) stands in for it."""
+    k = [P.table_info(i) for i in range(5)]
+    if k[1][0] == 0 and P.table_info(5)[0]:
+        k[1] = P.table_info(5)
+    return k
+
+
+def table_kinds(P):
+    return [k[0] for k in table_infos(P)]

@@ -2202,9 +2202,8 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
 // key, from the witness its tables are first built for (as the tables' own plans are).  Unsharded keys, zg_prove* only: the
 // phase API keeps six transforms (its h scalars and its l partial are documented quantities).
 // mode 1's sizes: from ZG_OPT_C_FOLD_MIN_LOG_M (below 2^20 the folded l job's longer chain costs more than two transforms of
-// a short pipeline save) to 2^24 (beyond it the job's sort buffers, sized for 3 x the positions, are not what the tables'
-// budget was planned with: not measured, so not taken)
-static constexpr int C_FOLD_MAX_LOG_M = 24;
+// a short pipeline save) to 2^26 (measured: config-4 shape 163.3 -> 154.0 ms; 2^27, the largest legal domain, is not)
+static constexpr int C_FOLD_MAX_LOG_M = 26;
 static bool c_fold_size_ok(const Ctx* ctx, uint32_t log_m) {
     return ctx->opt_c_fold >= 2 || ((int)log_m >= ctx->opt_c_fold_min_log_m && (int)log_m <= C_FOLD_MAX_LOG_M);
 }
@@ -2307,18 +2306,13 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
                 break;
             if ((rc = h_eval_bases_build(ctx, p->q[0].buf.as<G1Affine>(), p->q[0].total, log_m, built.as<G1Affine>() + n_l, /*c_fold=*/true)) != ZG_OK)
                 break;
-            QueryUse u[5] = {};
-            u[1] = QueryUse{built.p, cb.scalars, nullptr, n_l + 2 * m, cb.cls};
-            {
+            {   // the folded query's table is built with the other queries' (ensure_tables, in their order of priority)
                 std::lock_guard<std::mutex> lock(p->fbw_mu);
                 p->fbw_lc.buf.release();
                 p->fbw_lc.rank.release();
                 p->fbw_lc.state = 0;
             }
-            if ((rc = ensure_tables(ctx, p, u, 2u, false, /*lc_form=*/true)) != ZG_OK) break;
-            ok = true;   // (with whatever table the folded query got, or none: ensure_tables' rules and budget)
-            if (trace_level() != 0)
-                fprintf(stderr, "[za_amd trace] c_fold: table state %d kind %d (%zu bytes)\n", p->fbw_lc.state, p->fbw_lc.kind, p->fbw_lc.buf.bytes);
+            ok = true;
         } while (false);
     } catch (...) {
         rc = ZG_E_HIP;
@@ -2365,9 +2359,23 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     ZG_TRY(ensure_h_eval(ctx, p, r->log_m, /*retry=*/true));
     const bool eval_form = h_eval_ready(p, r->log_m);
     if (eval_form) use[0] = QueryUse{p->h_eval.p, nullptr, nullptr, p->h_eval_hi - p->h_eval_lo};   // (a sharded key: its slice)
-    ZG_TRY(ensure_tables(ctx, p, use, 0x1f, eval_form));
+    // (first: a key whose C rows are folded into the l query needs no table for the plain l query, but one for the folded
+    // query -- over this witness's aux values and the values its C rows evaluate to)
     if (eval_form && d_witness) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness, /*retry=*/true));
-    return ZG_OK;
+    const bool folded = eval_form && d_witness && ctx->opt_c_fold && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
+    if (folded) {
+        CFoldBufs cb;
+        ZG_TRY(c_fold_buffers(ctx, r, d_witness, c_fold_n_l(p, r), &cb));
+        ProveWs& ws = prove_ws(ctx);
+        Fr* abc[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 2; k++) {
+            ZG_HIP(ctx, ws.abc[k].reserve(((size_t)1 << r->log_m) * sizeof(Fr)));
+            abc[k] = ws.abc[k].as<Fr>();
+        }
+        ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/true, cb.c_nat, cb.c_cls));
+        use[1] = QueryUse{p->lc.p, cb.scalars, nullptr, p->lc_n_l + ((uint64_t)2 << r->log_m), cb.cls};
+    }
+    return ensure_tables(ctx, p, use, 0x1fu, eval_form, folded);
 } catch (...) {
     return zg::on_exception(ctx);
 }
