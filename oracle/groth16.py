@@ -249,6 +249,45 @@ def h_eval_bases(h_points, log_m):
     return out
 
 
+def h_eval_scalars_without_c(r1cs, w):
+    """e'[p] = (A B / Z)(g omega^bitrev(p)): the quotient's values WITHOUT its C term -- what za_amd's h_eval_dev leaves when
+    the C rows are folded into the l multiexp (ZG_OPT_C_FOLD; four transforms: a and b only).  The quotient is linear in
+    c:  e = e' - c(g omega^bitrev(p)) / Z(g)."""
+    a, b, _c, *_ = eval_constraints(r1cs, w)
+    d = Domain(r1cs.domain_log())
+    a, b = d.pad(a), d.pad(b)
+    for v in (a, b):
+        d.ifft(v)
+        d.coset_fft(v)
+    for i in range(d.m):
+        a[i] = a[i] * b[i] % R
+    d.divide_by_z_on_coset(a)
+    return [a[bitreverse(p, d.exp)] for p in range(d.m)]
+
+
+def c_fold_bases(h_points, log_m):
+    """C_j = -(1 / (m Z(g))) sum_(i < m-1) omega^(-i j) H_i in ROW order, by the definition: the bases that go with the
+    values c_j of the R1CS rows' C sides (za_amd/csrc/heval.hip, c_fold).  c's values on the coset are the transform of its
+    values on the domain, so  sum_p (c(g omega^bitrev(p)) / Z(g)) H'[p] = -sum_j c_j C_j  (i < m - 1 in both: the points the
+    h query has)."""
+    from .bn254 import pt_add, pt_mul
+    d = Domain(log_m)
+    m = d.m
+    assert len(h_points) >= m - 1
+    k = (R - inv(d.z(FR_GENERATOR), R) * d.minv % R) % R
+    scaled = [pt_mul(h_points[i], k) for i in range(m - 1)]
+    out = []
+    for j in range(m):
+        acc = None
+        wj = pow(d.omegainv, j, R)
+        t = 1
+        for i in range(m - 1):
+            acc = pt_add(acc, pt_mul(scaled[i], t))
+            t = t * wj % R
+        out.append(acc)
+    return out
+
+
 def h_eval_bases_fft(h_points, log_m):
     """The same array by a decimation-in-frequency transform over the group (natural order in, bit-reversed out) -- the
     schedule of heval.hip; tests/test_oracle_python.py checks it against h_eval_bases' definition."""

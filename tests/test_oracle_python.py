@@ -173,3 +173,47 @@ def test_h_in_evaluation_form_is_the_same_group_element():
             acc = bn.pt_add(acc, bn.pt_mul(P, ep))
         parts = bn.pt_add(parts, acc)
     assert parts == lhs
+
+
+def test_c_rows_folded_into_the_l_multiexp_is_the_same_group_element():
+    """The identity behind ZG_OPT_C_FOLD (za_amd/csrc/prover.hip ensure_c_fold, heval.hip c_fold), by definitions only:
+    sum_i h_i H_i = sum_p e'[p] H'[p] + sum_j c_j C_j  with e' the quotient without its C term (four transforms) and c_j the
+    values of the R1CS rows' C sides, zero padded -- for a witness that satisfies the circuit and for one that does not
+    (bellman interpolates (a b - c) / Z on the coset whatever it is and drops the coefficient of x^(m-1); every sum here runs
+    over the m - 1 points the h query has; nothing in the identity uses a b = c on the domain).
+    A row that evaluates to 2 enters as a ONE on the doubled base."""
+    from oracle.circuits import chain_r1cs
+    r1, w = chain_r1cs(4, n_inputs=2, seed=77, bit_fraction=0.5)
+    params, _ = g.generate_parameters(r1, 21, 22, 23, 24, 25)
+    Hp = g.h_eval_bases(params.h, 4)
+    Cj = g.c_fold_bases(params.h, 4)
+    C2 = [bn.pt_add(P, P) for P in Cj]
+    bad = list(w)
+    bad[len(bad) // 2] = (bad[len(bad) // 2] + 5) % bn.R
+    assert r1.is_satisfied(w) and not r1.is_satisfied(bad)
+    def h_truncated(wit):      # bellman's sequence (oracle/groth16.py h_coefficients) without the satisfaction check
+        a, b, c, *_ = g.eval_constraints(r1, wit)
+        d = g.Domain(r1.domain_log())
+        a, b, c = d.pad(a), d.pad(b), d.pad(c)
+        for v in (a, b, c):
+            d.ifft(v)
+            d.coset_fft(v)
+        a = [(x * y - z) % bn.R for x, y, z in zip(a, b, c)]
+        d.divide_by_z_on_coset(a)
+        d.icoset_fft(a)
+        return a[: d.m - 1]
+    assert h_truncated(w) == g.h_coefficients(r1, w)
+    for wit in (w, bad):
+        lhs = None
+        for hi, Hi in zip(h_truncated(wit), params.h):
+            lhs = bn.pt_add(lhs, bn.pt_mul(Hi, hi))
+        rhs = None
+        for ep, P in zip(g.h_eval_scalars_without_c(r1, wit), Hp):
+            rhs = bn.pt_add(rhs, bn.pt_mul(P, ep))
+        c = g.eval_constraints(r1, wit)[2]
+        for j, cj in enumerate(c):                     # (rows beyond the constraints -- inputs, padding -- evaluate to 0)
+            if cj == 2:
+                rhs = bn.pt_add(rhs, C2[j])
+            else:
+                rhs = bn.pt_add(rhs, bn.pt_mul(Cj[j], cj))
+        assert lhs == rhs and lhs is not None

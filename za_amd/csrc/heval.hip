@@ -16,7 +16,7 @@
 // prover.hip ensure_c_fold).  e is linear in c, and c's values on the coset are the transform of its values c_j on the
 // domain, so
 //     sum_p e_p H'_p = sum_p (a b / Z)_p H'_p + sum_j c_j C_j,      C_j = -(1 / (m Z(g))) sum_i omega^(-i j) H_i
-// (i < m - 1 in both sums: what the two terms put on tau^(m-1) cancels, as h has degree m - 2).  C_j is [L_j(tau) Z(tau) /
+// (i < m - 1 in both sums -- the points the h query has; bellman truncates h there too).  C_j is [L_j(tau) Z(tau) /
 // delta] scaled by -1/Z(g) and truncated: the c_j are the R1CS rows' C sides as evaluated, in row order -- out[j] = C_j,
 // followed by out[m + j] = 2 C_j (a row that evaluates to 2 -- an XOR gate written (2a) b = a + b - c with a = b = 1 -- is a
 // ONE on the doubled base: a quarter of a bit-level circuit's rows, which as digits would all land in one bucket).

@@ -2282,8 +2282,8 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
             }
             if (rc != ZG_OK) break;
             if ((rc = r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/true, cb.c_nat, cb.c_cls)) != ZG_OK) break;
-            uint64_t zeros = 0, ones = 0;
-            if ((rc = msm_classify_counts(ctx, cb.scalars, nullptr, n_l + 2 * m, &zeros, &ones)) != ZG_OK) break;
+            uint64_t zeros = 0, ones = 0;   // (for the trace only)
+            if (trace_level() != 0 && (rc = msm_classify_counts(ctx, cb.scalars, nullptr, n_l + 2 * m, &zeros, &ones)) != ZG_OK) break;
             // What the rows cost as a multiexp: their non-zero 16-bit digits (an addition each; rows equal to 2 are ones on
             // the doubled bases and not counted).  Two transforms of m elements are worth ~3.4 additions per row (1.0 ms
             // against 71 ps per addition at 2^22); folded up to 3 digits per row -- a bit-level circuit has 0.3 - 0.8 (AND
