@@ -468,7 +468,8 @@ def main():
                      "witness_msm_ms_rank0_beside_ntt": phase_ms.get("witness_msm"),
                      "h_ntt_ms": phase_ms.get("h_total"), "scatter_ms": phase_ms.get("scatter"),
                      "gather_ms": phase_ms.get("gather"), "combine_ms": phase_ms.get("combine"),
-                     "h_form": "evaluation (6 transforms, transformed h bases)" if getattr(engine, "h_eval", False)
+                     "h_form": ("evaluation, C rows folded on rank 0 (4 transforms, transformed h bases)" if getattr(engine, "c_folded", False)
+                                else "evaluation (6 transforms, transformed h bases)") if getattr(engine, "h_eval", False)
                                else "coefficient (7 transforms)",
                      "note": "host wall times per proof; h_ntt_ms = rank 0's R1CS evaluation + H transforms from start to "
                              "finish (its witness MSMs run beside them); msm_phase_ms = max over ranks of witness MSMs + "
@@ -608,6 +609,26 @@ def main():
                 tt.append(time.perf_counter() - t1)
             flow[name] = 1e3 * float(np.mean(tt[1:]))
         h_alone = float(ts[:, 0].mean())
+        # ... and with the C rows folded on rank 0 (zg_prove_h_eval_enqueue_fold_dev: four transforms, rank 0's l partial
+        # carries the rows' multiexp; the other ranks' phases are the ones above)
+        fold = None
+        if ev and hasattr(ctx, "prove_h_eval_enqueue_fold_dev"):
+            th, tf, was = [], [], False
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                was = ctx.prove_h_eval_enqueue_fold_dev(Pk, r1, d_w, d_h)
+                ctx.sync()
+                th.append(time.perf_counter() - t1)
+                ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x1e)          # (takes the armed rows)
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.prove_h_eval_enqueue_fold_dev(Pk, r1, d_w, d_h)
+                ctx.prove_partials_dev(Pk, r1, d_w, d_h, 0x1e)
+                ctx.prove_partials_dev(Pk, r1, d_w, d_h, h_mask)
+                tf.append(time.perf_counter() - t1)
+            fold = {"folded": bool(was), "h_ntt_ms": 1e3 * float(np.mean(th[1:])), "flow_ms": 1e3 * float(np.mean(tf[1:]))}
         shard_line = {"world": W, "h_form": "evaluation" if ev else "coefficient", "h_ntt_ms": h_alone, "witness_msm_ms": float(ts[:, 1].mean()),
                       "h_msm_ms": float(ts[:, 2].mean()), "msm_phase_ms": float(ts[:, 1:].sum(axis=1).mean()),
                       "unsharded_msm_phase_ms": float(full_w.sum(axis=1).mean()),
@@ -616,6 +637,7 @@ def main():
                       "msm_critical_path_ms": max(flow["shard"] - h_alone, 0.0),
                       "unsharded_msm_critical_path_ms": max(flow["unsharded"] - h_alone, 0.0),
                       "msm_critical_path_scaling": (flow["unsharded"] - h_alone) / max(flow["shard"] - h_alone, 1e-9),
+                      "rank0_with_c_rows_folded": fold,
                       "note": "one GPU.  msm_phase_ms / msm_scaling_model: the phases run one after the other (no overlap), rank "
                               "0's shard of a proof sharded %d ways vs the same phases unsharded.  flow_ms: the phases as the "
                               "sharded flow runs them on rank 0 (H queued, witness multiexps beside it, h multiexp behind it); "

@@ -136,7 +136,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          points of the l multiexp (a second transformed basis and its doubles, built once per key), for
  *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^26 rows; 2 = for every such key
  *                          whatever its witness and size (tests); 0 = six transforms.  The proof is the same group element
- *                          either way; the phase API always takes six.  Measured (config-4 shape, one box, alternated):
+ *                          either way; of the phase API only zg_prove_h_eval_enqueue_fold_dev folds.  Measured (config-4 shape, one box, alternated):
  *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */
 #define ZG_OPT_C_FOLD 22
 #define ZG_OPT_C_FOLD_MIN_LOG_M 23
@@ -346,6 +346,15 @@ int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness,
  * Every rank of a proof must use the same form: agree on min(info[0]) over the ranks first (za_amd/dist.py does). */
 #define ZG_MASK_H_EVAL 0x20u
 int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_witness, void* d_e_out);
+/* The same for a caller that names the key, so that the rank that runs the transforms of a sharded proof (rank 0) can drop
+ * C's two as well (ZG_OPT_C_FOLD): where `params` has the bases of the folded C rows -- rank 0's shard of a sharded key gets
+ * them in zg_params_load, an unsharded key on first use; decided from the rows' values as in zg_prove -- the pipeline runs
+ * FOUR transforms, d_e_out receives a b / Z instead of (a b - c) / Z, and the next zg_prove_partials_ex on this context with
+ * this key and the l query in its mask adds the multiexp of the rows' values to its l partial (*folded = 1).  The other
+ * ranks do what they did: their h shards multiply whatever scalars they are sent.  Any other key: *folded = 0 and
+ * exactly zg_prove_h_eval_enqueue_dev.  The sum of all ranks' partials is the same group element either way. */
+int zg_prove_h_eval_enqueue_fold_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
+                                     void* d_e_out, int* folded);
 int zg_params_h_eval_info(const zg_params* params, uint64_t info[4]);
 /* zg_prove's hand-over of a HOST witness on its own, for callers that drive the phases themselves (every rank of a sharded
  * proof needs the witness): n = n_inputs + n_aux canonical-LE scalars, copied -- in packed form by a few host threads

@@ -1353,3 +1353,79 @@ def test_c_rows_folded_into_the_l_multiexp(ctx, opts, lg, bitf, n_in):
         ctx.free(d_w)
         P.close()
     sr.close()
+
+
+@pytest.mark.parametrize("lg,bitf", [(13, 0.97), (12, 0.0)])
+def test_sharded_phases_with_the_c_rows_folded_on_rank_0(ctx, opts, lg, bitf):
+    """zg_prove_h_eval_enqueue_fold_dev: the rank that runs the transforms of a sharded proof drops C's two as well -- its
+    shard of the key took the bases of the folded C rows when it was cut (or loaded), the scalars it scatters are a b / Z,
+    and its l partial carries the rows' multiexp; the other ranks' calls are what they were.  Three shards and the unsharded
+    key through the same entry point, in every mode, against the unsharded proof; then zg_params_load(rank, world) on a
+    bellman key against the golden 2^10 proof."""
+    from tests import golden_1k as k1
+    from tests.util import golden
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, 3, bitf, 6100 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    d_w = ctx.upload(sr.witness)
+    d_e = ctx.alloc(32 * m)
+    r, s = 424242, 171717
+    opts(za_amd.OPT_C_FOLD_MIN_LOG_M, 8)
+    whole = None
+
+    def sharded(keys, world, then_plain=False):
+        folded = ctx.prove_h_eval_enqueue_fold_dev(keys[0], R, d_w, d_e)
+        if then_plain:         # a pipeline queued the plain way behind it: nothing stays armed, d_e holds the six-transform scalars
+            ctx.prove_h_eval_enqueue_dev(R, d_w, d_e)
+            folded = False
+        w0 = ctx.prove_partials_dev(keys[0], R, d_w, 0, mask=0x1e)      # rank 0's witness multiexps beside its transforms
+        assert ctx.last_stats()["c_folded"] == folded
+        ctx.sync()
+        parts = []
+        for rank, Pk in enumerate(keys):
+            lo = Pk.h_eval_info()[2]
+            hp = ctx.prove_partials_dev(Pk, R, d_w, d_e + 32 * lo, mask=0x01 | za_amd.ZG_MASK_H_EVAL)
+            wp = w0 if rank == 0 else ctx.prove_partials_dev(Pk, R, d_w, 0, mask=0x1e)
+            part = np.array(wp, copy=True)
+            part[:96] = hp[:96]
+            parts.append(part)
+        return folded, np.concatenate(parts)
+
+    for mode in (2, 1, 0):
+        opts(za_amd.OPT_C_FOLD, mode)
+        P1 = synth.synth_params(ctx, *sizes, 777)
+        if whole is None:
+            whole = ctx.prove_dev(P1, R, d_w, r, s)
+        want_fold = mode == 2 or (mode == 1 and bitf == 0.97)
+        for _ in range(2):
+            folded, allp = sharded([P1], 1)                              # the unsharded key through the phase API
+            assert folded == want_fold and ctx.prove_combine(P1, allp, 1, r, s) == whole
+        keys = [synth.params_shard(ctx, P1, rank, 3) for rank in range(3)]
+        for _ in range(2):
+            folded, allp = sharded(keys, 3)
+            assert folded == want_fold and ctx.prove_combine(P1, allp, 3, r, s) == whole
+        folded, allp = sharded(keys, 3, then_plain=True)
+        assert not folded and ctx.prove_combine(P1, allp, 3, r, s) == whole
+        for Pk in keys:
+            Pk.close()
+        P1.close()
+    ctx.free(d_e); ctx.free(d_w)
+    sr.close()
+    if lg != 13:
+        return
+    opts(za_amd.OPT_C_FOLD, 2)
+    fx = golden("proof_chain10.json")
+    r1, w = k1.chain10_circuit(fx)
+    csr = co.CsrR1CS.from_r1cs(r1)
+    R2 = ctx.r1cs_load(csr.n_inputs, csr.n_aux, csr.n_constraints, csr.row_ptr, csr.col, csr.coeff)
+    pbytes = k1.chain10_params()
+    d_w = ctx.upload(co.witness_bytes(w))
+    d_e = ctx.alloc(32 << 10)
+    keys = [ctx.params_load(pbytes, checked=False, rank=rank, world=3)[0] for rank in range(3)]
+    R, hold = R2, R
+    folded, allp = sharded(keys, 3)
+    Pf, _ = ctx.params_load(pbytes, checked=False)
+    assert folded and ctx.prove_combine(Pf, allp, 3, int(fx["r"], 16), int(fx["s"], 16)).hex() == fx["proof"]
+    ctx.free(d_e); ctx.free(d_w)

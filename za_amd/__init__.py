@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "zg_params_load", "zg_params_from_mont", "zg_params_free", "zg_params_write", "zg_params_write_vk", "zg_pk_params_offset",
     "zg_pk_load", "zg_witness_from_binwitness", "zg_setup", "zg_setup_random",
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
-    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_params_h_eval_info", "zg_witness_to_device", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
+    "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_prove_h_eval_enqueue_fold_dev", "zg_params_h_eval_info", "zg_witness_to_device", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
     "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings", "zg_last_stats",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
@@ -420,6 +420,15 @@ class Context:
     def prove_h_eval_enqueue_dev(self, r1cs, d_witness, d_e_out):
         """Non-blocking zg_prove_h_eval_dev; call sync() before using d_e_out."""
         self._check(self.lib.zg_prove_h_eval_enqueue_dev(self.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out)))
+
+    def prove_h_eval_enqueue_fold_dev(self, params, r1cs, d_witness, d_e_out):
+        """zg_prove_h_eval_enqueue_dev naming the key: four transforms where the key has the bases of the folded C rows (then
+        the next prove_partials_dev with this key and the l query adds the rows' multiexp to its l partial).  Returns True
+        if the pipeline was queued folded."""
+        folded = C.c_int(0)
+        self._check(self.lib.zg_prove_h_eval_enqueue_fold_dev(self.h, params.h, r1cs.h, C.c_void_p(d_witness), C.c_void_p(d_e_out),
+                                                              C.byref(folded)))
+        return bool(folded.value)
 
     def prove_h_enqueue_dev(self, r1cs, d_witness, d_h_out):
         """Non-blocking: queue R1CS evaluation + H; call sync() before using d_h_out."""

@@ -79,6 +79,9 @@ struct zg_params {
     mutable uint32_t lc_log_m = 0;
     mutable uint64_t lc_n_l = 0;
     mutable Fbw fbw_lc;
+    // rank 0's shard of a sharded key gets `lc` when it is loaded, before any witness is seen (the group transform needs the
+    // whole h query): whether proofs USE it is decided with the first witness (0 not yet, 1 fold, -1 six transforms)
+    mutable int lc_rule = 0;
 };
 
 

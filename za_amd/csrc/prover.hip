@@ -501,6 +501,7 @@ struct HostPacker {
 struct ProveWs {
     DevBuf abc[3], h, wcls, w;
     DevBuf w_lc;   // "C folded", witness in the caller's memory: [aux part of the witness | the C rows' values] (c_fold_buffers)
+    DevBuf cls_lc; // ... and for rank 0's shard of a sharded key: [class bytes of its aux range | the rows' classes]
     // zg_prove's host-side packing (see there): the packer (pool + per-slice lists) and the pinned staging of the packed form
     std::unique_ptr<HostPacker> packer;
     double pack_ema_ms = 0;   // running average of the packing pass's host time
@@ -1783,6 +1784,7 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
     if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ctx->fold_armed_key = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_h_out));
@@ -1797,6 +1799,7 @@ extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witne
 extern "C" int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_e_out) try {
     if (!ctx || !r || !d_e_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ctx->fold_armed_key = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     double t0 = now_ms();
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_e_out, nullptr, /*eval_form=*/true));
@@ -1811,6 +1814,7 @@ extern "C" int zg_prove_h_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_
 extern "C" int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_e_out) try {
     if (!ctx || !r || !d_e_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ctx->fold_armed_key = nullptr;   // (whatever zg_prove_h_eval_enqueue_fold_dev queued before is superseded)
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     ZG_TRY(gate_events(ctx));
     ZG_TRY(witness_classes(ctx, r, d_witness));   // as zg_prove_h_enqueue_dev: the witness gate sits before the pipeline
@@ -1843,6 +1847,7 @@ extern "C" int zg_prove_partials_dev(zg_ctx* ctx, const zg_params* p, const zg_r
 extern "C" int zg_prove_h_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
     if (!ctx || !r || !d_h_out) return ZG_E_INVALID_ARG;
     if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    ctx->fold_armed_key = nullptr;
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     // "witness ready" is recorded BEFORE the H pipeline is queued: a following zg_prove_partials_ex with the witness
     // mask gates its multiexps on this event instead of on everything queued so far, so rank 0's l / a / b jobs run
@@ -1875,6 +1880,7 @@ static bool h_eval_allowed(const Ctx* ctx) { return ctx->opt_h_eval; }   // ZG_O
 // A sharded key's slice: positions [rank * ceil(m / world), ...) of the m-point evaluation-form array.  The group
 // transform needs the whole query, so this runs where it is at hand: zg_params_load (every rank parses the whole key),
 // zg_params_shard (cut from a full resident key; d_h_eval_full = its transformed array if it has one).
+static void c_fold_shard_bases(Ctx* ctx, const zg_params* p, const G1Affine* d_h_full, uint64_t n_h, uint32_t log_m);
 int zg::params_h_eval_slice(Ctx* ctx, const zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full) {
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     p->h_eval.release();
@@ -1912,6 +1918,9 @@ int zg::params_h_eval_slice(Ctx* ctx, const zg_params* p, const G1Affine* d_h_fu
     p->h_eval_lo = lo;
     p->h_eval_hi = hi;
     p->h_eval_state = 1;
+    // rank 0 -- the rank that runs the transforms -- also takes the bases of the folded C rows (ensure_c_fold), while the
+    // whole h query is at hand
+    if (p->world > 1 && p->rank == 0) c_fold_shard_bases(ctx, p, d_h_full, n_h, log_m);
     return ZG_OK;
 }
 // States of zg_params::h_eval_state: 0 not tried, 2 being built by some context, 1 built -- and from then on IMMUTABLE for
@@ -2199,8 +2208,9 @@ static int query_uses(Ctx* ctx, const zg_params* p, const zg_r1cs* r, const void
 // aux part of the witness followed by the c_j, its class bytes likewise (both contiguous: c_fold_buffers); the second m
 // points are the doubled bases, for the rows that evaluate to 2 (R1csMats::c_nat).  Worth it where
 // the c_j are bits -- the subset-sum table makes their multiexp one addition per eight rows -- which is decided once per
-// key, from the witness its tables are first built for (as the tables' own plans are).  Unsharded keys, zg_prove* only: the
-// phase API keeps six transforms (its h scalars and its l partial are documented quantities).
+// key, from the witness its tables are first built for (as the tables' own plans are).  zg_prove* with an unsharded key, and
+// the phase API through zg_prove_h_eval_enqueue_fold_dev (below: the rank that runs a sharded proof's transforms); the
+// plain phase entries keep six transforms (their h scalars and the l partial are documented quantities).
 // mode 1's sizes: from ZG_OPT_C_FOLD_MIN_LOG_M (below 2^20 the folded l job's longer chain costs more than two transforms of
 // a short pipeline save) to 2^26 (measured: config-4 shape 163.3 -> 154.0 ms; 2^27, the largest legal domain, is not)
 static constexpr int C_FOLD_MAX_LOG_M = 26;
@@ -2226,9 +2236,26 @@ struct CFoldBufs {
     Fr* c_nat = nullptr;
     uint8_t* c_cls = nullptr;
 };
-static int c_fold_buffers(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, uint64_t n_l, CFoldBufs* out) {
+// (rank 0's shard of a sharded key: its range of the aux values and of their class bytes is copied in front of the rows' --
+// the classes behind it in the witness's array belong to the other aux values; call it AFTER witness_classes)
+static int c_fold_buffers(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, uint64_t n_l, CFoldBufs* out) {
     ProveWs& ws = prove_ws(ctx);
     const size_t m = (size_t)1 << r->log_m, nv = (size_t)r->n_inputs + r->n_aux;
+    if (p->world != 1) {
+        const size_t lo = (size_t)p->q[1].lo;
+        if (lo + n_l > r->n_aux) return fail(ctx, ZG_E_INVALID_ARG, "internal: l shard beyond the aux values");
+        ZG_HIP(ctx, ws.w_lc.reserve((n_l + 2 * m) * 32));
+        ZG_HIP(ctx, ws.cls_lc.reserve(n_l + 2 * m));
+        if (n_l) {
+            ZG_HIP(ctx, hipMemcpyAsync(ws.w_lc.p, (const Fr*)d_witness + r->n_inputs + lo, n_l * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            ZG_HIP(ctx, hipMemcpyAsync(ws.cls_lc.p, ws.wcls.as<uint8_t>() + r->n_inputs + lo, n_l, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        out->scalars = ws.w_lc.as<uint32_t>();
+        out->c_nat = ws.w_lc.as<Fr>() + n_l;
+        out->cls = ws.cls_lc.as<uint8_t>();
+        out->c_cls = ws.cls_lc.as<uint8_t>() + n_l;
+        return ZG_OK;
+    }
     if (n_l != r->n_aux) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows need the whole l query");
     ZG_HIP(ctx, ws.wcls.reserve(nv + 2 * m));
     Fr* base;
@@ -2273,7 +2300,7 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
         do {
             // the C rows for THIS witness: is their multiexp a bit job?
             CFoldBufs cb;
-            if ((rc = c_fold_buffers(ctx, r, d_witness, n_l, &cb)) != ZG_OK) break;
+            if ((rc = c_fold_buffers(ctx, p, r, d_witness, n_l, &cb)) != ZG_OK) break;
             ProveWs& ws = prove_ws(ctx);
             Fr* abc[3] = {nullptr, nullptr, nullptr};
             for (int k = 0; k < 2 && rc == ZG_OK; k++) {
@@ -2337,6 +2364,112 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
     return ZG_OK;
 }
 
+// ---- the folded form in the phase API: the rank that runs the transforms of a SHARDED proof (rank 0, za_amd/dist.py) drops
+// C's two as well.  Nothing changes for the other ranks and nothing more crosses the links: the scalars rank 0 scatters
+// are a b / Z instead of (a b - c) / Z, and rank 0's l partial carries the C term -- the whole of it: a bit multiexp over
+// the m rows' values against the 2 m bases behind ITS shard of the l query, which costs rank 0 a third of what the two
+// transforms did (its transforms are the serial part of a sharded proof: 3.7 of ~6.3 ms at 2^22 and N = 8).
+// The bases are made when the key is loaded or cut (params_h_eval_slice: the group transform needs the whole h query,
+// fbw_mu held); any failure leaves the key as it was (six transforms).
+static void c_fold_shard_bases(Ctx* ctx, const zg_params* p, const G1Affine* d_h_full, uint64_t n_h, uint32_t log_m) {
+    const uint64_t m = (uint64_t)1 << log_m;
+    const auto& q = p->q[1];
+    const uint64_t n_l = q.hi > q.lo ? q.hi - q.lo : 0;
+    p->lc_state = -1;
+    if (!ctx->opt_c_fold || ctx->one_shot || log_m < 8 || !c_fold_size_ok(ctx, log_m) || q.lo != 0 || n_l + 2 * m >= ((uint64_t)1 << 31) || n_h < m - 1)
+        return;
+    DevBuf built;
+    bool ok = false;
+    try {
+        ok = built.alloc((n_l + 2 * m) * sizeof(G1Affine)) == hipSuccess &&
+             (n_l == 0 || hipMemcpyAsync(built.p, q.buf.p, n_l * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) &&
+             h_eval_bases_build(ctx, d_h_full, n_h, log_m, built.as<G1Affine>() + n_l, /*c_fold=*/true) == ZG_OK &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    } catch (...) {
+        ok = false;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        ctx->last_error.clear();
+        return;
+    }
+    std::swap(p->lc.p, built.p);
+    std::swap(p->lc.bytes, built.bytes);
+    p->lc_log_m = log_m;
+    p->lc_n_l = n_l;
+    p->lc_rule = 0;
+    p->lc_state = 1;
+}
+// Whether the proofs of a key whose bases were made without a witness (c_fold_shard_bases) use them: ensure_c_fold's rule, on
+// the first witness this key sees (blocking, once).  `cb`: this witness's buffers; the rows are evaluated into them.
+static int c_fold_rule(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, const CFoldBufs& cb, bool* fold) {
+    {
+        std::lock_guard<std::mutex> lock(p->fbw_mu);
+        if (p->lc_rule != 0 || ctx->opt_c_fold >= 2) {
+            *fold = ctx->opt_c_fold >= 2 || p->lc_rule > 0;
+            return ZG_OK;
+        }
+    }
+    const size_t m = (size_t)1 << r->log_m;
+    ProveWs& ws = prove_ws(ctx);
+    Fr* abc[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 2; k++) {
+        ZG_HIP(ctx, ws.abc[k].reserve(m * sizeof(Fr)));
+        abc[k] = ws.abc[k].as<Fr>();
+    }
+    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/true, cb.c_nat, cb.c_cls));
+    DevBuf cnt;
+    unsigned long long nz = 0;
+    ZG_HIP(ctx, cnt.alloc(8));
+    ZG_HIP(ctx, hipMemsetAsync(cnt.p, 0, 8, ctx->stream));
+    ZG_LAUNCH(ctx, k_count_digits16, dim3((unsigned)std::min<uint64_t>((m + 255) / 256, 4096)), dim3(256), 0, ctx->stream, cb.c_nat, m,
+              (unsigned long long*)cnt.p);
+    ZG_HIP(ctx, hipMemcpyAsync(&nz, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lock(p->fbw_mu);
+    if (p->lc_rule == 0) p->lc_rule = nz <= (unsigned long long)m * 3 ? 1 : -1;
+    *fold = p->lc_rule > 0;
+    return ZG_OK;
+}
+// zg_prove_h_eval_enqueue_dev for a caller that names the key: where the key has the bases of the folded C rows (an
+// unsharded key: made here on first use; rank 0's shard of a sharded one: made when it was loaded) the pipeline runs four
+// transforms, d_e_out receives a b / Z, and the NEXT zg_prove_partials_ex on this context with this key and the l query in
+// its mask adds the rows' multiexp to the l partial.  Any other key: exactly zg_prove_h_eval_enqueue_dev.
+extern "C" int zg_prove_h_eval_enqueue_fold_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness, void* d_e_out,
+                                                int* folded) try {
+    if (!ctx || !p || !r || !d_e_out) return ZG_E_INVALID_ARG;
+    if (!d_witness) return fail(ctx, ZG_E_ASSIGNMENT_MISSING, "witness is NULL");
+    if (folded) *folded = 0;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    ZG_TRY(gate_events(ctx));
+    ctx->fold_armed_key = nullptr;
+    if (p->world == 1) {   // (an unsharded key makes its transformed bases on first use, here as in zg_prove)
+        ZG_TRY(ensure_h_eval(ctx, p, r->log_m));
+        if (h_eval_ready(p, r->log_m)) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness));
+    }
+    bool fold = ctx->opt_c_fold && (p->world == 1 || p->rank == 0) && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
+    ZG_TRY(witness_classes(ctx, r, d_witness));   // as zg_prove_h_enqueue_dev: the witness gate sits before the pipeline
+    CFoldBufs cfb;
+    if (fold) {
+        ZG_TRY(c_fold_buffers(ctx, p, r, d_witness, c_fold_n_l(p, r), &cfb));
+        if (p->world != 1) ZG_TRY(c_fold_rule(ctx, p, r, d_witness, cfb, &fold));
+    }
+    prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
+    ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
+    ctx->witness_gate_armed = true;
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_e_out, ctx->tm_ev[1], /*eval_form=*/true, 0, fold ? cfb.c_nat : nullptr,
+                           fold ? cfb.c_cls : nullptr));
+    if (fold) {
+        ctx->fold_armed_key = p;
+        ctx->fold_scalars = cfb.scalars;
+        ctx->fold_cls = cfb.cls;
+        if (folded) *folded = 1;
+    }
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(ctx);
+}
+
 extern "C" int zg_params_table_info(const zg_params* p, int which, int* kind, uint64_t* bytes) try {
     if (!p || which < 0 || which > 5 || !kind || !bytes) return ZG_E_INVALID_ARG;
     std::lock_guard<std::mutex> lock(p->fbw_mu);
@@ -2365,7 +2498,7 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     const bool folded = eval_form && d_witness && ctx->opt_c_fold && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
     if (folded) {
         CFoldBufs cb;
-        ZG_TRY(c_fold_buffers(ctx, r, d_witness, c_fold_n_l(p, r), &cb));
+        ZG_TRY(c_fold_buffers(ctx, p, r, d_witness, c_fold_n_l(p, r), &cb));
         ProveWs& ws = prove_ws(ctx);
         Fr* abc[3] = {nullptr, nullptr, nullptr};
         for (int k = 0; k < 2; k++) {
@@ -2545,6 +2678,14 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
 }
 extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const void* d_witness,
                                     const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
+    // (a pipeline queued by zg_prove_h_eval_enqueue_fold_dev left out C's transforms: the l query of that key carries its rows)
+    if (ctx && (mask & 2u) && ctx->fold_armed_key && ctx->fold_armed_key == (const void*)p) {
+        CFoldBufs cfb;
+        cfb.scalars = ctx->fold_scalars;
+        cfb.cls = ctx->fold_cls;
+        ctx->fold_armed_key = nullptr;
+        return prove_partials_impl(ctx, p, r, d_witness, d_h_shard, mask & 0x1fu, partials, (mask & ZG_MASK_H_EVAL) != 0, 0, &cfb, ctx->tm_ev[1]);
+    }
     return prove_partials_impl(ctx, p, r, d_witness, d_h_shard, mask & 0x1fu, partials, (mask & ZG_MASK_H_EVAL) != 0);
 } catch (...) {
     return zg::on_exception(ctx);
@@ -2691,6 +2832,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     double t0 = now_ms();
     if (!ctx->stats_keep) ctx->n_launches = 0;
     ctx->stats_keep = false;
+    ctx->fold_armed_key = nullptr;
     if (ctx->prof_enabled && !ctx->prof_pending.empty()) ZG_TRY(prof_drain(ctx));   // recycle the last proof's events
     ZG_TRY(check_query_sizes(ctx, p, r));
     const size_t m = (size_t)1 << r->log_m;
@@ -2711,7 +2853,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     if (eval_form) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness));
     const bool c_fold = eval_form && ctx->opt_c_fold && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
     CFoldBufs cfb;
-    if (c_fold) ZG_TRY(c_fold_buffers(ctx, r, d_witness, c_fold_n_l(p, r), &cfb));
+    if (c_fold) ZG_TRY(c_fold_buffers(ctx, p, r, d_witness, c_fold_n_l(p, r), &cfb));
     ZG_TRY(witness_classes(ctx, r, d_witness));   // 26 us at 2^22; read by the evaluator and by the witness multiexps
     prove_ws(ctx).wcls_fresh = prove_ws(ctx).wcls_armed = true;
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));

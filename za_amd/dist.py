@@ -162,7 +162,9 @@ class GpuEngine:
             self._h_all = torch.zeros(need * 32, dtype=torch.uint8, device=self.device)
             torch.cuda.current_stream(self.device).synchronize()
         if self.h_eval:
-            self.ctx.prove_h_eval_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
+            # (names the key: rank 0's shard may hold the bases of the folded C rows -- then four transforms instead of six,
+            # and this rank's l partial carries the C term; nothing changes for the other ranks)
+            self.c_folded = self.ctx.prove_h_eval_enqueue_fold_dev(self.params, self.r1cs, self.d_witness, self._h_all.data_ptr())
         else:
             self.ctx.prove_h_enqueue_dev(self.r1cs, self.d_witness, self._h_all.data_ptr())
 
