@@ -2495,10 +2495,17 @@ extern "C" int zg_params_prepare(zg_ctx* ctx, const zg_params* p, const zg_r1cs*
     // (first: a key whose C rows are folded into the l query needs no table for the plain l query, but one for the folded
     // query -- over this witness's aux values and the values its C rows evaluate to)
     if (eval_form && d_witness) ZG_TRY(ensure_c_fold(ctx, p, r, d_witness, /*retry=*/true));
-    const bool folded = eval_form && d_witness && ctx->opt_c_fold && c_fold_ready(p, r) && c_fold_size_ok(ctx, r->log_m);
-    if (folded) {
-        CFoldBufs cb;
+    bool folded = eval_form && d_witness && ctx->opt_c_fold && (p->world == 1 || p->rank == 0) && c_fold_ready(p, r) &&
+                  c_fold_size_ok(ctx, r->log_m);
+    CFoldBufs cb;
+    if (folded && p->world != 1) {   // rank 0's shard: its class bytes are copied (after they are made), its rule may not be decided yet
+        ZG_TRY(witness_classes(ctx, r, d_witness));
         ZG_TRY(c_fold_buffers(ctx, p, r, d_witness, c_fold_n_l(p, r), &cb));
+        ZG_TRY(c_fold_rule(ctx, p, r, d_witness, cb, &folded));
+    } else if (folded) {
+        ZG_TRY(c_fold_buffers(ctx, p, r, d_witness, c_fold_n_l(p, r), &cb));
+    }
+    if (folded) {
         ProveWs& ws = prove_ws(ctx);
         Fr* abc[3] = {nullptr, nullptr, nullptr};
         for (int k = 0; k < 2; k++) {
