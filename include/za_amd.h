@@ -107,8 +107,9 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *   ZG_OPT_SUBSET_W        positions per subset-sum group, 4 or 8 (default 8).  Read when a key's tables are built.
  *   ZG_OPT_COMPACT_TABLE   1 (default): compact window table behind the subset sums.  Read when tables are built.
  *   ZG_OPT_H_PARTS         parts the h multiexp is split into (0 = default: 2 for a lone context from 2^20 points, else 1).
- *   ZG_OPT_H_PIPE          1: the last transform kernel is launched range by range and every h part is gated on its
- *                          range alone (default 0: measured, no gain). */
+ *   ZG_OPT_H_PIPE          the last transform kernel is launched range by range and every h part is gated on its range alone:
+ *                          -1 (default) where the h multiexp runs in two parts anyway (a lone context, from 2^22 rows: one
+ *                          per cent of a 2^22 proof, measured four times out of four), 1 from 2^20 rows, 0 never. */
 #define ZG_OPT_SMALL_LOG_N 12
 #define ZG_OPT_SMALL_W_LOG_N 13
 #define ZG_OPT_SORT_STAGED 14

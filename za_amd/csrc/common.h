@@ -47,7 +47,8 @@ struct Ctx {
     int opt_subset_w = 8;             // ZG_OPT_SUBSET_W: positions per subset-sum group (4 | 8), read when a key's tables are built
     bool opt_compact_table = true;    // ZG_OPT_COMPACT_TABLE: compact window table behind the subset sums, read at table build
     int opt_h_parts = 0;              // ZG_OPT_H_PARTS: parts of the h multiexp (0 = the scheduler's choice)
-    bool opt_h_pipe = false;          // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
+    int opt_h_pipe = -1;              // ZG_OPT_H_PIPE: last transform kernel launched range by range, h parts gated per range
+                                      // (-1 = where the h multiexp runs in two parts: a lone context from 2^22 rows; 1 = from 2^20; 0 = off)
     int opt_ntt_batch_log_m = 21;     // ZG_OPT_NTT_BATCH_LOG_M: up to 2^value rows the H pipeline's passes take a, b, c in one launch
     int opt_share_sort = 1;           // ZG_OPT_SHARE_SORT: 0 a sort per query; 1 b_g1 behind b_g2, and one sort for the
                                       // full-density queries of one window-table plan; 2 one sort for all of them (position maps)

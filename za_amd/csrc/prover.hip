@@ -875,7 +875,10 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             if (value < 0 || value > Ctx::H_PARTS_MAX) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_H_PARTS: 0 .. %d", (int)Ctx::H_PARTS_MAX);
             ctx->opt_h_parts = (int)value;
             return ZG_OK;
-        case ZG_OPT_H_PIPE: ctx->opt_h_pipe = value != 0; return ZG_OK;
+        case ZG_OPT_H_PIPE:
+            if (value < -1 || value > 1) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_H_PIPE takes -1, 0 or 1");
+            ctx->opt_h_pipe = (int)value;
+            return ZG_OK;
         case ZG_OPT_NTT_BATCH_LOG_M:
             if (value < 0 || value > 28) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_NTT_BATCH_LOG_M: 0 .. 28");
             ctx->opt_ntt_batch_log_m = (int)value;
@@ -2867,11 +2870,15 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[0], ctx->stream));
     // The h multiexp of a large proof runs in parts (msm_batch5); in evaluation form the scalars of part k are final as
     // soon as the last transform kernel has passed them, so that kernel can be launched range by range with part k gated
-    // on its range alone (ZG_OPT_H_PIPE = 1).  Measured at 2^22, A/B on one box: no difference (11.93 / 11.76 vs 11.77 /
-    // 11.83 ms) -- the first part's digit sort and the rest of the transform kernel want the same CUs -- so it is off.
+    // on its range alone (ZG_OPT_H_PIPE).  Round 4, 2^22, A/B on one box: no difference (11.93 / 11.76 vs 11.77 / 11.83 ms: the
+    // first part's digit sort and the rest of the transform kernel want the same CUs).  Re-measured at the end of round 5 with
+    // the shorter pipeline (four transforms): 8.96 -> 8.87, 9.01 -> 8.90, 9.68 -> 9.57 (90 % bits), 9.82 -> 9.68 (six
+    // transforms) witness resident, zg_prove -0.09 / -0.10 / -0.18 / -0.01 -- one per cent, every time: on (-1 = auto) where the
+    // h multiexp runs in two parts anyway (a lone context, from 2^22 rows); 1 = from 2^20 rows (tests); 0 = off.
     int h_split = 0;
-    if (ctx->opt_h_pipe && eval_form && r->log_m >= 14) {
-        h_split = r->log_m >= 20 && live_contexts() == 1 ? 2 : 0;
+    const bool pipe_auto = ctx->opt_h_pipe < 0 && r->log_m >= 22;
+    if ((ctx->opt_h_pipe > 0 || pipe_auto) && eval_form && r->log_m >= 14) {
+        h_split = r->log_m >= (pipe_auto ? 22u : 20u) && live_contexts() == 1 ? 2 : 0;
         if (ctx->opt_h_parts > 0) h_split = std::min(ctx->opt_h_parts, (int)Ctx::H_PARTS_MAX);
         if (h_split == 1) h_split = 0;
     }
