@@ -1408,6 +1408,9 @@ def test_sharded_phases_with_the_c_rows_folded_on_rank_0(ctx, opts, lg, bitf):
             assert folded == want_fold and ctx.prove_combine(P1, allp, 3, r, s) == whole
         folded, allp = sharded(keys, 3, then_plain=True)
         assert not folded and ctx.prove_combine(P1, allp, 3, r, s) == whole
+        with pytest.raises(za_amd.ZaAmdError) as e:          # (argument checks as the plain entry's)
+            ctx.prove_h_eval_enqueue_fold_dev(keys[0], R, 0, d_e)
+        assert e.value.code == za_amd.ZG_E_ASSIGNMENT_MISSING
         for Pk in keys:
             Pk.close()
         P1.close()
