@@ -353,7 +353,9 @@ int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_
  * FOUR transforms, d_e_out receives a b / Z instead of (a b - c) / Z, and the next zg_prove_partials_ex on this context with
  * this key and the l query in its mask adds the multiexp of the rows' values to its l partial (*folded = 1).  The other
  * ranks do what they did: their h shards multiply whatever scalars they are sent.  Any other key: *folded = 0 and
- * exactly zg_prove_h_eval_enqueue_dev.  The sum of all ranks' partials is the same group element either way. */
+ * exactly zg_prove_h_eval_enqueue_dev.  The sum of all ranks' partials is the same group element either way.
+ * (What it costs rank 0 when its shard is loaded: a second group transform of the h query and 128 m bytes, whether or not
+ * the circuit's rows turn out to fold; zg_set_option(ZG_OPT_C_FOLD, 0) before zg_params_load leaves both out.) */
 int zg_prove_h_eval_enqueue_fold_dev(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness,
                                      void* d_e_out, int* folded);
 int zg_params_h_eval_info(const zg_params* params, uint64_t info[4]);
