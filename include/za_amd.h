@@ -106,7 +106,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          (default -1 = 16384; 0 = all of them).
  *   ZG_OPT_SUBSET_W        positions per subset-sum group, 4 or 8 (default 8).  Read when a key's tables are built.
  *   ZG_OPT_COMPACT_TABLE   1 (default): compact window table behind the subset sums.  Read when tables are built.
- *   ZG_OPT_H_PARTS         parts the h multiexp is split into (0 = default: 2 for a lone context from 2^20 points, else 1).
+ *   ZG_OPT_H_PARTS         parts the h multiexp is split into (0 = default: 2 for a lone context from 2^22 points, else 1).
  *   ZG_OPT_H_PIPE          the last transform kernel is launched range by range and every h part is gated on its range alone:
  *                          -1 (default) where the h multiexp runs in two parts anyway (a lone context, from 2^22 rows: one
  *                          per cent of a 2^22 proof, measured four times out of four), 1 from 2^20 rows, 0 never. */
