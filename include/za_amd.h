@@ -131,7 +131,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
 #define ZG_OPT_NTT_BATCH_LOG_M 21
 /*   ZG_OPT_C_FOLD          the quotient (a b - c) / Z is linear in c, and c's values on the domain are the C sides of the R1CS
  *                          rows as evaluated -- for a circuit of bit signals, bits and small integers.  1 (default): for a key
- *                          with the evaluation form whose first witness gives rows of few non-zero 16-bit digits (at most 3
+ *                          with the evaluation form whose first witness gives rows of few non-zero 16-bit digits (at most 2
  *                          per row on average, rows equal to 2 not counted; decided once per key, with its tables), zg_prove*
  *                          transform a and b only -- FOUR transforms instead of six -- and the C term enters as 2 m more
  *                          points of the l multiexp (a second transformed basis and its doubles, built once per key), for

@@ -2316,7 +2316,8 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
             if (trace_level() != 0 && (rc = msm_classify_counts(ctx, cb.scalars, nullptr, n_l + 2 * m, &zeros, &ones)) != ZG_OK) break;
             // What the rows cost as a multiexp: their non-zero 16-bit digits (an addition each; rows equal to 2 are ones on
             // the doubled bases and not counted).  Two transforms of m elements are worth ~3.4 additions per row (1.0 ms
-            // against 71 ps per addition at 2^22); folded up to 3 digits per row -- a bit-level circuit has 0.3 - 0.8 (AND
+            // against 71 ps per addition at 2^22, and the rows' entries are also sorted); folded up to 2 digits per row, the
+            // neighbourhood that was measured -- a bit-level circuit has 0.3 - 0.8 (AND
             // rows: bits; XOR rows as (2a) b = a + b - c: 0 or 2; adder rows: a word), the config-4 recipe at 90 % bits 1.8 (2^22:
             // 11.66 -> 10.88 ms folded), a circuit of field elements (Poseidon) 16 (2^20: 7.5 -> 8.4 ms folded).
             DevBuf cnt;
@@ -2330,7 +2331,7 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
             if (trace_level() != 0)
                 fprintf(stderr, "[za_amd trace] c_fold: %llu zeros, %llu ones among %llu aux values + 2 x %llu rows; the rows hold %llu digits\n",
                         (unsigned long long)zeros, (unsigned long long)ones, (unsigned long long)n_l, (unsigned long long)m, nz);
-            if (ctx->opt_c_fold == 1 && nz > m * 3) break;   // field elements: six transforms stay
+            if (ctx->opt_c_fold == 1 && nz > m * 2) break;   // field elements: six transforms stay
             if (built.alloc((n_l + 2 * m) * sizeof(G1Affine)) != hipSuccess) break;
             if (n_l && hipMemcpyAsync(built.p, p->q[1].buf.p, n_l * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
                 break;
@@ -2430,7 +2431,7 @@ static int c_fold_rule(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const 
     ZG_HIP(ctx, hipMemcpyAsync(&nz, cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::lock_guard<std::mutex> lock(p->fbw_mu);
-    if (p->lc_rule == 0) p->lc_rule = nz <= (unsigned long long)m * 3 ? 1 : -1;
+    if (p->lc_rule == 0) p->lc_rule = nz <= (unsigned long long)m * 2 ? 1 : -1;
     *fold = p->lc_rule > 0;
     return ZG_OK;
 }
