@@ -2317,7 +2317,7 @@ static int ensure_c_fold(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, cons
             // What the rows cost as a multiexp: their non-zero 16-bit digits (an addition each; rows equal to 2 are ones on
             // the doubled bases and not counted).  Two transforms of m elements are worth ~3.4 additions per row (1.0 ms
             // against 71 ps per addition at 2^22, and the rows' entries are also sorted); folded up to 2 digits per row, the
-            // neighbourhood that was measured -- a bit-level circuit has 0.3 - 0.8 (AND
+            // neighbourhood that was measured -- the SHA-256 Merkle circuit has 0.18, the config-4 recipe 0.27 (AND
             // rows: bits; XOR rows as (2a) b = a + b - c: 0 or 2; adder rows: a word), the config-4 recipe at 90 % bits 1.8 (2^22:
             // 11.66 -> 10.88 ms folded), a circuit of field elements (Poseidon) 16 (2^20: 7.5 -> 8.4 ms folded).
             DevBuf cnt;
