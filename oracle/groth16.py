@@ -312,6 +312,28 @@ def h_eval_bases_fft(h_points, log_m):
     return a
 
 
+def c_fold_bases_fft(h_points, log_m):
+    """c_fold_bases by the same decimation-in-frequency transform over the group (heval.hip with c_fold: every point scaled
+    by the constant -1 / (m Z(g)), no coset factor, bit-reversed out and put back in row order);
+    tests/test_oracle_python.py checks it against the definition."""
+    from .bn254 import pt_add, pt_mul, pt_neg
+    d = Domain(log_m)
+    m = d.m
+    k = (R - inv(d.z(FR_GENERATOR), R) * d.minv % R) % R
+    a = [pt_mul(h_points[i], k) for i in range(m - 1)] + [None]
+    for s in range(log_m - 1, -1, -1):
+        span = 1 << s
+        for t in range(m // 2):
+            low = t & (span - 1)
+            i0 = ((t >> s) << (s + 1)) | low
+            i1 = i0 | span
+            x, y = a[i0], a[i1]
+            a[i0] = pt_add(x, y)
+            dd = pt_add(x, pt_neg(y))
+            a[i1] = pt_mul(dd, pow(d.omegainv, low << (log_m - 1 - s), R)) if low else dd
+    return [a[bitreverse(j, log_m)] for j in range(m)]
+
+
 # ----------------------------------------------------------------------------- multiexp (bellman's Pippenger)
 def multiexp_window(n):
     return 3 if n < 32 else int(math.ceil(math.log(n)))

@@ -21,7 +21,7 @@ from tests.util import golden, r1cs_from_fixture
 class OracleEngine:
     """Same interface as za_amd.dist.GpuEngine, computed with the Python / C oracle on CPU tensors."""
 
-    def __init__(self, fx, rank, world, h_eval=False):
+    def __init__(self, fx, rank, world, h_eval=False, c_fold=False):
         from za_amd.dist import shard_range
         self.device = torch.device("cpu")
         self.rank, self.world = rank, world
@@ -37,6 +37,10 @@ class OracleEngine:
         self.h_eval = h_eval
         self.h_mask_extra = 0
         self._agreed = False
+        # the rank that runs the transforms folds its C rows (za_amd.dist.GpuEngine.start_h ->
+        # zg_prove_h_eval_enqueue_fold_dev): it scatters a b / Z, and its l partial carries the rows' multiexp
+        self.c_fold = c_fold and rank == 0
+        self.c_folded = False
 
     def agree_h_form(self, group=None):
         """As GpuEngine.agree_h_form: evaluation form only if every rank has the transformed bases."""
@@ -52,11 +56,11 @@ class OracleEngine:
         self._agreed = True
 
     def start_h(self):
-        pass
+        self.c_folded = self.h_eval and self.c_fold       # (decided when the pipeline is queued, as the library does)
 
     def finish_h(self):
         if self.h_eval:
-            e = g.h_eval_scalars(self.r1, self.w)
+            e = g.h_eval_scalars_without_c(self.r1, self.w) if self.c_folded else g.h_eval_scalars(self.r1, self.w)
             n = self.world * self.h_chunk_entries
             e = e + [0] * (n - len(e))
             return torch.frombuffer(bytearray(b"".join(bn.le32(x) for x in e[:n])), dtype=torch.uint8)
@@ -93,6 +97,10 @@ class OracleEngine:
         aux = self.w[ni:]
         lo, hi = self.shard_range(len(p.l), self.rank, self.world)
         l_acc = bn.msm_naive(p.l[lo:hi], aux[lo:hi])
+        if self.c_folded:                                   # rank 0: + sum_j c_j C_j over ALL the rows
+            c = g.eval_constraints(self.r1, self.w)[2]
+            Cj = g.c_fold_bases_fft(p.h, self.r1.domain_log())
+            l_acc = bn.pt_add(l_acc, bn.msm_naive(Cj[:len(c)], c))
         a_idx = list(range(ni)) + [ni + i for i, d in enumerate(self.ad) if d]
         b_idx = [i for i, d in enumerate(self.bi) if d] + [ni + i for i, d in enumerate(self.bd) if d]
         lo, hi = self.shard_range(len(p.a), self.rank, self.world)
@@ -132,10 +140,11 @@ def _worker(rank, world, port, out_path, form="coefficient"):
         from za_amd.dist import sharded_prove
         fx = golden("proof_chain7.json")
         # "evaluation": every rank has the transformed bases; "mixed": rank 1 has not -- all ranks must fall back
-        has_eval = form == "evaluation" or (form == "mixed" and rank == 0)
-        eng = OracleEngine(fx, rank, world, h_eval=has_eval)
+        has_eval = form in ("evaluation", "folded") or (form == "mixed" and rank == 0)
+        eng = OracleEngine(fx, rank, world, h_eval=has_eval, c_fold=form == "folded")
         proof = sharded_prove(eng, int(fx["r"], 16), int(fx["s"], 16))
-        assert eng.h_eval == (form == "evaluation")   # (the coefficient engine never had the bases; mixed ranks agree on "no")
+        assert eng.h_eval == (form in ("evaluation", "folded"))   # (the coefficient engine never had the bases; mixed ranks agree on "no")
+        assert eng.c_folded == (form == "folded" and rank == 0)
         if rank == 0:
             with open(out_path, "wb") as f:
                 f.write(proof)
@@ -161,11 +170,12 @@ def test_sharded_prove_over_gloo_matches_golden(tmp_path, world):
     assert open(out, "rb").read().hex() == fx["proof"]
 
 
-@pytest.mark.parametrize("form", ["evaluation", "mixed"])
+@pytest.mark.parametrize("form", ["evaluation", "mixed", "folded"])
 def test_sharded_prove_with_h_in_evaluation_form(tmp_path, form):
     """The orchestration's second mode: rank 0 scatters the coset evaluations e in ranges of ceil(m / world), the ranks
     multiply them into their slices of the transformed h bases (mask bit 0x20) -- same golden proof; and when one rank
-    lacks those bases, every rank agrees on the coefficient form."""
+    lacks those bases, every rank agrees on the coefficient form.  "folded": rank 0 runs four transforms -- it scatters
+    a b / Z and its l partial carries the multiexp of the C rows' values (the other rank does what it did)."""
     out = str(tmp_path / "proof.bin")
     mp.spawn(_worker, args=(2, _free_port(), out, form), nprocs=2, join=True)
     assert open(out, "rb").read().hex() == golden("proof_chain7.json")["proof"]

@@ -187,6 +187,7 @@ def test_c_rows_folded_into_the_l_multiexp_is_the_same_group_element():
     params, _ = g.generate_parameters(r1, 21, 22, 23, 24, 25)
     Hp = g.h_eval_bases(params.h, 4)
     Cj = g.c_fold_bases(params.h, 4)
+    assert g.c_fold_bases_fft(params.h, 4) == Cj      # the transform schedule of heval.hip gives the defined array
     C2 = [bn.pt_add(P, P) for P in Cj]
     bad = list(w)
     bad[len(bad) // 2] = (bad[len(bad) // 2] + 5) % bn.R
