@@ -281,6 +281,92 @@ assert is_on_curve(G1_GEN, G1_B)
 assert is_on_curve(G2_GEN, G2_B)
 
 
+# ----------------------------------------------------------------------------- G2 membership (order-r subgroup of the twist)
+# pairing_ce's G2Uncompressed::into_affine -- what Parameters::read(checked = true) pays per b_g2 point
+# (prover/src/groth16/format.rs:285) -- tests [r]P = O.  The twist E'(Fq2) has order r * (2q - r), so that IS a test:
+# g2_in_subgroup_by_order below is the definition.  g2_in_subgroup_by_psi is the endomorphism form the device kernel
+# uses (za_amd/csrc/keyload.hip): with psi = twist o Frobenius o untwist,
+#     P in G2  <=>  [u + 1]P + psi([u]P) + psi^2([u]P) = psi^3([2u]P)             (u = BN_U)
+# "=>": psi acts on G2 as multiplication by q, and f(q) = (u+1) + u q + u q^2 - 2u q^3 = 0 (mod r).
+# "<=": psi^2 - t psi + q = 0 on E'(Fq2) (t = 6u^2 + 1), so f(psi) has a norm N = a^2 + a b t + b^2 q in Z (f = a + b psi
+# after reduction) with N P = O whenever f(psi) P = O; gcd(N, 2q - r) = 1, hence the order of such a P divides r.
+# Both facts are integers and are asserted in tests/test_oracle_python.py::test_psi_membership_test_is_exact.
+def fq2_pow(a, e):
+    r = Fq2(1, 0)
+    while e:
+        if e & 1:
+            r = r * a
+        a = a * a
+        e >>= 1
+    return r
+
+
+def fq_sqrt(a):
+    a %= Q
+    s = pow(a, (Q + 1) // 4, Q)          # q = 3 (mod 4)
+    return s if s * s % Q == a else None
+
+
+def fq2_sqrt(a):
+    """A square root of a in Fq2 = Fq[u]/(u^2 + 1), or None."""
+    if a.is_zero():
+        return Fq2(0, 0)
+    n = fq_sqrt(a.c0 * a.c0 + a.c1 * a.c1)
+    if n is None:
+        return None
+    for s in (n, Q - n):
+        x0 = fq_sqrt((a.c0 + s) * inv(2, Q))
+        if x0:
+            r = Fq2(x0, a.c1 * inv(2 * x0, Q))
+            if r * r == a:
+                return r
+    if a.c1 == 0:                        # a = -(x1^2): a pure-imaginary root
+        x1 = fq_sqrt(-a.c0)
+        if x1 is not None:
+            return Fq2(0, x1)
+    return None
+
+
+def fq2_conj(a):
+    return Fq2(a.c0, -a.c1)
+
+
+_XI = Fq2(9, 1)
+PSI_X = fq2_pow(_XI, (Q - 1) // 3)       # xi^((q-1)/3)
+PSI_Y = fq2_pow(_XI, (Q - 1) // 2)       # xi^((q-1)/2)
+
+
+def g2_psi(P):
+    """The untwist-Frobenius-twist endomorphism of E'(Fq2): (x, y) -> (conj(x) xi^((q-1)/3), conj(y) xi^((q-1)/2))."""
+    if P is None:
+        return None
+    return (fq2_conj(P[0]) * PSI_X, fq2_conj(P[1]) * PSI_Y)
+
+
+def g2_in_subgroup_by_order(P):
+    return P is None or pt_mul(P, R, order=1 << 300) is None
+
+
+def g2_in_subgroup_by_psi(P):
+    if P is None:
+        return True
+    uP = pt_mul(P, BN_U, order=1 << 300)
+    lhs = pt_add(pt_add(pt_add(uP, P), g2_psi(uP)), g2_psi(g2_psi(uP)))
+    rhs = pt_double(g2_psi(g2_psi(g2_psi(uP))))
+    return lhs == rhs if (lhs is None) == (rhs is None) else False
+
+
+def g2_twist_point(seed):
+    """A point of E'(Fq2) with x derived from `seed` -- almost never in the order-r subgroup (cofactor 2q - r)."""
+    k = seed
+    while True:
+        x = Fq2(k, seed * 7 + 1)
+        y = fq2_sqrt(x * x * x + G2_B)
+        if y is not None:
+            return (x, y)
+        k += 1
+
+
 # ----------------------------------------------------------------------------- Fq12 and the optimal ate pairing
 # Degree-12 extension as Fq[w]/(w^12 - 18 w^6 + 82) (w^6 = 9 + u).  Plain schoolbook
 # polynomial arithmetic; slow (a verification takes a few seconds) and only used by tests.

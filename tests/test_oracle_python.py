@@ -218,3 +218,45 @@ def test_c_rows_folded_into_the_l_multiexp_is_the_same_group_element():
             else:
                 rhs = bn.pt_add(rhs, bn.pt_mul(Cj[j], cj))
         assert lhs == rhs and lhs is not None
+
+
+def test_psi_membership_test_is_exact():
+    """The device's G2 membership test (za_amd/csrc/keyload.hip) is [u+1]P + psi([u]P) + psi^2([u]P) = psi^3([2u]P) instead
+    of pairing_ce's [r]P = O.  Both directions of "accepts the same set" are integer facts (oracle/bn254.py), checked
+    here, and the two tests are compared on points in G2, outside it, of small cofactor order, and on sums of both kinds."""
+    import math
+    q, r, u = bn.Q, bn.R, bn.BN_U
+    t = 6 * u * u + 1                      # trace of Frobenius: #E(Fq) = q + 1 - t = r
+    assert q + 1 - t == r
+    cof = 2 * q - r                        # #E'(Fq2) = r (2q - r)
+    # "=>": psi = [q] on G2 and f(q) = 0 (mod r)
+    lam = q % r
+    assert ((u + 1) + u * lam + u * lam * lam - 2 * u * pow(lam, 3, r)) % r == 0
+    assert bn.g2_psi(bn.G2_GEN) == bn.pt_mul(bn.G2_GEN, lam) and bn.is_on_curve(bn.g2_psi(bn.G2_GEN), bn.G2_B)
+    # "<=": f(X) mod (X^2 - t X + q) = a + b X; its norm a^2 + a b t + b^2 q annihilates the kernel of f(psi) and is
+    # coprime to the cofactor (and a multiple of r, as it must be)
+    c = [u + 1, u, u, -2 * u]
+    while len(c) > 2:
+        top = c.pop()
+        c[-1] += top * t
+        c[-2] -= top * q
+    a, b = c
+    norm = a * a + a * b * t + b * b * q
+    assert math.gcd(norm, cof) == 1 and norm % r == 0 and cof % r != 0
+    # the two tests side by side
+    for k in (1, 2, 0xdeadbeef, r - 1):
+        P = bn.pt_mul(bn.G2_GEN, k)
+        assert bn.g2_in_subgroup_by_psi(P) and bn.g2_in_subgroup_by_order(P)
+    assert cof % 10069 == 0
+    for seed in (1, 2, 3):
+        T = bn.g2_twist_point(seed)
+        assert bn.is_on_curve(T, bn.G2_B)
+        assert not bn.g2_in_subgroup_by_psi(T) and not bn.g2_in_subgroup_by_order(T)
+        in_g2 = bn.pt_mul(T, cof, order=1 << 600)                  # cofactor cleared
+        assert bn.g2_in_subgroup_by_psi(in_g2) and bn.g2_in_subgroup_by_order(in_g2)
+        small = bn.pt_mul(T, r * (cof // 10069), order=1 << 600)    # order 1 or 10069
+        if small is not None:
+            assert bn.pt_mul(small, 10069, order=1 << 20) is None
+            assert not bn.g2_in_subgroup_by_psi(small) and not bn.g2_in_subgroup_by_order(small)
+            mixed = bn.pt_add(in_g2, small)
+            assert not bn.g2_in_subgroup_by_psi(mixed) and not bn.g2_in_subgroup_by_order(mixed)

@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libza_amd.so")
 LIB_ZA2C = os.path.join(HERE, "libza2c.so")     # the outer drop-in boundary: za's C binding symbols (csrc/za2c.cpp)
 DRIVER = os.path.join(HERE, "za-gpu")           # `za setup|prove` shaped command-line driver (csrc/za_gpu_main.cpp)
 LIB_SYNTH = os.path.join(HERE, "libza_amd_synth.so")   # synthetic workloads + self-test hooks (include/za_amd_synth.h): NOT the product
-SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "prover.hip", "setup.hip", "pairing.hip", "outer.hip"]
+SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "keyload.hip", "prover.hip", "setup.hip", "pairing.hip", "outer.hip"]
 SYNTH_SOURCES = ["synth.hip"]
 HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "nttd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

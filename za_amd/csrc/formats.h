@@ -15,7 +15,8 @@ struct ParsedParams {
     std::vector<G2Affine> b_g2;
 };
 
-// Parameters::read(reader, checked) -- reference call site prover/src/groth16/format.rs:285.
+// Parameters::read(reader, checked) -- reference call site prover/src/groth16/format.rs:285.  Everything on the host: the
+// cross-check of the device path below (zg_params_inspect) and the reader of verifying keys.
 int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed);
 // Parameters::write -- reference call site prover/src/groth16/format.rs:250.
 void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out);
@@ -42,6 +43,35 @@ struct PkR1cs {
 int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public, uint32_t n_aux, PkR1cs* out);
 int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal, uint32_t n_vars, const uint8_t* bw,
                             size_t len, uint8_t* witness_out);
+
+// ---- Parameters::read with the five queries decoded and validated on the device (keyload.hip) -------------------------
+// What is wrong with a point, in the order pairing_ce's readers test it; KEY_PT_INFINITY = a well-formed identity inside a
+// query (bellman: "point at infinity").
+enum KeyPointStatus { KEY_PT_OK = 0, KEY_PT_COMPRESSED, KEY_PT_BAD_INFINITY, KEY_PT_NOT_IN_FIELD, KEY_PT_NOT_ON_CURVE,
+                      KEY_PT_NOT_IN_SUBGROUP, KEY_PT_INFINITY };
+// the error both parsers raise for a bad point of `what` ("h", "vk.alpha_g1", ...): ZG_E_IO + bellman's wording
+int key_point_error(Ctx* ctx, const char* what, int status);
+const char* key_query_name(int which);
+struct KeyQuery {
+    size_t off = 0;     // first point, from the start of the Parameters body
+    uint64_t n = 0;
+};
+// The host's part: the verifying key (parsed, validated and converted on the host: 6 points + ic), the walk over the five
+// length-prefixed queries (bounds only).  out receives the vk and ic; its query vectors stay empty.
+int parse_bellman_header(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, KeyQuery q[5], size_t* consumed);
+struct KeyStage {   // the raw bytes' way through HBM: two chunk buffers used in turn
+    static constexpr size_t CHUNK_BYTES = (size_t)64 << 20;
+    DevBuf buf[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int next = 0;
+    ~KeyStage() {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+int key_decode_query_dev(Ctx* ctx, int which, const uint8_t* host_raw, uint64_t n, bool checked, uint64_t lo, uint64_t hi,
+                         void* d_out, unsigned long long* d_verdict, KeyStage* stage);
+int key_verdict_to_error(Ctx* ctx, const unsigned long long verdict[5]);
 
 Fq2 g2_coeff_b();                       // 3/(9+u), Montgomery
 bool g2_in_subgroup(const G2Affine& p); // [r]P == identity (the twist has a large cofactor; G1's is 1)

@@ -47,7 +47,11 @@ bool fq_from_be(const uint8_t in[32], Fq* mont) {
 
 namespace {
 
-enum PointStatus { PT_OK = 0, PT_COMPRESSED, PT_BAD_INFINITY, PT_NOT_IN_FIELD, PT_NOT_ON_CURVE, PT_NOT_IN_SUBGROUP };
+// (the same classes, in the same order, as the device decoder's: formats.h KeyPointStatus)
+using PointStatus = KeyPointStatus;
+constexpr PointStatus PT_OK = KEY_PT_OK, PT_COMPRESSED = KEY_PT_COMPRESSED, PT_BAD_INFINITY = KEY_PT_BAD_INFINITY,
+                      PT_NOT_IN_FIELD = KEY_PT_NOT_IN_FIELD, PT_NOT_ON_CURVE = KEY_PT_NOT_ON_CURVE,
+                      PT_NOT_IN_SUBGROUP = KEY_PT_NOT_IN_SUBGROUP;
 
 // pairing_ce bn256 G1Uncompressed: x || y big-endian; byte0 bit7 = compression flag (must be clear),
 // bit6 = identity (then everything else must be zero).
@@ -88,7 +92,7 @@ PointStatus read_g2(const uint8_t* b, bool checked, const Fq2& coeff_b, G2Affine
     return PT_OK;
 }
 
-const char* status_str(PointStatus s) {
+const char* status_str(int s) {
     switch (s) {
         case PT_COMPRESSED: return "unexpected compression mode";
         case PT_BAD_INFINITY: return "unexpected information in infinity encoding";
@@ -135,9 +139,23 @@ struct Reader {
     }
 };
 
+// lowest (index << 3 | class) over the points that fail: what the device decoder reports too
+void note_bad(std::atomic<uint64_t>* first, uint64_t index, int status) {
+    const uint64_t v = (index << 3) | (uint64_t)status;
+    uint64_t cur = first->load();
+    while (v < cur && !first->compare_exchange_weak(cur, v)) {
+    }
+}
+
 }  // namespace
 
-int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed) {
+int key_point_error(Ctx* ctx, const char* what, int status) {
+    if (status == KEY_PT_INFINITY) return fail(ctx, ZG_E_IO, "%s: point at infinity", what);
+    return fail(ctx, ZG_E_IO, "%s: %s", what, status_str(status));
+}
+
+// vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1, delta_g2, ic) on the host, then the bounds of the five queries
+int parse_bellman_header(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, KeyQuery q[5], size_t* consumed) {
     Reader rd{buf, len};
     const Fq2 b2 = g2_coeff_b();
     const uint8_t* b;
@@ -145,14 +163,12 @@ int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked,
 #define RD_G1(dst, what)                                                                              \
     do {                                                                                              \
         if (!rd.take(64, &b)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading " what); \
-        if ((st = read_g1(b, checked, &(dst))) != PT_OK)                                              \
-            return fail(ctx, ZG_E_IO, what ": %s", status_str(st));                                   \
+        if ((st = read_g1(b, checked, &(dst))) != PT_OK) return key_point_error(ctx, what, st);      \
     } while (0)
 #define RD_G2(dst, what)                                                                              \
     do {                                                                                              \
         if (!rd.take(128, &b)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading " what); \
-        if ((st = read_g2(b, checked, b2, &(dst))) != PT_OK)                                          \
-            return fail(ctx, ZG_E_IO, what ": %s", status_str(st));                                   \
+        if ((st = read_g2(b, checked, b2, &(dst))) != PT_OK) return key_point_error(ctx, what, st);  \
     } while (0)
     RD_G1(out->alpha_g1, "vk.alpha_g1");
     RD_G1(out->beta_g1, "vk.beta_g1");
@@ -165,52 +181,54 @@ int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked,
     if ((size_t)n * 64 > len - rd.pos) return fail(ctx, ZG_E_IO, "ic length %u exceeds the buffer", n);
     out->ic.resize(n);
     for (uint32_t i = 0; i < n; i++) RD_G1(out->ic[i], "vk.ic");
-
-    auto read_vec_g1 = [&](std::vector<G1Affine>& v, const char* what) -> int {
+#undef RD_G1
+#undef RD_G2
+    for (int which = 0; which < 5; which++) {
+        const char* what = key_query_name(which);
         uint32_t cnt;
         if (!rd.u32be(&cnt)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading |%s|", what);
         const uint8_t* base;
-        if (!rd.take((size_t)cnt * 64, &base)) return fail(ctx, ZG_E_IO, "unexpected end of parameters inside %s", what);
-        v.resize(cnt);
-        std::atomic<int> bad{0};
-        parallel_chunks(cnt, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; i++) {
-                PointStatus s = read_g1(base + 64 * i, checked, &v[i]);
-                if (s != PT_OK) bad.store((int)s);
-                else if (v[i].is_inf()) bad.store(100);
-            }
-        });
-        int bs = bad.load();
-        if (bs == 100) return fail(ctx, ZG_E_IO, "%s: point at infinity", what);
-        if (bs) return fail(ctx, ZG_E_IO, "%s: %s", what, status_str((PointStatus)bs));
-        return ZG_OK;
-    };
-    ZG_TRY(read_vec_g1(out->h, "h"));
-    ZG_TRY(read_vec_g1(out->l, "l"));
-    ZG_TRY(read_vec_g1(out->a, "a"));
-    ZG_TRY(read_vec_g1(out->b_g1, "b_g1"));
-    {
-        uint32_t cnt;
-        if (!rd.u32be(&cnt)) return fail(ctx, ZG_E_IO, "unexpected end of parameters reading |b_g2|");
-        const uint8_t* base;
-        if (!rd.take((size_t)cnt * 128, &base)) return fail(ctx, ZG_E_IO, "unexpected end of parameters inside b_g2");
-        out->b_g2.resize(cnt);
-        std::atomic<int> bad{0};
-        parallel_chunks(cnt, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; i++) {
-                PointStatus s = read_g2(base + 128 * i, checked, b2, &out->b_g2[i]);
-                if (s != PT_OK) bad.store((int)s);
-                else if (out->b_g2[i].is_inf()) bad.store(100);
-            }
-        });
-        int bs = bad.load();
-        if (bs == 100) return fail(ctx, ZG_E_IO, "b_g2: point at infinity");
-        if (bs) return fail(ctx, ZG_E_IO, "b_g2: %s", status_str((PointStatus)bs));
+        if (!rd.take((size_t)cnt * (which == 4 ? 128 : 64), &base))
+            return fail(ctx, ZG_E_IO, "unexpected end of parameters inside %s", what);
+        q[which].off = (size_t)(base - buf);
+        q[which].n = cnt;
     }
     if (consumed) *consumed = rd.pos;
     return ZG_OK;
-#undef RD_G1
-#undef RD_G2
+}
+
+int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed) {
+    KeyQuery q[5];
+    ZG_TRY(parse_bellman_header(ctx, buf, len, checked, out, q, consumed));
+    const Fq2 b2 = g2_coeff_b();
+    std::vector<G1Affine>* g1v[4] = {&out->h, &out->l, &out->a, &out->b_g1};
+    for (int which = 0; which < 5; which++) {
+        const uint8_t* base = buf + q[which].off;
+        const uint64_t cnt = q[which].n;
+        if (which < 4) g1v[which]->resize(cnt);
+        else out->b_g2.resize(cnt);
+        std::atomic<uint64_t> first{~0ull};
+        parallel_chunks(cnt, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                PointStatus s;
+                bool inf;
+                if (which < 4) {
+                    G1Affine& p = (*g1v[which])[i];
+                    s = read_g1(base + 64 * i, checked, &p);
+                    inf = s == PT_OK && p.is_inf();
+                } else {
+                    G2Affine& p = out->b_g2[i];
+                    s = read_g2(base + 128 * i, checked, b2, &p);
+                    inf = s == PT_OK && p.is_inf();
+                }
+                if (s != PT_OK) note_bad(&first, i, (int)s);
+                else if (inf) note_bad(&first, i, KEY_PT_INFINITY);
+            }
+        });
+        const uint64_t v = first.load();
+        if (v != ~0ull) return key_point_error(ctx, key_query_name(which), (int)(v & 7u));
+    }
+    return ZG_OK;
 }
 
 static void put_g1(std::vector<uint8_t>* o, const G1Affine& p) {

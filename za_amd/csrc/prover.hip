@@ -1428,6 +1428,8 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
 } catch (...) {
     return zg::on_exception(ctx);
 }
+static int params_load_impl(zg_ctx* ctx, const uint8_t* body, size_t len, bool checked, int rank, int world, zg_params** out,
+                            size_t* consumed, ParsedParams* vk_out);
 // za proving key -> (R1CS, Parameters) in one call
 extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checked, int rank, int world, zg_r1cs** r1cs_out,
                           zg_params** params_out) try {
@@ -1437,24 +1439,22 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     size_t off = 0;
     if (pk_params_offset(pk, len, &off) != ZG_OK) return fail(ctx, ZG_E_IO, "pk: truncated container header");
     // the key itself tells how many public inputs (|ic| - 1) and aux variables (|l|) the circuit has
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    if (world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
     ParsedParams pp;
-    size_t used = 0;
-    ZG_TRY(parse_bellman_params(ctx, pk + off, len - off, checked != 0, &pp, &used));
+    zg_params* p = nullptr;
+    ZG_TRY(params_load_impl(ctx, pk + off, len - off, checked != 0, rank, world, &p, nullptr, &pp));
+    std::unique_ptr<zg_params> pguard(p);
     if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
     PkR1cs pr;
-    ZG_TRY(parse_pk_r1cs(ctx, pk, len, (uint32_t)pp.ic.size() - 1, (uint32_t)pp.l.size(), &pr));
+    ZG_TRY(parse_pk_r1cs(ctx, pk, len, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
     const uint64_t* rp[3] = {pr.row_ptr[0].data(), pr.row_ptr[1].data(), pr.row_ptr[2].data()};
     const uint32_t* cl[3] = {pr.col[0].data(), pr.col[1].data(), pr.col[2].data()};
     const uint8_t* cf[3] = {pr.coeff[0].data(), pr.coeff[1].data(), pr.coeff[2].data()};
     zg_r1cs* r = nullptr;
     ZG_TRY(zg_r1cs_load(ctx, pr.n_inputs, pr.n_aux, pr.n_constraints, rp, cl, cf, &r));
     r->var_of_signal = pr.var_of_signal;
-    zg_params* p = nullptr;
-    int rc = zg_params_load(ctx, pk + off, len - off, 0 /* already validated above */, rank, world, &p, nullptr);
-    if (rc) {
-        delete r;
-        return rc;
-    }
+    pguard.release();
     *r1cs_out = r;
     *params_out = p;
     return ZG_OK;
@@ -1673,13 +1673,15 @@ extern "C" int zg_params_from_mont(zg_ctx* ctx, const uint8_t vk5[448], const ui
     return zg::on_exception(ctx);
 }
 
-extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank, int world,
-                              zg_params** out, size_t* consumed) try {
-    if (!ctx || !bellman_params || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
-    *out = nullptr;
-    ZG_HIP(ctx, hipSetDevice(ctx->device));
+// Parameters::read(reader, checked): the verifying key on the host, the five queries decoded -- and, checked, validated:
+// on the curve, G2 points in the order-r subgroup, no identity -- by the device (keyload.hip) straight into the resident
+// arrays.  A sharded key validates the WHOLE key on every rank (as every process of the reference reads all of it) but
+// keeps, and when unchecked only uploads, its own chunk of each query.
+static int params_load_impl(zg_ctx* ctx, const uint8_t* body, size_t len, bool checked, int rank, int world, zg_params** out,
+                            size_t* consumed, ParsedParams* vk_out /* nullable: the parsed vk + ic */) {
     ParsedParams pp;
-    ZG_TRY(parse_bellman_params(ctx, bellman_params, len, checked != 0, &pp, consumed));
+    KeyQuery kq[5];
+    ZG_TRY(parse_bellman_header(ctx, body, len, checked, &pp, kq, consumed));
     std::unique_ptr<zg_params> p(new zg_params());
     p->rank = rank;
     p->world = world;
@@ -1687,26 +1689,48 @@ extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t
     p->beta_g2 = pp.beta_g2; p->delta_g2 = pp.delta_g2;
     p->gamma_g2 = pp.gamma_g2;
     p->ic = pp.ic;
-    ZG_TRY(params_upload(ctx, p.get(), 0, pp.h.data(), pp.h.size(), 64));
-    ZG_TRY(params_upload(ctx, p.get(), 1, pp.l.data(), pp.l.size(), 64));
-    ZG_TRY(params_upload(ctx, p.get(), 2, pp.a.data(), pp.a.size(), 64));
-    ZG_TRY(params_upload(ctx, p.get(), 3, pp.b_g1.data(), pp.b_g1.size(), 64));
-    ZG_TRY(params_upload(ctx, p.get(), 4, pp.b_g2.data(), pp.b_g2.size(), 128));
-    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (world > 1 && !pp.h.empty()) {
-        // a sharded key takes its slice of the evaluation-form h bases now, while the whole query is at hand (every rank
-        // parses the whole key): upload it, transform, keep [rank * ceil(m / world), ...)
-        DevBuf whole;
-        if (whole.alloc(pp.h.size() * sizeof(G1Affine)) == hipSuccess) {
-            ZG_HIP(ctx, hipMemcpyAsync(whole.p, pp.h.data(), pp.h.size() * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
-            ZG_TRY(convert_mont_dev(ctx, whole.p, pp.h.size() * 2, 0, 0));
-            ZG_TRY(params_h_eval_slice(ctx, p.get(), whole.as<G1Affine>(), pp.h.size(), nullptr));
+    KeyStage stage;
+    DevBuf verdict, whole_h;
+    ZG_HIP(ctx, verdict.alloc(5 * sizeof(unsigned long long)));
+    ZG_HIP(ctx, hipMemsetAsync(verdict.p, 0xff, 5 * sizeof(unsigned long long), ctx->stream));
+    // a sharded key takes its slice of the evaluation-form h bases now, while the whole query is at hand: decode all of h
+    bool want_whole_h = world > 1 && kq[0].n > 0;
+    if (want_whole_h && whole_h.alloc(kq[0].n * sizeof(G1Affine)) != hipSuccess) {
+        (void)hipGetLastError();
+        want_whole_h = false;
+    }
+    for (int which = 0; which < 5; which++) {
+        auto& q = p->q[which];
+        const size_t elem = which == 4 ? 128 : 64;
+        q.total = kq[which].n;
+        shard_range(q.total, rank, world, &q.lo, &q.hi);
+        ZG_HIP(ctx, q.buf.alloc((q.hi - q.lo) * elem));
+        unsigned long long* v = verdict.as<unsigned long long>() + which;
+        if (which == 0 && want_whole_h) {
+            ZG_TRY(key_decode_query_dev(ctx, 0, body + kq[0].off, q.total, checked, 0, q.total, whole_h.p, v, &stage));
+            if (q.hi > q.lo)
+                ZG_HIP(ctx, hipMemcpyAsync(q.buf.p, whole_h.as<G1Affine>() + q.lo, (q.hi - q.lo) * elem, hipMemcpyDeviceToDevice,
+                                           ctx->stream));
         } else {
-            (void)hipGetLastError();
+            ZG_TRY(key_decode_query_dev(ctx, which, body + kq[which].off, q.total, checked, q.lo, q.hi, q.buf.p, v, &stage));
         }
     }
+    unsigned long long vh[5];
+    ZG_HIP(ctx, hipMemcpyAsync(vh, verdict.p, sizeof(vh), hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZG_TRY(key_verdict_to_error(ctx, vh));
+    if (want_whole_h) ZG_TRY(params_h_eval_slice(ctx, p.get(), whole_h.as<G1Affine>(), kq[0].n, nullptr));
+    if (vk_out) *vk_out = std::move(pp);
     *out = p.release();
     return ZG_OK;
+}
+
+extern "C" int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank, int world,
+                              zg_params** out, size_t* consumed) try {
+    if (!ctx || !bellman_params || !out || world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
+    *out = nullptr;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
+    return params_load_impl(ctx, bellman_params, len, checked != 0, rank, world, out, consumed, nullptr);
 } catch (...) {
     return zg::on_exception(ctx);
 }
