@@ -239,9 +239,13 @@ int zg_r1cs_eval(zg_ctx* ctx, const zg_r1cs* r, const uint8_t* witness32, uint8_
  * zg_params_load replaces bellman_ce::groth16::Parameters::<Bn256>::read(reader, checked)
  * (prover/src/groth16/format.rs:285): vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
  * delta_g2, u32be |ic|, ic[]), then u32be-length-prefixed h, l, a, b_g1, b_g2, points uncompressed
- * big-endian.  `checked` enables the on-curve test; identity inside h/l/a/b_* is rejected.
- * rank/world shard every query into `world` contiguous chunks and keep chunk `rank` in HBM
- * (world = 1: everything).  *consumed receives the number of bytes read. */
+ * big-endian.  `checked` enables the tests Parameters::read(.., true) makes per point -- on the curve, and for G2
+ * in the order-r subgroup (pairing_ce's into_affine); identity inside h/l/a/b_* is rejected either way.  The five queries
+ * are decoded and validated ON THE DEVICE (csrc/keyload.hip: the raw bytes are uploaded, one kernel per query writes the
+ * resident arrays and reports the first bad point), the verifying key on the host; the errors are bellman's, worded as
+ * the host-only parser words them.  rank/world shard every query into `world` contiguous chunks and keep chunk `rank`
+ * in HBM (world = 1: everything); a checked load validates the whole key on every rank.  *consumed receives the number of
+ * bytes read. */
 int zg_params_load(zg_ctx* ctx, const uint8_t* bellman_params, size_t len, int checked, int rank,
                    int world, zg_params** out, size_t* consumed);
 /* Same, from Montgomery-LE arrays already in memory (what a Rust caller holding a
@@ -432,10 +436,16 @@ int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size
                   char* out, size_t cap);
 
 /* ---- timing of the last zg_prove* call on this ctx (milliseconds, host clock):
- * [0] witness bytes uploaded by zg_prove (the copy itself is part of [5]), [1] R1CS evaluation, [2] H (7 NTTs), [3] MSMs, [4] combine, [5] total. */
+ * [0] witness bytes uploaded by zg_prove (the copy itself is part of [5]), [1] R1CS evaluation, [2] the H pipeline (seven
+ * transforms in coefficient form, six with the key's h bases in evaluation form, four with the C rows folded: zg_last_stats[3]),
+ * [3] MSMs, [4] combine, [5] total. */
 int zg_last_timings(const zg_ctx* ctx, double ms[6]);
+/* ---- timing of the last zg_params_load / zg_pk_load on this ctx (milliseconds, host clock): [0] verifying key + container
+ * walk on the host, [1] the five queries: upload, decoding and (checked) validation on the device, [2] zg_pk_load only: the
+ * constraint sections of the container -> CSR (host threads), [3] zg_pk_load only: zg_r1cs_load of that CSR. */
+int zg_last_load_timings(const zg_ctx* ctx, double ms[4]);
 /* ---- what the last zg_prove* call (or, for the phase API, everything since the last one) queued on the GPU:
- * [0] kernel launches, [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
+ * [0] kernel launches (a key's FIRST proof also counts its one-time work: table builds, the group transforms of the h query), [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
  * sort over the witness positions in the last batch of multiexps (0 = none), [2] 1 if the b_g1 multiexp ran over the b_g2
  * multiexp's sorted entries (same scalars, same positions, tables of one layout), [3] 1 if the proof ran with four
  * transforms and its C rows folded into the l multiexp (ZG_OPT_C_FOLD). */

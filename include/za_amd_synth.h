@@ -29,6 +29,15 @@ int zg_synth_r1cs_info(const zg_synth* s, uint64_t info[6]);
 const void* zg_synth_ptr(const zg_synth* s, int which);
 void zg_synth_free(zg_synth* s);
 
+/* What `za setup` and the evaluator would leave on disk for such a circuit: the proving.key container
+ * (prover/src/groth16/format.rs:223-252) around a Parameters body -- signal id = variable index, no ignored signals, an
+ * empty AST vector, C's coefficients negated (the container holds a*b + c = 0) -- and the .binwitness dump
+ * (compiler/src/tester/embeeded.rs:47-57) of n 32-byte canonical values.  Inputs of libza2c's prove() at bench sizes. */
+int zg_synth_pk_container_write(const char* path, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
+                                const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                                const uint8_t* const coeff[3], const uint8_t* params, size_t params_len);
+int zg_synth_binwitness_write(const char* path, const uint8_t* witness32, size_t n);
+
 /* d_out[i] = k_i * G with k_i = splitmix64(seed + i) (a known discrete log, so MSM results can be
  * checked as (sum s_i k_i) * G).  Affine Montgomery LE, 64 B (G1) / 128 B (G2) per point. */
 int zg_synth_bases_g1_dev(zg_ctx* ctx, void* d_out, size_t n, uint64_t seed);

@@ -129,3 +129,50 @@ def test_r1cs_check_finds_the_first_violated_constraint(ctx):
     bad = R.check(co.witness_bytes(w2))
     assert bad is not None and bad <= 700 and not g.R1CS(r1.num_inputs, r1.num_aux, [r1.constraints[bad]]).is_satisfied(w2)
     assert all(g.R1CS(r1.num_inputs, r1.num_aux, [c]).is_satisfied(w2) for c in r1.constraints[:bad])
+
+
+def test_za2c_cycle_at_a_2p20_domain(ctx, tmp_path):
+    """The outer boundary at size (it had only ever run at 2^0 / 2^7 domains): setup -> prove -> verify through
+    the four C symbols on the 2^20 config-4 recipe written as the files za leaves on disk; prove() reads the key
+    checked = true (device validation), checks the constraints, proves one-shot, self-verifies."""
+    import za_amd
+    from oracle import bn254 as bn
+    from za_amd import synth
+    sr = synth.SynthR1CS(20, 2, 0.97, 0x5A)
+    R = sr.load(ctx)
+    P, pbytes = ctx.setup(R, 0x1f3a, 0x2b4c, 0x3d5e, 0x4f60, 0x5172, want_bytes=True)
+    want = ctx.prove(P, R, sr.witness, 5, 7)
+    P.close(); R.close()
+    circuit, pk, bw = str(tmp_path / "circuit.pk"), str(tmp_path / "proving.key"), str(tmp_path / "w.binwitness")
+    sr.write_proving_key(circuit, pbytes)
+    sr.write_binwitness(bw)
+    w1 = int.from_bytes(bytes(sr.witness[32:64]), "little")
+    lib = _za2c()
+    lib.verbose(1)
+    # prove from the container as it stands (the key of the in-process set-up): the public input and an accepted proof
+    rc, proof_json, err = _call_prove(lib, circuit, bw)
+    assert rc == 0, err
+    proof, pub = za_amd.proof_from_json(proof_json)
+    assert pub == [w1] and proof != want                      # fresh r, s
+    assert za_amd.verify(pbytes, proof, [w1]) is True
+    # setup re-keys the container (fresh toxic waste) and returns the verifier; prove + verify with the new key
+    rc, vk_json, err = _call_setup(lib, circuit, pk, "json", cap=1 << 20)
+    assert rc == 0, err
+    rc, proof_json, err = _call_prove(lib, pk, json.dumps({"@binwitness": bw}))
+    assert rc == 0, err
+    assert _call_verify(lib, vk_json, proof_json) == (0, "")
+    assert g.verify_proof(g.vk_from_json(vk_json), *g.proof_from_json(proof_json))     # independent pairing check
+    j = json.loads(proof_json)
+    j["public_inputs"][0] = str(int(j["public_inputs"][0]) ^ 1)
+    assert _call_verify(lib, vk_json, json.dumps(j))[0] == 2
+    # Parameters::read(pk, checked = true) inside prove(): a twist point outside the subgroup deep inside b_g2 -> code 100
+    raw = bytearray(open(pk, "rb").read())
+    at = len(raw) - 128 * 4321
+    raw[at:at + 128] = g.g2_uncompressed(bn.g2_twist_point(11))
+    bad_pk = str(tmp_path / "bad.key")
+    with open(bad_pk, "wb") as f:
+        f.write(raw)
+    rc, _, err = _call_prove(lib, bad_pk, bw)
+    assert rc == 100 and err == 'Io("b_g2: point is not in the correct subgroup")', err
+    lib.verbose(0)
+    sr.close()

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "zg_prove", "zg_prove_dev", "zg_prove_random", "zg_prove_packed", "zg_witness_pack",
     "zg_prove_h_dev", "zg_prove_h_eval_dev", "zg_prove_h_eval_enqueue_dev", "zg_prove_h_eval_enqueue_fold_dev", "zg_params_h_eval_info", "zg_witness_to_device", "zg_prove_h_enqueue_dev", "zg_prove_partials_dev", "zg_prove_partials_ex", "zg_prove_combine", "zg_params_shard_range", "zg_params_query_total",
     "zg_params_prepare", "zg_params_table_info",
-    "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings", "zg_last_stats",
+    "zg_proof_json", "zg_verify", "zg_vk_json", "zg_last_timings", "zg_last_load_timings", "zg_last_stats",
     "zg_vk_from_json", "zg_proof_from_json", "zg_verifier_solidity", "zg_last_error_thread", "zg_r1cs_check",
     "zg_profile_enable", "zg_profile_reset", "zg_profile_get", "zg_profile_get_units", "zg_profile_name",
 ]
@@ -474,6 +474,11 @@ class Context:
         t = (C.c_double * 6)()
         self._check(self.lib.zg_last_timings(self.h, t))
         return dict(zip(("upload_bytes", "r1cs_eval_ms", "h_ms", "msm_ms", "combine_ms", "total_ms"), list(t)))
+
+    def last_load_timings(self):
+        t = (C.c_double * 4)()
+        self._check(self.lib.zg_last_load_timings(self.h, t))
+        return dict(zip(("vk_and_walk_ms", "queries_device_ms", "constraints_ms", "r1cs_load_ms"), list(t)))
 
     def last_stats(self):
         """zg_last_stats: kernel launches of the last zg_prove* call, bit mask of the witness queries that shared a digit sort."""

@@ -21,6 +21,7 @@ struct Ctx {
     int num_cu = 256;
     std::string last_error;
     double timings[6] = {0, 0, 0, 0, 0, 0};
+    double load_timings[4] = {0, 0, 0, 0};   // zg_last_load_timings
     // optional per-kernel timing with HIP events on `stream` (zg_profile_*)
     int prof_enabled = 0;   // 0 off, 1 = the accumulation kernels only (about 5 scopes per proof), 2 = every class
     struct ProfPending { int id; hipEvent_t e0, e1; uint64_t bytes, units; };

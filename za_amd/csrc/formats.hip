@@ -388,28 +388,13 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     if (!rd.u32be(&nc)) return fail(ctx, ZG_E_IO, "pk: truncated constraint count");
     // a constraint takes at least its u32 length prefix + three u64 term counts: bound the allocation by the buffer
     if ((size_t)nc > (len - rd.pos) / 28) return fail(ctx, ZG_E_IO, "pk: %u constraints do not fit the container", nc);
-    struct Term { uint64_t sig; Fr coeff; };
-    std::vector<std::vector<Term>> lcs[3];
-    for (int k = 0; k < 3; k++) lcs[k].resize(nc);
-    uint64_t max_sig = 0;
+    // pass 1: where every constraint lies (its length prefix says), then the ignore list behind them
+    std::vector<size_t> at((size_t)nc + 1);
     for (uint32_t i = 0; i < nc; i++) {
         if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated constraint %u", i);
-        LeReader lr{b, n, 0};
-        for (int k = 0; k < 3; k++) {
-            uint64_t cnt;
-            if (!lr.u64(&cnt) || cnt > n) return fail(ctx, ZG_E_BAD_FORMAT, "pk: bad LC in constraint %u", i);
-            for (uint64_t t = 0; t < cnt; t++) {
-                uint64_t sig, nw;
-                if (!lr.u64(&sig) || !lr.u64(&nw) || nw > 8) return fail(ctx, ZG_E_BAD_FORMAT, "pk: bad term in constraint %u", i);
-                Fr c = Fr::zero();
-                for (uint64_t w = 0; w < nw; w++)
-                    if (!lr.u32(&c.l[w])) return fail(ctx, ZG_E_BAD_FORMAT, "pk: truncated coefficient in constraint %u", i);
-                lcs[k][i].push_back(Term{sig, c});
-                if (sig > max_sig) max_sig = sig;
-            }
-        }
-        if (lr.pos != n) return fail(ctx, ZG_E_BAD_FORMAT, "pk: trailing bytes in constraint %u", i);
+        at[i] = (size_t)(b - pk);
     }
+    at[nc] = rd.pos + 4;   // (constraint i spans [at[i], at[i + 1] - 4): the next one's length prefix lies in between)
     uint32_t ni;
     if (!rd.u32be(&ni)) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
     if ((size_t)ni > (len - rd.pos) / 4) return fail(ctx, ZG_E_IO, "pk: %u ignored signals do not fit the container", ni);
@@ -421,9 +406,6 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     // ignored ids get no variable; main public inputs (ids 1..n_public: the evaluator numbers outputs and public
     // inputs first, compiler/src/evaluator/test.rs:739-768) are inputs; the rest are aux.
     const uint64_t n_signals = 1ull + n_public + n_aux + ni;
-    if (max_sig >= n_signals)
-        return fail(ctx, ZG_E_BAD_FORMAT, "pk: signal id %llu but the key describes %llu signals",
-                    (unsigned long long)max_sig, (unsigned long long)n_signals);
     out->n_inputs = n_public + 1;
     out->n_aux = n_aux;
     out->var_of_signal.assign(n_signals, UINT32_MAX);
@@ -441,23 +423,81 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     }
     if (ig != ignore.size()) return fail(ctx, ZG_E_BAD_FORMAT, "pk: ignore_signals is not sorted / in range");
     if (next_aux != n_aux) return fail(ctx, ZG_E_BAD_FORMAT, "pk: aux count mismatch");
-    for (int k = 0; k < 3; k++) {
-        out->row_ptr[k].assign(1, 0);
-        out->col[k].clear();
-        out->coeff[k].clear();
-        for (uint32_t i = 0; i < nc; i++) {
-            for (const Term& t : lcs[k][i]) {
-                uint32_t v = out->var_of_signal[t.sig];
-                if (v == UINT32_MAX)
-                    return fail(ctx, ZG_E_BAD_FORMAT, "pk: constraint %u uses ignored signal %llu (signal not defined, format.rs:215)",
-                                i, (unsigned long long)t.sig);
-                Fr c = t.coeff;
-                if (k == 2) c = c.to_mont().neg().from_mont();   // bellman gets a*b = -c (prover.rs:98)
-                out->col[k].push_back(v);
-                const uint8_t* cb = reinterpret_cast<const uint8_t*>(&c);
-                out->coeff[k].insert(out->coeff[k].end(), cb, cb + 32);
+    // pass 2: the constraints, in ranges on host threads, straight into CSR pieces that are joined afterwards
+    struct Piece {
+        std::vector<uint32_t> rowlen[3], col[3];
+        std::vector<uint8_t> coeff[3];
+        uint64_t bad_row = UINT64_MAX;   // first constraint of the range that does not parse
+        int bad_code = 0;
+        std::string bad_msg;
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 32u) : 4u;
+    if (nc < 1u << 14) nt = 1;
+    std::vector<Piece> pieces(nt);
+    auto work = [&](unsigned t) {
+        Piece& pc = pieces[t];
+        const uint64_t lo = (uint64_t)nc * t / nt, hi = (uint64_t)nc * (t + 1) / nt;
+        for (int k = 0; k < 3; k++) pc.rowlen[k].reserve(hi - lo);
+        char msg[160];
+        auto bad = [&](uint64_t i, int code, const char* fmt, unsigned long long a1 = 0, unsigned long long a2 = 0) {
+            snprintf(msg, sizeof(msg), fmt, a1, a2);
+            pc.bad_row = i;
+            pc.bad_code = code;
+            pc.bad_msg = msg;
+        };
+        for (uint64_t i = lo; i < hi; i++) {
+            const size_t nbytes = at[i + 1] - 4 - at[i];
+            LeReader lr{pk + at[i], nbytes, 0};
+            for (int k = 0; k < 3; k++) {
+                uint64_t cnt;
+                if (!lr.u64(&cnt) || cnt > nbytes) return bad(i, ZG_E_BAD_FORMAT, "pk: bad LC in constraint %llu", i);
+                for (uint64_t tm = 0; tm < cnt; tm++) {
+                    uint64_t sig, nw;
+                    if (!lr.u64(&sig) || !lr.u64(&nw) || nw > 8) return bad(i, ZG_E_BAD_FORMAT, "pk: bad term in constraint %llu", i);
+                    Fr c = Fr::zero();
+                    for (uint64_t w = 0; w < nw; w++)
+                        if (!lr.u32(&c.l[w])) return bad(i, ZG_E_BAD_FORMAT, "pk: truncated coefficient in constraint %llu", i);
+                    if (sig >= n_signals)
+                        return bad(i, ZG_E_BAD_FORMAT, "pk: signal id %llu but the key describes %llu signals", sig, n_signals);
+                    const uint32_t v = out->var_of_signal[sig];
+                    if (v == UINT32_MAX)
+                        return bad(i, ZG_E_BAD_FORMAT, "pk: constraint %llu uses ignored signal %llu (signal not defined, format.rs:215)", i, sig);
+                    if (k == 2) c = c.to_mont().neg().from_mont();   // bellman gets a*b = -c (prover.rs:98)
+                    pc.col[k].push_back(v);
+                    const uint8_t* cb = reinterpret_cast<const uint8_t*>(&c);
+                    pc.coeff[k].insert(pc.coeff[k].end(), cb, cb + 32);
+                }
+                pc.rowlen[k].push_back((uint32_t)cnt);
             }
-            out->row_ptr[k].push_back(out->col[k].size());
+            if (lr.pos != nbytes) return bad(i, ZG_E_BAD_FORMAT, "pk: trailing bytes in constraint %llu", i);
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (auto& t : th) t.join();
+    }
+    for (const Piece& pc : pieces)   // (ranges are in constraint order: the first piece with an error holds the lowest row)
+        if (pc.bad_row != UINT64_MAX) return fail(ctx, pc.bad_code, "%s", pc.bad_msg.c_str());
+    for (int k = 0; k < 3; k++) {
+        size_t nnz = 0;
+        for (const Piece& pc : pieces) nnz += pc.col[k].size();
+        out->row_ptr[k].assign(1, 0);
+        out->row_ptr[k].reserve((size_t)nc + 1);
+        out->col[k].clear();
+        out->col[k].reserve(nnz);
+        out->coeff[k].clear();
+        out->coeff[k].reserve(nnz * 32);
+        uint64_t run = 0;
+        for (Piece& pc : pieces) {
+            for (uint32_t c : pc.rowlen[k]) out->row_ptr[k].push_back(run += c);
+            out->col[k].insert(out->col[k].end(), pc.col[k].begin(), pc.col[k].end());
+            out->coeff[k].insert(out->coeff[k].end(), pc.coeff[k].begin(), pc.coeff[k].end());
+            std::vector<uint32_t>().swap(pc.col[k]);
+            std::vector<uint8_t>().swap(pc.coeff[k]);
         }
     }
     out->n_constraints = nc;

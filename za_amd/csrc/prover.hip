@@ -956,6 +956,13 @@ extern "C" int zg_last_timings(const zg_ctx* ctx, double ms[6]) try {
 } catch (...) {
     return zg::on_exception(nullptr);
 }
+extern "C" int zg_last_load_timings(const zg_ctx* ctx, double ms[4]) try {
+    if (!ctx || !ms) return ZG_E_INVALID_ARG;
+    for (int i = 0; i < 4; i++) ms[i] = ctx->load_timings[i];
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
 
 // ------------------------------------------------------------------------------------------------ profiling
 extern "C" int zg_profile_enable(zg_ctx* ctx, int on) try {
@@ -1447,13 +1454,17 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     std::unique_ptr<zg_params> pguard(p);
     if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
     PkR1cs pr;
+    double t0 = now_ms();
     ZG_TRY(parse_pk_r1cs(ctx, pk, len, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
+    ctx->load_timings[2] = now_ms() - t0;
     const uint64_t* rp[3] = {pr.row_ptr[0].data(), pr.row_ptr[1].data(), pr.row_ptr[2].data()};
     const uint32_t* cl[3] = {pr.col[0].data(), pr.col[1].data(), pr.col[2].data()};
     const uint8_t* cf[3] = {pr.coeff[0].data(), pr.coeff[1].data(), pr.coeff[2].data()};
     zg_r1cs* r = nullptr;
+    t0 = now_ms();
     ZG_TRY(zg_r1cs_load(ctx, pr.n_inputs, pr.n_aux, pr.n_constraints, rp, cl, cf, &r));
-    r->var_of_signal = pr.var_of_signal;
+    ctx->load_timings[3] = now_ms() - t0;
+    r->var_of_signal = std::move(pr.var_of_signal);
     pguard.release();
     *r1cs_out = r;
     *params_out = p;
@@ -1681,7 +1692,10 @@ static int params_load_impl(zg_ctx* ctx, const uint8_t* body, size_t len, bool c
                             size_t* consumed, ParsedParams* vk_out /* nullable: the parsed vk + ic */) {
     ParsedParams pp;
     KeyQuery kq[5];
+    const double t_start = now_ms();
     ZG_TRY(parse_bellman_header(ctx, body, len, checked, &pp, kq, consumed));
+    ctx->load_timings[0] = now_ms() - t_start;
+    ctx->load_timings[1] = ctx->load_timings[2] = ctx->load_timings[3] = 0;
     std::unique_ptr<zg_params> p(new zg_params());
     p->rank = rank;
     p->world = world;
@@ -1719,6 +1733,7 @@ static int params_load_impl(zg_ctx* ctx, const uint8_t* body, size_t len, bool c
     ZG_HIP(ctx, hipMemcpyAsync(vh, verdict.p, sizeof(vh), hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZG_TRY(key_verdict_to_error(ctx, vh));
+    ctx->load_timings[1] = now_ms() - t_start - ctx->load_timings[0];
     if (want_whole_h) ZG_TRY(params_h_eval_slice(ctx, p.get(), whole_h.as<G1Affine>(), kq[0].n, nullptr));
     if (vk_out) *vk_out = std::move(pp);
     *out = p.release();

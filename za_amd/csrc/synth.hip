@@ -156,6 +156,97 @@ extern "C" const void* zg_synth_ptr(const zg_synth* s, int which) {
     return s->witness.data();
 }
 extern "C" void zg_synth_free(zg_synth* s) { delete s; }
+
+// ---- what `za setup` and the evaluator would leave on disk for a synthetic circuit: the proving.key container
+// (prover/src/groth16/format.rs:223-252) around a Parameters body, and the .binwitness dump
+// (compiler/src/tester/embeeded.rs:47-57, fs.rs:116-126).  Signal id = variable index (ONE, public inputs, aux), no
+// ignored signals, an empty AST vector.  The container stores a*b + c = 0 (constraint.rs:51): C's coefficients are negated.
+namespace {
+struct FileOut {
+    FILE* f;
+    std::vector<uint8_t> buf;
+    explicit FileOut(const char* path) : f(fopen(path, "wb")) { buf.reserve(1 << 22); }
+    ~FileOut() { if (f) fclose(f); }
+    bool flush() {
+        const bool ok = buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+        return ok;
+    }
+    bool put(const void* p, size_t n) {
+        if (buf.size() + n > buf.capacity() && !flush()) return false;
+        if (n > buf.capacity()) return fwrite(p, 1, n, f) == n;
+        buf.insert(buf.end(), (const uint8_t*)p, (const uint8_t*)p + n);
+        return true;
+    }
+    bool u32be(uint32_t v) {
+        const uint8_t b[4] = {(uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v};
+        return put(b, 4);
+    }
+    bool u64le(uint64_t v) { return put(&v, 8); }
+};
+}  // namespace
+extern "C" int zg_synth_pk_container_write(const char* path, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
+                                           const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                                           const uint8_t* const coeff[3], const uint8_t* params, size_t params_len) try {
+    if (!path || !row_ptr || !col || !coeff || !params || n_constraints > 0xffffffffull) return ZG_E_INVALID_ARG;
+    FileOut o(path);
+    if (!o.f) return ZG_E_IO;
+    bool ok = o.u32be(8) && o.u64le(0) && o.u32be((uint32_t)n_constraints);
+    std::vector<uint8_t> q;
+    for (uint64_t i = 0; ok && i < n_constraints; i++) {
+        q.clear();
+        for (int k = 0; k < 3; k++) {
+            const uint64_t e0 = row_ptr[k][i], e1 = row_ptr[k][i + 1], cnt = e1 - e0;
+            q.insert(q.end(), (const uint8_t*)&cnt, (const uint8_t*)&cnt + 8);
+            for (uint64_t e = e0; e < e1; e++) {
+                uint32_t w[8];
+                memcpy(w, coeff[k] + 32 * e, 32);
+                if (k == 2) {   // r - c (c != 0)
+                    uint64_t br = 0;
+                    bool nz = false;
+                    for (int j = 0; j < 8; j++) nz |= w[j] != 0;
+                    if (nz)
+                        for (int j = 0; j < 8; j++) {
+                            const uint64_t d = (uint64_t)FrParams::MOD[j] - w[j] - br;
+                            w[j] = (uint32_t)d;
+                            br = (d >> 32) & 1;
+                        }
+                }
+                uint64_t nw = 8;
+                while (nw && !w[nw - 1]) nw--;
+                const uint64_t sig = col[k][e];
+                q.insert(q.end(), (const uint8_t*)&sig, (const uint8_t*)&sig + 8);
+                q.insert(q.end(), (const uint8_t*)&nw, (const uint8_t*)&nw + 8);
+                q.insert(q.end(), (const uint8_t*)w, (const uint8_t*)w + 4 * nw);
+            }
+        }
+        ok = o.u32be((uint32_t)q.size()) && o.put(q.data(), q.size());
+    }
+    ok = ok && o.u32be(0) && o.flush() && fwrite(params, 1, params_len, o.f) == params_len;
+    (void)n_inputs; (void)n_aux;
+    return ok ? ZG_OK : ZG_E_IO;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
+extern "C" int zg_synth_binwitness_write(const char* path, const uint8_t* witness32, size_t n) try {
+    if (!path || !witness32) return ZG_E_INVALID_ARG;
+    FileOut o(path);
+    if (!o.f) return ZG_E_IO;
+    auto w32 = [&](const uint8_t* le) {   // FS::write_256_w32: 4-byte groups from the least significant, each big-endian
+        uint8_t b[32];
+        for (int g = 0; g < 8; g++)
+            for (int k = 0; k < 4; k++) b[4 * g + (3 - k)] = le[4 * g + k];
+        return o.put(b, 32);
+    };
+    uint8_t cnt[32] = {0};
+    const uint64_t n64 = n;
+    memcpy(cnt, &n64, 8);
+    bool ok = w32(cnt);
+    for (size_t i = 0; ok && i < n; i++) ok = w32(witness32 + 32 * i);
+    return ok && o.flush() ? ZG_OK : ZG_E_IO;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
 extern "C" uint64_t zg_synth_dlog(uint64_t seed, uint64_t i) { return splitmix64_at(seed, i); }
 
 // ------------------------------------------------------------------------------------------------ device generators

@@ -13,7 +13,7 @@ SYNTH_SYMBOLS = ["zg_synth_r1cs_new", "zg_synth_r1cs_info", "zg_synth_ptr", "zg_
                  "zg_synth_bases_g1_dev", "zg_synth_bases_g2_dev", "zg_synth_params_dev", "zg_synth_dlog",
                  "zg_synth_scalars_dev", "zg_params_download", "zg_params_shard",
                  "zg_selftest_field_host", "zg_selftest_field_dev", "zg_selftest_curve_host", "zg_selftest_curve_dev", "zg_params_inspect",
-                 "zg_selftest_pack_mt", "zg_selftest_pack_split"]
+                 "zg_selftest_pack_mt", "zg_selftest_pack_split", "zg_synth_pk_container_write", "zg_synth_binwitness_write"]
 
 MASK64 = (1 << 64) - 1
 
@@ -66,6 +66,25 @@ class SynthR1CS:
 
     def load(self, ctx: Context):
         return ctx.r1cs_load(self.n_inputs, self.n_aux, self.n_constraints, self.row_ptr, self.col, self.coeff)
+
+    def write_proving_key(self, path, params_bytes):
+        """The za proving.key container `za setup` would write for this circuit around the Parameters body `params_bytes`."""
+        pb = np.frombuffer(params_bytes, dtype=np.uint8)
+        rp = (C.c_void_p * 3)(*[a.ctypes.data for a in self.row_ptr])
+        cl = (C.c_void_p * 3)(*[a.ctypes.data if a.size else None for a in self.col])
+        cf = (C.c_void_p * 3)(*[a.ctypes.data if a.size else None for a in self.coeff])
+        rc = self.lib.zg_synth_pk_container_write(str(path).encode(), C.c_uint32(self.n_inputs), C.c_uint32(self.n_aux),
+                                                  C.c_uint64(self.n_constraints), rp, cl, cf, pb.ctypes.data_as(C.c_void_p),
+                                                  C.c_size_t(pb.size))
+        if rc:
+            raise ZaAmdError(rc, "writing %s" % path)
+
+    def write_binwitness(self, path):
+        """The evaluator's .binwitness dump of this circuit's witness."""
+        rc = self.lib.zg_synth_binwitness_write(str(path).encode(), self.witness.ctypes.data_as(C.c_void_p),
+                                                C.c_size_t(self.n_inputs + self.n_aux))
+        if rc:
+            raise ZaAmdError(rc, "writing %s" % path)
 
     def close(self):
         if self.h:
