@@ -1,5 +1,6 @@
 // Wire formats on the za side of the boundary (host only).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,19 @@ int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
 // proof.json (format.rs:80-128)
 int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, std::string* out);
 
+// a host array that is NOT zero-filled when it is sized (the threads that fill it touch it first)
+template <class T>
+struct RawBuf {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t k) {
+        p.reset(new T[k ? k : 1]);
+        n = k;
+    }
+    T* data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+
 // R1CS recovered from a za proving key (format.rs:223-247) in the variable numbering of
 // CircomCircuit::synthesize (prover.rs:45-103)
 struct PkR1cs {
@@ -36,11 +50,17 @@ struct PkR1cs {
     uint64_t n_constraints = 0;
     size_t params_offset = 0;
     std::vector<uint32_t> var_of_signal;   // UINT32_MAX for ignored signals
-    std::vector<uint64_t> row_ptr[3];
-    std::vector<uint32_t> col[3];
-    std::vector<uint8_t> coeff[3];
+    RawBuf<uint64_t> row_ptr[3];
+    RawBuf<uint32_t> col[3];
+    RawBuf<uint8_t> coeff[3];
 };
-int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public, uint32_t n_aux, PkR1cs* out);
+struct PkWalk {                        // where the container's sections lie
+    std::vector<size_t> at;            // constraint i spans [at[i], at[i + 1] - 4)
+    std::vector<uint32_t> ignore;      // ignore_signals
+    size_t params_offset = 0;          // the bellman Parameters body
+};
+int pk_walk(Ctx* ctx, const uint8_t* pk, size_t len, PkWalk* w);
+int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, const PkWalk& walk, uint32_t n_public, uint32_t n_aux, PkR1cs* out);
 int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal, uint32_t n_vars, const uint8_t* bw,
                             size_t len, uint8_t* witness_out);
 

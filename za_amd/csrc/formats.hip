@@ -378,8 +378,9 @@ struct LeReader {
 };
 }  // namespace
 
-int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* |ic| - 1 */, uint32_t n_aux /* |l| */,
-                  PkR1cs* out) {
+// One pass over the container's length prefixes (a chain of dependent loads, ~190 bytes apart: 0.15 s at 2^22
+// constraints -- done once, for the offset of the Parameters body AND for the constraint parser)
+int pk_walk(Ctx* ctx, const uint8_t* pk, size_t len, PkWalk* w) {
     Reader rd{pk, len};
     uint32_t n;
     const uint8_t* b;
@@ -388,20 +389,29 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     if (!rd.u32be(&nc)) return fail(ctx, ZG_E_IO, "pk: truncated constraint count");
     // a constraint takes at least its u32 length prefix + three u64 term counts: bound the allocation by the buffer
     if ((size_t)nc > (len - rd.pos) / 28) return fail(ctx, ZG_E_IO, "pk: %u constraints do not fit the container", nc);
-    // pass 1: where every constraint lies (its length prefix says), then the ignore list behind them
-    std::vector<size_t> at((size_t)nc + 1);
+    w->at.resize((size_t)nc + 1);
     for (uint32_t i = 0; i < nc; i++) {
         if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated constraint %u", i);
-        at[i] = (size_t)(b - pk);
+        w->at[i] = (size_t)(b - pk);
     }
-    at[nc] = rd.pos + 4;   // (constraint i spans [at[i], at[i + 1] - 4): the next one's length prefix lies in between)
+    w->at[nc] = rd.pos + 4;   // (constraint i spans [at[i], at[i + 1] - 4): the next one's length prefix lies in between)
     uint32_t ni;
     if (!rd.u32be(&ni)) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
     if ((size_t)ni > (len - rd.pos) / 4) return fail(ctx, ZG_E_IO, "pk: %u ignored signals do not fit the container", ni);
-    std::vector<uint32_t> ignore(ni);
+    w->ignore.resize(ni);
     for (uint32_t i = 0; i < ni; i++)
-        if (!rd.u32be(&ignore[i])) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
-    out->params_offset = rd.pos;
+        if (!rd.u32be(&w->ignore[i])) return fail(ctx, ZG_E_IO, "pk: truncated ignore list");
+    w->params_offset = rd.pos;
+    return ZG_OK;
+}
+
+int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, const PkWalk& walk, uint32_t n_public /* |ic| - 1 */,
+                  uint32_t n_aux /* |l| */, PkR1cs* out) {
+    (void)len;
+    const std::vector<size_t>& at = walk.at;
+    const std::vector<uint32_t>& ignore = walk.ignore;
+    const uint32_t nc = (uint32_t)(at.size() - 1), ni = (uint32_t)ignore.size();
+    out->params_offset = walk.params_offset;
     // variable numbering of CircomCircuit::synthesize (prover.rs:55-88): ONE, then signal ids in order;
     // ignored ids get no variable; main public inputs (ids 1..n_public: the evaluator numbers outputs and public
     // inputs first, compiler/src/evaluator/test.rs:739-768) are inputs; the rest are aux.
@@ -423,30 +433,34 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
     }
     if (ig != ignore.size()) return fail(ctx, ZG_E_BAD_FORMAT, "pk: ignore_signals is not sorted / in range");
     if (next_aux != n_aux) return fail(ctx, ZG_E_BAD_FORMAT, "pk: aux count mismatch");
-    // pass 2: the constraints, in ranges on host threads, straight into CSR pieces that are joined afterwards
-    struct Piece {
-        std::vector<uint32_t> rowlen[3], col[3];
-        std::vector<uint8_t> coeff[3];
+    // pass 2, in ranges on host threads: every constraint is walked (format checks, signal ids) and its terms counted;
+    // pass 3, same ranges: the terms are written where the counts say -- straight into the final arrays, which are
+    // first touched by the threads that fill them (no zero fill, no joining copy: at 2^22 constraints that is 0.5 GB)
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 32u) : 4u;
+    if (nc < 1u << 14) nt = 1;
+    struct Range {
+        uint64_t lo = 0, hi = 0, terms[3] = {0, 0, 0};
         uint64_t bad_row = UINT64_MAX;   // first constraint of the range that does not parse
         int bad_code = 0;
         std::string bad_msg;
     };
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt ? std::min(nt, 32u) : 4u;
-    if (nc < 1u << 14) nt = 1;
-    std::vector<Piece> pieces(nt);
-    auto work = [&](unsigned t) {
-        Piece& pc = pieces[t];
-        const uint64_t lo = (uint64_t)nc * t / nt, hi = (uint64_t)nc * (t + 1) / nt;
-        for (int k = 0; k < 3; k++) pc.rowlen[k].reserve(hi - lo);
+    std::vector<Range> ranges(nt);
+    for (unsigned t = 0; t < nt; t++) {
+        ranges[t].lo = (uint64_t)nc * t / nt;
+        ranges[t].hi = (uint64_t)nc * (t + 1) / nt;
+    }
+    for (int k = 0; k < 3; k++) out->row_ptr[k].alloc((size_t)nc + 1);
+    auto count = [&](unsigned t) {
+        Range& rg = ranges[t];
         char msg[160];
         auto bad = [&](uint64_t i, int code, const char* fmt, unsigned long long a1 = 0, unsigned long long a2 = 0) {
             snprintf(msg, sizeof(msg), fmt, a1, a2);
-            pc.bad_row = i;
-            pc.bad_code = code;
-            pc.bad_msg = msg;
+            rg.bad_row = i;
+            rg.bad_code = code;
+            rg.bad_msg = msg;
         };
-        for (uint64_t i = lo; i < hi; i++) {
+        for (uint64_t i = rg.lo; i < rg.hi; i++) {
             const size_t nbytes = at[i + 1] - 4 - at[i];
             LeReader lr{pk + at[i], nbytes, 0};
             for (int k = 0; k < 3; k++) {
@@ -455,51 +469,62 @@ int parse_pk_r1cs(Ctx* ctx, const uint8_t* pk, size_t len, uint32_t n_public /* 
                 for (uint64_t tm = 0; tm < cnt; tm++) {
                     uint64_t sig, nw;
                     if (!lr.u64(&sig) || !lr.u64(&nw) || nw > 8) return bad(i, ZG_E_BAD_FORMAT, "pk: bad term in constraint %llu", i);
-                    Fr c = Fr::zero();
-                    for (uint64_t w = 0; w < nw; w++)
-                        if (!lr.u32(&c.l[w])) return bad(i, ZG_E_BAD_FORMAT, "pk: truncated coefficient in constraint %llu", i);
+                    if (lr.pos + 4 * nw > nbytes) return bad(i, ZG_E_BAD_FORMAT, "pk: truncated coefficient in constraint %llu", i);
+                    lr.pos += 4 * nw;
                     if (sig >= n_signals)
                         return bad(i, ZG_E_BAD_FORMAT, "pk: signal id %llu but the key describes %llu signals", sig, n_signals);
-                    const uint32_t v = out->var_of_signal[sig];
-                    if (v == UINT32_MAX)
+                    if (out->var_of_signal[sig] == UINT32_MAX)
                         return bad(i, ZG_E_BAD_FORMAT, "pk: constraint %llu uses ignored signal %llu (signal not defined, format.rs:215)", i, sig);
-                    if (k == 2) c = c.to_mont().neg().from_mont();   // bellman gets a*b = -c (prover.rs:98)
-                    pc.col[k].push_back(v);
-                    const uint8_t* cb = reinterpret_cast<const uint8_t*>(&c);
-                    pc.coeff[k].insert(pc.coeff[k].end(), cb, cb + 32);
                 }
-                pc.rowlen[k].push_back((uint32_t)cnt);
+                rg.terms[k] += cnt;
             }
             if (lr.pos != nbytes) return bad(i, ZG_E_BAD_FORMAT, "pk: trailing bytes in constraint %llu", i);
         }
     };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
-        for (auto& t : th) t.join();
-    }
-    for (const Piece& pc : pieces)   // (ranges are in constraint order: the first piece with an error holds the lowest row)
-        if (pc.bad_row != UINT64_MAX) return fail(ctx, pc.bad_code, "%s", pc.bad_msg.c_str());
-    for (int k = 0; k < 3; k++) {
-        size_t nnz = 0;
-        for (const Piece& pc : pieces) nnz += pc.col[k].size();
-        out->row_ptr[k].assign(1, 0);
-        out->row_ptr[k].reserve((size_t)nc + 1);
-        out->col[k].clear();
-        out->col[k].reserve(nnz);
-        out->coeff[k].clear();
-        out->coeff[k].reserve(nnz * 32);
-        uint64_t run = 0;
-        for (Piece& pc : pieces) {
-            for (uint32_t c : pc.rowlen[k]) out->row_ptr[k].push_back(run += c);
-            out->col[k].insert(out->col[k].end(), pc.col[k].begin(), pc.col[k].end());
-            out->coeff[k].insert(out->coeff[k].end(), pc.coeff[k].begin(), pc.coeff[k].end());
-            std::vector<uint32_t>().swap(pc.col[k]);
-            std::vector<uint8_t>().swap(pc.coeff[k]);
+    uint64_t base[3] = {0, 0, 0};
+    std::vector<uint64_t> first[3];
+    auto fill = [&](unsigned t) {
+        const Range& rg = ranges[t];
+        uint64_t e[3] = {first[0][t], first[1][t], first[2][t]};
+        for (uint64_t i = rg.lo; i < rg.hi; i++) {
+            LeReader lr{pk + at[i], at[i + 1] - 4 - at[i], 0};
+            for (int k = 0; k < 3; k++) {
+                uint64_t cnt = 0;
+                lr.u64(&cnt);
+                for (uint64_t tm = 0; tm < cnt; tm++, e[k]++) {
+                    uint64_t sig = 0, nw = 0;
+                    lr.u64(&sig);
+                    lr.u64(&nw);
+                    Fr c = Fr::zero();
+                    for (uint64_t w = 0; w < nw; w++) lr.u32(&c.l[w]);
+                    if (k == 2) c = c.to_mont().neg().from_mont();   // bellman gets a*b = -c (prover.rs:98)
+                    out->col[k].data()[e[k]] = out->var_of_signal[sig];
+                    memcpy(out->coeff[k].data() + 32 * e[k], &c, 32);
+                }
+                out->row_ptr[k].data()[i + 1] = e[k];
+            }
         }
+    };
+    auto run = [&](auto&& fn) {
+        if (nt == 1) return fn(0u);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, t);
+        for (auto& t : th) t.join();
+    };
+    run(count);
+    for (const Range& rg : ranges)   // (ranges are in constraint order: the first one with an error holds the lowest row)
+        if (rg.bad_row != UINT64_MAX) return fail(ctx, rg.bad_code, "%s", rg.bad_msg.c_str());
+    for (int k = 0; k < 3; k++) {
+        first[k].resize(nt);
+        for (unsigned t = 0; t < nt; t++) {
+            first[k][t] = base[k];
+            base[k] += ranges[t].terms[k];
+        }
+        out->col[k].alloc(base[k]);
+        out->coeff[k].alloc(base[k] * 32);
+        out->row_ptr[k].data()[0] = 0;
     }
+    run(fill);
     out->n_constraints = nc;
     return ZG_OK;
 }

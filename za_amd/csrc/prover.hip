@@ -1443,8 +1443,11 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     if (!ctx || !pk || !r1cs_out || !params_out) return ZG_E_INVALID_ARG;
     *r1cs_out = nullptr;
     *params_out = nullptr;
-    size_t off = 0;
-    if (pk_params_offset(pk, len, &off) != ZG_OK) return fail(ctx, ZG_E_IO, "pk: truncated container header");
+    const double t_walk = now_ms();
+    PkWalk walk;
+    ZG_TRY(pk_walk(ctx, pk, len, &walk));
+    const size_t off = walk.params_offset;
+    const double walk_ms = now_ms() - t_walk;
     // the key itself tells how many public inputs (|ic| - 1) and aux variables (|l|) the circuit has
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     if (world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
@@ -1455,8 +1458,9 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
     PkR1cs pr;
     double t0 = now_ms();
-    ZG_TRY(parse_pk_r1cs(ctx, pk, len, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
+    ZG_TRY(parse_pk_r1cs(ctx, pk, len, walk, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
     ctx->load_timings[2] = now_ms() - t0;
+    ctx->load_timings[0] += walk_ms;
     const uint64_t* rp[3] = {pr.row_ptr[0].data(), pr.row_ptr[1].data(), pr.row_ptr[2].data()};
     const uint32_t* cl[3] = {pr.col[0].data(), pr.col[1].data(), pr.col[2].data()};
     const uint8_t* cf[3] = {pr.coeff[0].data(), pr.coeff[1].data(), pr.coeff[2].data()};

@@ -91,7 +91,7 @@ struct FileBytes {
         }
         struct stat st;
         if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // (pre-faulted: one call instead of a fault per 64 KB)
             if (m != MAP_FAILED) {
                 (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
                 map = m;
