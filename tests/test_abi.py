@@ -38,6 +38,13 @@ def test_library_exports_every_declared_symbol(lib_built):
     out = subprocess.run(["nm", "-D", "--defined-only", za_amd.LIB_PATH], capture_output=True, text=True).stdout
     exported_c = sorted(set(re.findall(r" T (zg_[a-z0-9_]+)$", out, flags=re.M)))
     assert exported_c == decl, sorted(set(exported_c) ^ set(decl))
+    # ... and nothing else: no C++ symbol leaves the library (csrc/libza_amd.map); the one data symbol is the private table
+    # the scaffolding library reaches the internals through (csrc/internal_api.h)
+    others = [ln.split()[-1] for ln in out.splitlines() if ln.strip() and not re.search(r" T zg_[a-z0-9_]+$", ln)]
+    assert others == ["zg_internal_v1"], others
+    from za_amd import build as zb
+    out = subprocess.run(["nm", "-D", "--defined-only", zb.LIB_ZA2C], capture_output=True, text=True).stdout
+    assert sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip()) == ["prove", "setup", "verbose", "verify"]
 
 
 def test_header_compiles_as_plain_c(tmp_path):

@@ -13,7 +13,7 @@ DRIVER = os.path.join(HERE, "za-gpu")           # `za setup|prove` shaped comman
 LIB_SYNTH = os.path.join(HERE, "libza_amd_synth.so")   # synthetic workloads + self-test hooks (include/za_amd_synth.h): NOT the product
 SOURCES = ["msm.hip", "ntt.hip", "heval.hip", "formats.hip", "keyload.hip", "prover.hip", "setup.hip", "pairing.hip", "outer.hip"]
 SYNTH_SOURCES = ["synth.hip"]
-HEADERS = ["verifier_sol.inc", "fp.h", "fd.h", "ec.h", "ecd.h", "nttd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
+HEADERS = ["verifier_sol.inc", "internal_api.h", "fp.h", "fd.h", "ec.h", "ecd.h", "nttd.h", "common.h", "formats.h", "handles.h", os.path.join("..", "..", "include", "za_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result", "-fno-gpu-rdc"]
 
@@ -60,7 +60,9 @@ def build(force=False, verbose=False):
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs if s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # no C++ symbol leaves the library: the C ABI of include/za_amd.h (+ the private table of csrc/internal_api.h)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
+            "-Wl,--version-script=" + os.path.join(CSRC, "libza_amd.map")]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
@@ -76,7 +78,7 @@ def build(force=False, verbose=False):
     za2c_src = os.path.join(CSRC, "za2c.cpp")
     if force or jobs or _stale(LIB_ZA2C, [za2c_src, LIB, os.path.join(HERE, "..", "include", "za_amd.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", LIB_ZA2C, za2c_src, "-L" + HERE, "-lza_amd",
-               "-Wl,-rpath,$ORIGIN"]
+               "-Wl,-rpath,$ORIGIN", "-Wl,--version-script=" + os.path.join(CSRC, "libza2c.map")]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("libza2c build failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -97,6 +97,7 @@ struct Ctx {
 };
 
 int fail(Ctx* ctx, int code, const char* fmt, ...);
+int fail_msg(Ctx* ctx, int code, const char* msg);   // (fail with a finished message: what csrc/internal_api.h hands out)
 // Every extern "C" entry point is a function-try-block ending in `return on_exception(ctx)`: no C++ exception
 // (std::bad_alloc from a container sized by untrusted input, ...) crosses the C boundary.
 int on_exception(Ctx* ctx);

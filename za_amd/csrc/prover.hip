@@ -24,6 +24,7 @@
 #include "common.h"
 #include "formats.h"
 #include "handles.h"
+#include "internal_api.h"
 
 namespace zg {
 
@@ -55,6 +56,8 @@ int on_exception(Ctx* ctx) {
         return fail(ctx, ZG_E_IO, "unexpected exception");
     }
 }
+
+int fail_msg(Ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
 
 static std::atomic<int> g_live_ctx{0};
 int live_contexts() { return g_live_ctx.load(); }
@@ -3384,3 +3387,11 @@ extern "C" int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inp
 } catch (...) {
     return zg::on_exception(nullptr);
 }
+
+// the scaffolding library's way in (csrc/internal_api.h): the one non-function symbol libza_amd.so exports
+#if !defined(__HIP_DEVICE_COMPILE__)   // (host data: the device pass must not emit it)
+extern "C" const zg_internal_api zg_internal_v1 = {
+    zg::fail_msg,           zg::on_exception,           zg::convert_mont_dev,     zg::host_pack_for_test,
+    zg::host_pack_split_for_test, zg::params_h_eval_slice, zg::parse_bellman_params, zg::write_bellman_params,
+};
+#endif

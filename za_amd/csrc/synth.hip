@@ -3,13 +3,50 @@
 // libza_amd.so and reaches its internals through the C++ symbols of common.h.  Stands in for the za compiler's R1CS +
 // witness output and for bellman's generate_random_parameters.
 #include <algorithm>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <vector>
 
 #include "../../include/za_amd_synth.h"
 #include "common.h"
+#include "formats.h"
 #include "handles.h"
+#include "internal_api.h"
+
+// libza_amd.so exports no C++ symbol: the internals this library uses are reached through its private table.  The
+// definitions below give the declarations of common.h / formats.h a body HERE, forwarding to it.
+namespace zg {
+int fail(Ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return zg_internal_v1.fail_msg(ctx, code, buf);
+}
+int on_exception(Ctx* ctx) { return zg_internal_v1.on_exception(ctx); }   // (called inside a handler: the callee rethrows)
+int convert_mont_dev(Ctx* ctx, void* d_elems, size_t n, int which, int dir, hipStream_t st) {
+    return zg_internal_v1.convert_mont_dev(ctx, d_elems, n, which, dir, st);
+}
+int host_pack_for_test(const uint8_t* witness32, size_t nv, int threads, uint8_t* classes, uint32_t* other_index,
+                       uint8_t* others32, size_t* n_others) {
+    return zg_internal_v1.host_pack_for_test(witness32, nv, threads, classes, other_index, others32, n_others);
+}
+int host_pack_split_for_test(const uint8_t* witness32, size_t nv, int threads, int cap_permille, int ready_every, uint8_t* raw_out,
+                             uint8_t* classes, uint32_t* other_index, uint8_t* others32, size_t* n_others, size_t* first) {
+    return zg_internal_v1.host_pack_split_for_test(witness32, nv, threads, cap_permille, ready_every, raw_out, classes, other_index,
+                                                   others32, n_others, first);
+}
+int params_h_eval_slice(Ctx* ctx, const ::zg_params* p, const G1Affine* d_h_full, uint64_t n_h, const G1Affine* d_h_eval_full) {
+    return zg_internal_v1.params_h_eval_slice(ctx, p, d_h_full, n_h, d_h_eval_full);
+}
+int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed) {
+    return zg_internal_v1.parse_bellman_params(ctx, buf, len, checked, out, consumed);
+}
+void write_bellman_params(const ParsedParams& p, std::vector<uint8_t>* out) { zg_internal_v1.write_bellman_params(p, out); }
+}  // namespace zg
 
 using namespace zg;
 
