@@ -91,6 +91,8 @@ struct Ctx {
     // zg_prove_h_eval_enqueue_fold_dev queued a pipeline without C's transforms for this key: the next zg_prove_partials_ex
     // with the l query of the same key takes the folded query over these scalars / class bytes
     const void* fold_armed_key = nullptr;
+    const void* fold_armed_r1cs = nullptr;      // ... for this circuit and this device witness: a partials call that names
+    const void* fold_armed_witness = nullptr;   // another is refused (its class bytes would be rewritten underneath)
     const uint32_t* fold_scalars = nullptr;
     const uint8_t* fold_cls = nullptr;
     bool stats_keep = false;   // zg_prove / zg_prove_packed cleared the counter for the zg_prove_dev they are about to call

@@ -2479,6 +2479,13 @@ static int c_fold_rule(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const 
     std::lock_guard<std::mutex> lock(p->fbw_mu);
     if (p->lc_rule == 0) p->lc_rule = nz <= (unsigned long long)m * 2 ? 1 : -1;
     *fold = p->lc_rule > 0;
+    if (p->lc_rule < 0) {   // six transforms for this key: the folded rows' bases (64 (n_l + 2 m) bytes) and their table go
+        p->lc.release();
+        p->fbw_lc.buf.release();
+        p->fbw_lc.rank.release();
+        p->fbw_lc.state = 0;
+        p->lc_state = -1;
+    }
     return ZG_OK;
 }
 // zg_prove_h_eval_enqueue_dev for a caller that names the key: where the key has the bases of the folded C rows (an
@@ -2511,6 +2518,8 @@ extern "C" int zg_prove_h_eval_enqueue_fold_dev(zg_ctx* ctx, const zg_params* p,
                            fold ? cfb.c_cls : nullptr));
     if (fold) {
         ctx->fold_armed_key = p;
+        ctx->fold_armed_r1cs = r;
+        ctx->fold_armed_witness = d_witness;
         ctx->fold_scalars = cfb.scalars;
         ctx->fold_cls = cfb.cls;
         if (folded) *folded = 1;
@@ -2638,7 +2647,10 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         }
         if (k < 4) d1[k] = d; else d2 = d;
     }
-    if (ctx->opt_share_sort && use[3].n && use[3].n == use[4].n) {
+    // (b_g1 may only ride b_g2's sorted entries when both jobs cover the SAME positions: equal lengths, the same start of the
+    // shard, the same index list and scalars -- true of every key cut by shard_range from equal totals, asserted here)
+    if (ctx->opt_share_sort && use[3].n && use[3].n == use[4].n && p->q[3].lo == p->q[4].lo && use[3].index == use[4].index &&
+        use[3].scalars == use[4].scalars) {
         const auto &t1 = p->fbw[3], &t2 = p->fbw[4];
         const bool tab1 = t1.state == 1 && t1.n == use[3].n, tab2 = t2.state == 1 && t2.n == use[4].n;
         // (mode 1: not for jobs in small-job mode -- their chains of short launches are bound by latency, not by the work of a
@@ -2737,6 +2749,13 @@ extern "C" int zg_prove_partials_ex(zg_ctx* ctx, const zg_params* p, const zg_r1
                                     const void* d_h_shard, unsigned mask, uint8_t partials[ZG_PARTIALS_BYTES]) try {
     // (a pipeline queued by zg_prove_h_eval_enqueue_fold_dev left out C's transforms: the l query of that key carries its rows)
     if (ctx && (mask & 2u) && ctx->fold_armed_key && ctx->fold_armed_key == (const void*)p) {
+        // the armed scalars and class bytes were derived from the witness and circuit of the enqueue call: another witness
+        // here would have its classes rewritten underneath them and a silently wrong l partial
+        if (ctx->fold_armed_r1cs != (const void*)r || ctx->fold_armed_witness != d_witness) {
+            ctx->fold_armed_key = nullptr;
+            return fail(ctx, ZG_E_INVALID_ARG, "zg_prove_partials_ex: the pipeline queued by zg_prove_h_eval_enqueue_fold_dev left C's "
+                                               "rows to the l partial of THAT circuit and witness; this call names another");
+        }
         CFoldBufs cfb;
         cfb.scalars = ctx->fold_scalars;
         cfb.cls = ctx->fold_cls;

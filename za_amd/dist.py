@@ -24,15 +24,20 @@ def shard_range(total, rank, world):
 H_MASK, WITNESS_MASK = 0x01, 0x1e
 
 
-def _merge_partials(h_part, w_part):
+def _merge_partials(h_part, w_part, out=None):
     """h sum from one buffer, l / a / b_g1 / b_g2 from the other (576-byte layout of zg_prove_partials_*)."""
-    out = w_part.clone()
+    if out is None:
+        out = w_part.clone()
+    else:
+        out.copy_(w_part)
     out[:96] = h_part[:96]
     return out
 
 
-def sharded_prove(engine, r, s, group=None, timings=None):
+def sharded_prove(engine, r, s, group=None, timings=None, force_collectives=False):
     """Collective: every rank calls it; rank 0 returns the 256-byte proof, the others None.
+    force_collectives: run the scatter, the all-gather and the form agreement's all-reduce even in a world of one rank
+    (tests/test_gpu_rccl.py: RCCL's first contact with this code does not have to wait for an 8-GPU node).
     timings (optional dict) receives this rank's host wall times in ms: witness_msm, h_wait (rank 0: what is left
     of R1CS evaluation + 7 NTTs after the witness MSMs returned), scatter, h_msm, gather, combine.
 
@@ -47,8 +52,13 @@ def sharded_prove(engine, r, s, group=None, timings=None):
     """
     import time
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    collect = world > 1 or force_collectives
     if hasattr(engine, "agree_h_form"):
-        engine.agree_h_form(group)      # evaluation or coefficient form of H: the same on every rank (once per engine)
+        # evaluation or coefficient form of H: the same on every rank (once per engine)
+        if force_collectives:
+            engine.agree_h_form(group, force=True)
+        else:
+            engine.agree_h_form(group)
     nbytes = engine.h_chunk_entries * 32
     tm = {}
     t0 = time.perf_counter()
@@ -67,9 +77,9 @@ def sharded_prove(engine, r, s, group=None, timings=None):
     else:
         scatter_list = None
     # gloo (CPU tests, or a debugging run of several ranks on one GPU) moves bytes through host memory
-    staged = world > 1 and dist.get_backend(group) == "gloo" and mine.is_cuda
+    staged = collect and dist.get_backend(group) == "gloo" and mine.is_cuda
     t2 = time.perf_counter()
-    if world > 1:
+    if collect:
         if staged:
             host = torch.empty(nbytes, dtype=torch.uint8)
             dist.scatter(host, [t.cpu() for t in scatter_list] if rank == 0 else None, src=0, group=group)
@@ -83,12 +93,20 @@ def sharded_prove(engine, r, s, group=None, timings=None):
         mine = scatter_list[0]
     t3 = time.perf_counter()
     tm["scatter"] = 1e3 * (t3 - t2)
-    part = _merge_partials(engine.partials(mine, H_MASK | getattr(engine, "h_mask_extra", 0)), w_part)
+    # The five sums are finished on the HOST (a Horner pass over c - 1 bit planes per multiexp: DESIGN.md section 5), so
+    # the 576 bytes start in host memory: merged there, then ONE non-blocking copy from a pinned buffer into the device
+    # tensor the all-gather reads (RCCL) -- no synchronisation on this rank between its last multiexp and the collective;
+    # gloo takes the host tensor as it is.
+    h_part = engine.partials(mine, H_MASK | getattr(engine, "h_mask_extra", 0))
     t4 = time.perf_counter()
     tm["h_msm"] = 1e3 * (t4 - t3)
-    if world > 1:
+    if collect and dist.get_backend(group) != "gloo" and hasattr(engine, "partials_to_device"):
+        part = engine.partials_to_device(_merge_partials(h_part.cpu(), w_part.cpu(), out=engine.partials_pinned()))
+    else:
+        part = _merge_partials(h_part, w_part)
         if staged:
             part = part.cpu()
+    if collect:
         gathered = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(gathered, part, group=group)
     else:
@@ -139,10 +157,10 @@ class GpuEngine:
             self.h_chunk_entries = (self.n_h_total + self.world - 1) // self.world
             self.h_mask_extra = 0
 
-    def agree_h_form(self, group=None):
+    def agree_h_form(self, group=None, force=False):
         if self._agreed:
             return
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
             t = torch.tensor([1 if self.h_eval else 0], dtype=torch.int32,
                              device=self.device if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
@@ -173,9 +191,20 @@ class GpuEngine:
         return self._h_all[: self.world * self.h_chunk_entries * 32]
 
     def partials(self, h_shard, mask):
+        """The five partial sums of this rank's shards (576 bytes) as a HOST tensor: the library finishes them on the host."""
         ptr = 0 if h_shard is None else h_shard.data_ptr()
         out = self.ctx.prove_partials_dev(self.params, self.r1cs, self.d_witness, ptr, mask)
-        return torch.from_numpy(out).to(self.device)
+        return torch.from_numpy(out)
+
+    def partials_pinned(self):
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = torch.empty(576, dtype=torch.uint8).pin_memory()
+            self._part_dev = torch.empty(576, dtype=torch.uint8, device=self.device)
+        return self._pinned
+
+    def partials_to_device(self, pinned):
+        self._part_dev.copy_(pinned, non_blocking=True)    # queued on torch's stream, in front of the collective
+        return self._part_dev
 
     def combine(self, partials_all, world, r, s):
         return self.ctx.prove_combine(self.params, np.ascontiguousarray(partials_all), world, r, s)
