@@ -135,8 +135,12 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          per row on average, rows equal to 2 not counted; decided once per key, with its tables), zg_prove*
  *                          transform a and b only -- FOUR transforms instead of six -- and the C term enters as 2 m more
  *                          points of the l multiexp (a second transformed basis and its doubles, built once per key), for
- *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^26 rows; 2 = for every such key
- *                          whatever its witness and size (tests); 0 = six transforms.  The proof is the same group element
+ *                          domains of 2^ZG_OPT_C_FOLD_MIN_LOG_M (default 20) to 2^26 rows -- and EVERY proof of such a key
+ *                          is checked on the device: the evaluator counts the digits of this witness's rows and a proof
+ *                          whose rows hold field elements runs six transforms, its rows struck from the l multiexp (no host
+ *                          round trip: 2^22, a dense witness through a key folded by a bit witness 34.5 -> 29.8 ms, six
+ *                          transforms 29.6; the guard costs a bit witness 0.05 ms); 2 = for every such key whatever its
+ *                          witness and size, unguarded (tests); 0 = six transforms.  The proof is the same group element
  *                          either way; of the phase API only zg_prove_h_eval_enqueue_fold_dev folds.  Measured (config-4 shape, one box, alternated):
  *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */
 #define ZG_OPT_C_FOLD 22
@@ -355,7 +359,10 @@ int zg_prove_h_eval_enqueue_dev(zg_ctx* ctx, const zg_r1cs* r1cs, const void* d_
  * C's two as well (ZG_OPT_C_FOLD): where `params` has the bases of the folded C rows -- rank 0's shard of a sharded key gets
  * them in zg_params_load, an unsharded key on first use; decided from the rows' values as in zg_prove -- the pipeline runs
  * FOUR transforms, d_e_out receives a b / Z instead of (a b - c) / Z, and the next zg_prove_partials_ex on this context with
- * this key and the l query in its mask adds the multiexp of the rows' values to its l partial (*folded = 1).  The other
+ * this key and the l query in its mask adds the multiexp of the rows' values to its l partial (*folded = 1: the rows are
+ * ARMED -- with ZG_OPT_C_FOLD = 1 the device decides per proof, from the digits this witness's rows evaluate to, whether the
+ * C term travels in the l partial (four transforms) or stays in the scattered scalars (six; the rows are then struck from the
+ * l multiexp); zg_last_stats[3] after that partials call says which.  Either way the sum of the partials is the same).  The other
  * ranks do what they did: their h shards multiply whatever scalars they are sent.  Any other key: *folded = 0 and
  * exactly zg_prove_h_eval_enqueue_dev.  The sum of all ranks' partials is the same group element either way.
  * (What it costs rank 0 when its shard is loaded: a second group transform of the h query and 128 m bytes, whether or not

@@ -1355,6 +1355,61 @@ def test_c_rows_folded_into_the_l_multiexp(ctx, opts, lg, bitf, n_in):
     sr.close()
 
 
+@pytest.mark.parametrize("lg", [12, 16, 20])
+def test_the_fold_is_decided_per_proof_on_the_device(ctx, opts, lg):
+    """VERDICT r5 / ADVICE r5: a key folds its C rows because the FIRST witness it saw had rows of bits; a later witness whose
+    rows hold field elements must not send m dense scalars into the l multiexp.  With ZG_OPT_C_FOLD = 1 every proof's rows
+    are counted by the evaluator and k_fold_decide takes four or six transforms for THAT proof on the device (the rows'
+    values are struck from the l multiexp when it is six): a bits / dense / bits / dense sequence through one key, host and
+    device witnesses and the phase API, against the C oracle's bytes, with zg_last_stats saying which form ran.  Mode 2
+    keeps every proof folded."""
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, 2, 0.97, 4242 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    sizes = (m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    nv = sr.n_inputs + sr.n_aux
+    rng = np.random.default_rng(99 + lg)
+    dense = rng.integers(0, 256, size=32 * nv, dtype=np.uint8)
+    dense[31::32] = 0                                        # < 2^248: canonical
+    dense[:32] = 0
+    dense[0] = 1                                             # variable 0 is ONE
+    bits = np.array(sr.witness, copy=True)
+    r, s = 0x5151 + lg, 0x6262 + lg
+    opts(za_amd.OPT_C_FOLD_MIN_LOG_M, 10)
+    opts(za_amd.OPT_C_FOLD, 1)
+    P = synth.synth_params(ctx, *sizes, 170 + lg)
+    pk = download_params(ctx, P)
+    exp = {"bits": co.prove(pk, csr, bits, r, s, threads=16), "dense": co.prove(pk, csr, dense, r, s, threads=16)}
+    wit = {"bits": bits, "dense": dense}
+    for name in ("bits", "dense", "bits", "dense", "dense", "bits"):
+        assert ctx.prove(P, R, wit[name], r, s) == exp[name], name
+        assert ctx.last_stats()["c_folded"] == (name == "bits"), name
+    for name in ("dense", "bits"):
+        d_w = ctx.upload(wit[name])
+        assert ctx.prove_dev(P, R, d_w, r, s) == exp[name]
+        assert ctx.last_stats()["c_folded"] == (name == "bits")
+        # the phase API: the pipeline is queued with the rows armed; which form ran is known after the partials
+        d_e = ctx.alloc(32 * m)
+        armed = ctx.prove_h_eval_enqueue_fold_dev(P, R, d_w, d_e)
+        assert armed
+        w0 = ctx.prove_partials_dev(P, R, d_w, 0, mask=0x1e)
+        assert ctx.last_stats()["c_folded"] == (name == "bits")
+        ctx.sync()
+        hp = ctx.prove_partials_dev(P, R, d_w, d_e, mask=0x01 | za_amd.ZG_MASK_H_EVAL)
+        part = np.array(w0, copy=True)
+        part[:96] = hp[:96]
+        assert ctx.prove_combine(P, part, 1, r, s) == exp[name]
+        ctx.free(d_e); ctx.free(d_w)
+    opts(za_amd.OPT_C_FOLD, 2)                               # forced: no guard, the dense rows go through the l multiexp
+    assert ctx.prove(P, R, dense, r, s) == exp["dense"] and ctx.last_stats()["c_folded"]
+    opts(za_amd.OPT_C_FOLD, 0)
+    assert ctx.prove(P, R, bits, r, s) == exp["bits"] and not ctx.last_stats()["c_folded"]
+    P.close()
+    sr.close()
+
+
 @pytest.mark.parametrize("lg,bitf", [(13, 0.97), (12, 0.0)])
 def test_sharded_phases_with_the_c_rows_folded_on_rank_0(ctx, opts, lg, bitf):
     """zg_prove_h_eval_enqueue_fold_dev: the rank that runs the transforms of a sharded proof drops C's two as well -- its

@@ -88,6 +88,7 @@ struct Ctx {
     unsigned last_share_mask = 0;
     bool last_follow_g2 = false;
     bool last_c_fold = false;
+    bool fold_guarded = false;   // the pipeline queued last left the fold to k_fold_decide (prover.hip)
     // zg_prove_h_eval_enqueue_fold_dev queued a pipeline without C's transforms for this key: the next zg_prove_partials_ex
     // with the l query of the same key takes the folded query over these scalars / class bytes
     const void* fold_armed_key = nullptr;
@@ -279,7 +280,8 @@ int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 int h_poly_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_h_out);
 // H in evaluation form: d_e_out[p] = ((A B - C) / Z)(g omega^bitrev(p)) as plain integers, m of them -- the scalars of
 // a key's h_eval bases (heval.hip).  Six transforms in 4 L - 3 launches.  a, b, c as for h_poly_dev; clobbered.
-int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit = 0, const hipEvent_t* ev_split = nullptr);
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit = 0, const hipEvent_t* ev_split = nullptr,
+               const uint32_t* d_skip_c = nullptr);
 struct FrLimbs;
 int ntt_tables_for_heval(Ctx* ctx, uint32_t log_m, const FrLimbs** tw_inv, const Fr** gi_lo, const Fr** gi_hi_int, int* lo_bits,
                          Fr* cfold_int = nullptr);

@@ -207,13 +207,24 @@ struct BlockSync {
     __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
+// Which of a launch's vectors is c, and the device word that says whether THIS proof transforms it: the folded form (C rows
+// as scalars of the l multiexp, prover.hip ensure_c_fold) is decided per proof ON THE DEVICE from the digits its rows
+// evaluate to (k_fold_decide), after the launches are queued -- so c's passes are always queued and leave at once when the
+// word says "folded", and the last kernel takes the two- or three-vector form by it.  flag == NULL: no guard.
+struct SkipC {
+    const uint32_t* flag = nullptr;   // *flag != 0: the C rows are folded, c is not transformed
+    int y = -1;                       // blockIdx.y of c in this launch (-1: c is not in it)
+    __device__ __forceinline__ bool drops(uint32_t by) const { return flag && (int)by == y && *flag != 0u; }
+};
+
 // (data1, data2: two more vectors for the workgroups with blockIdx.y = 1, 2 -- the a, b, c of a small proof's H pipeline as ONE
 // launch per pass: their passes are chains of short launches, and three vectors one after the other make the chain three
 // times as long)
 template <bool DIT>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data0, const FrLimbs* __restrict__ tw, int log_m, int s_lo,
                                                   int k, int j, int contiguous, PassFuse fz, Fr* __restrict__ data1,
-                                                  Fr* __restrict__ data2) {
+                                                  Fr* __restrict__ data2, SkipC skip) {
+    if (skip.drops(blockIdx.y)) return;   // (c's transforms of a proof whose C rows went into the l multiexp: SkipC)
     Fr* __restrict__ data = blockIdx.y == 0 ? data0 : blockIdx.y == 1 ? data1 : data2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
@@ -273,7 +284,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(Fr* __restrict__ data0
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_mid(Fr* __restrict__ data0, const FrLimbs* __restrict__ tw_inv,
                                                          const FrLimbs* __restrict__ tw_fwd, int log_m, int s_lo, int k, int j,
                                                          int contiguous, const Fr* __restrict__ hi, const Fr* __restrict__ lo,
-                                                         int lo_bits, Fr* __restrict__ data1, Fr* __restrict__ data2) {
+                                                         int lo_bits, Fr* __restrict__ data1, Fr* __restrict__ data2, SkipC skip) {
+    if (skip.drops(blockIdx.y)) return;
     Fr* __restrict__ data = blockIdx.y == 0 ? data0 : blockIdx.y == 1 ? data1 : data2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
@@ -310,10 +322,11 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_mid(Fr* __restrict__ data0,
 // A thread parks its results of c and b in its own elements of those vectors (scratch by then; the same thread reads
 // them back, so no barrier) -- holding them in registers instead was tried: 174 VGPRs, two workgroups per CU.
 __global__ void __launch_bounds__(NTT_THREADS, 4) k_ntt_tail3(const Fr* __restrict__ a, Fr* __restrict__ b,
-                                                           Fr* __restrict__ c, const FrLimbs* __restrict__ tw_fwd,
+                                                           Fr* __restrict__ c_in, const FrLimbs* __restrict__ tw_fwd,
                                                            const FrLimbs* __restrict__ tw_inv, int log_m, int k, int j, int full,
                                                            const Fr* __restrict__ hi, const Fr* __restrict__ lo, int lo_bits,
-                                                           Fr zinv_int, Fr* __restrict__ out, uint32_t tile0) {
+                                                           Fr zinv_int, Fr* __restrict__ out, uint32_t tile0, const uint32_t* skip_c) {
+    Fr* __restrict__ c = skip_c && *skip_c != 0u ? nullptr : c_in;   // (SkipC: this proof's C rows are in its l multiexp)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsTile T{reinterpret_cast<uint32_t*>(smem)};
     const TileGeom G = TileGeom::make(log_m, 0, k, j, 1, (size_t)blockIdx.x + tile0);
@@ -480,7 +493,7 @@ static int run_passes(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, const 
         size_t lds_bytes = (size_t)36 << (k + j);   // 9 u32 limbs per element
         ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)64 << log_m, nullptr, ((uint64_t)k << log_m) >> 1);  // units: butterflies
         ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles), dim3(NTT_THREADS), lds_bytes, ctx->stream, d, tw, (int)log_m,
-                           s_lo, k, j, contiguous, fz, (Fr*)nullptr, (Fr*)nullptr);
+                           s_lo, k, j, contiguous, fz, (Fr*)nullptr, (Fr*)nullptr, SkipC{});
         ZG_HIP(ctx, hipGetLastError());
     }
     return ZG_OK;
@@ -634,14 +647,15 @@ static void pass_geometry(uint32_t log_m, int s_lo, int k, int* j, int* contiguo
     if (*j < 0) *j = 0;
 }
 template <bool DIT>
-static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int s_lo, int k, Fr* d1 = nullptr, Fr* d2 = nullptr) {
+static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int s_lo, int k, Fr* d1 = nullptr, Fr* d2 = nullptr,
+                        SkipC skip = SkipC{}) {
     int j, contiguous;
     pass_geometry(log_m, s_lo, k, &j, &contiguous);
     const size_t tiles = ((size_t)1 << log_m) >> (k + j);
     const unsigned nv = d2 ? 3u : d1 ? 2u : 1u;   // (one vector, or a, b (, c) together)
     ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)nv * 64 << log_m, nullptr, ((uint64_t)nv * k << log_m) >> 1);
     ZG_LAUNCH(ctx, (k_ntt_pass<DIT>), dim3((unsigned)tiles, nv), dim3(NTT_THREADS), (size_t)36 << (k + j), ctx->stream, d, tw,
-                       (int)log_m, s_lo, k, j, contiguous, no_fuse(), d1, d2);
+                       (int)log_m, s_lo, k, j, contiguous, no_fuse(), d1, d2, skip);
     ZG_HIP(ctx, hipGetLastError());
     return ZG_OK;
 }
@@ -656,7 +670,11 @@ static int run_one_pass(Ctx* ctx, Fr* d, const FrLimbs* tw, uint32_t log_m, int 
 // nsplit > 0: the last kernel runs in nsplit launches over consecutive ranges of e -- range k covers the positions
 // below min(m, (k + 1) * ceil(m / nsplit)) -- with ev_split[k] recorded behind launch k: part k of the h multiexp starts
 // its digit sort while the rest of e is still being computed.
-int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit, const hipEvent_t* ev_split) {
+// d_skip_c (with d_c): a device word written before these launches run (prover.hip k_fold_decide): non-zero = this proof's
+// C rows are folded -- c's passes leave at once and the last kernel takes the two-vector form; zero = six transforms.
+int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out, int nsplit, const hipEvent_t* ev_split,
+               const uint32_t* d_skip_c) {
+    if (!d_c) d_skip_c = nullptr;
     NttTables* T;
     ZG_TRY(get_tables(ctx, log_m, &T));
     if (log_m == 0) return fail(ctx, ZG_E_INVALID_ARG, "H needs a domain of at least 2 rows");
@@ -668,7 +686,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
         const uint64_t nt = d_c ? 6 : 4;
         ProfScope ps(ctx, PROF_NTT_PASS, nt * 64 << log_m, nullptr, (nt * log_m << log_m) >> 1);
         ZG_LAUNCH(ctx, k_ntt_tail3, dim3(1), dim3(NTT_THREADS), (size_t)36 << log_m, ctx->stream, d_a, d_b, d_c, twf, twi,
-                           (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out, 0u);
+                           (int)log_m, (int)log_m, 0, 1, hi, lo, T->lo_bits, T->zinv_int, d_e_out, 0u, d_skip_c);
         for (int k = 0; k < nsplit; k++) ZG_HIP(ctx, hipEventRecord(ev_split[k], ctx->stream));
         ZG_HIP(ctx, hipGetLastError());
         return ZG_OK;
@@ -685,17 +703,22 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
     for (int q = 0; q < (together ? 1 : n_vec); q++) {
         Fr *v1 = together ? v[1] : nullptr, *v2 = together ? v[2] : nullptr;   // (v[2] == NULL: a and b only)
         const unsigned nv = together ? (unsigned)n_vec : 1u;
-        for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p], v1, v2));
+        SkipC skip;   // where c is in these launches: blockIdx.y = 2 of a joint launch, 0 of its own
+        if (d_skip_c && (together || q == 2)) {
+            skip.flag = d_skip_c;
+            skip.y = together ? 2 : 0;
+        }
+        for (int p = 0; p + 1 < L; p++) ZG_TRY(run_one_pass<true>(ctx, v[q], twi, log_m, P.s_lo[p], P.k[p], v1, v2, skip));
         {
             int j, contiguous;
             pass_geometry(log_m, P.s_lo[L - 1], P.k[L - 1], &j, &contiguous);
             const size_t tiles = m >> (P.k[L - 1] + j);
             ProfScope ps(ctx, PROF_NTT_PASS, (uint64_t)nv * 64 << log_m, nullptr, ((uint64_t)nv * 2 * P.k[L - 1] << log_m) >> 1);
             ZG_LAUNCH(ctx, k_ntt_mid, dim3((unsigned)tiles, nv), dim3(NTT_THREADS), (size_t)36 << (P.k[L - 1] + j), ctx->stream,
-                               v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits, v1, v2);
+                               v[q], twi, twf, (int)log_m, P.s_lo[L - 1], P.k[L - 1], j, contiguous, hi, lo, T->lo_bits, v1, v2, skip);
             ZG_HIP(ctx, hipGetLastError());
         }
-        for (int p = L - 2; p >= 1; p--) ZG_TRY(run_one_pass<false>(ctx, v[q], twf, log_m, P.s_lo[p], P.k[p], v1, v2));
+        for (int p = L - 2; p >= 1; p--) ZG_TRY(run_one_pass<false>(ctx, v[q], twf, log_m, P.s_lo[p], P.k[p], v1, v2, skip));
     }
     {
         int j, contiguous;
@@ -711,7 +734,7 @@ int h_eval_dev(Ctx* ctx, Fr* d_a, Fr* d_b, Fr* d_c, uint32_t log_m, Fr* d_e_out,
             if (t1 > t0)
                 ZG_LAUNCH(ctx, k_ntt_tail3, dim3((unsigned)(t1 - t0)), dim3(NTT_THREADS), (size_t)36 << (P.k[0] + j), ctx->stream,
                                    d_a, d_b, d_c, twf, twi, (int)log_m, P.k[0], j, 0, hi, lo, T->lo_bits, T->zinv_int, d_e_out,
-                                   (uint32_t)t0);
+                                   (uint32_t)t0, d_skip_c);
             if (nsplit > 0) ZG_HIP(ctx, hipEventRecord(ev_split[q], ctx->stream));
             t0 = std::max(t0, t1);
         }

@@ -188,6 +188,25 @@ __global__ void __launch_bounds__(256) k_count_digits16(const Fr* __restrict__ v
     if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)part[0] + part[1] + part[2] + part[3]);
 }
 
+// The per-proof guard of the folded form (ZG_OPT_C_FOLD = 1).  A key folds its C rows because the FIRST witness it saw had
+// rows of bits and small integers; a later witness whose rows hold field elements would send m dense scalars into the l
+// multiexp (Poseidon's shape forced: 7.5 -> 8.4 ms at 2^20).  The evaluator has summed the non-zero 16-bit digits of this
+// witness's rows (R1csMats::c_digits) and written them in both forms; this kernel takes the key's own rule -- at most two
+// digits per row -- for THIS proof: *flag = 1: folded (c's transform passes, already queued, leave at once: ntt.hip
+// SkipC); *flag = 0: six transforms, and the rows' values are struck from the l multiexp (class 0 = a zero scalar, which no
+// pass of the multiexp reads).  No host round trip: the launches behind it are queued before it runs.
+__global__ void __launch_bounds__(256) k_fold_decide(const unsigned long long* __restrict__ digits, unsigned long long limit,
+                                                     uint32_t* __restrict__ flag, Fr* __restrict__ c_nat, uint8_t* __restrict__ c_cls,
+                                                     size_t n2) {
+    const bool fold = *digits <= limit;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = fold ? 1u : 0u;
+    if (fold) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        c_cls[i] = 0;
+        c_nat[i] = Fr::zero();
+    }
+}
+
 // first row with a*b != c (mod r): atomicMin over the row index
 __global__ void __launch_bounds__(256) k_r1cs_check(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c,
                                                     uint64_t n_rows, unsigned long long* __restrict__ first_bad) {
@@ -569,7 +588,17 @@ struct R1csMats {
     // bases, heval.hip)
     Fr* c_nat = nullptr;
     uint8_t* c_cls = nullptr;
+    // The per-proof guard of the folded form (k_fold_decide): with c_digits the rows are ALSO written as out[2] (what c's
+    // transforms would read) and the non-zero 16-bit digits of their values are summed into *c_digits -- what their
+    // multiexp costs in additions; the decision "folded or six transforms" is then taken on the device, for this witness.
+    unsigned long long* c_digits = nullptr;
 };
+__device__ __forceinline__ uint32_t digits16(const Fr& x) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) cnt += ((x.l[q] & 0xffffu) != 0) + ((x.l[q] >> 16) != 0);
+    return cnt;
+}
 __device__ __forceinline__ void store_folded_c(Fr* __restrict__ c_nat, uint8_t* __restrict__ c_cls, uint64_t row, uint64_t m, Fr cv) {
     const bool small = (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0 && cv.l[0] <= 2;
     const bool two = small && cv.l[0] == 2;
@@ -643,7 +672,17 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* _
         Fr cv;
         acc.reduce().from_mont().store(&cv);
         store_folded_c(M.c_nat, M.c_cls, row, (uint64_t)1 << log_m, cv);
-        return;
+        if (!M.c_digits) return;
+        // guarded: count the digits (a row equal to 2 is a one on the doubled bases: no digit) and write the row for the
+        // transforms as well
+        const bool two = cv.l[0] == 2 && (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0;
+        uint32_t cnt = two ? 0u : digits16(cv);
+        __shared__ uint32_t part[4];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+        if ((t & 63) == 0) part[t >> 6] = cnt;
+        __syncthreads();
+        if (t == 0 && (part[0] | part[1] | part[2] | part[3])) atomicAdd(M.c_digits, (unsigned long long)part[0] + part[1] + part[2] + part[3]);
     }
     acc.reduce().store(&tile[t]);
     __syncthreads();
@@ -661,7 +700,7 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
                                                         const Fr* __restrict__ coeff, const uint8_t* __restrict__ ccls,
                                                         const Fr* __restrict__ w, const uint8_t* __restrict__ wcls,
                                                         Fr* __restrict__ out, int log_m, Fr* __restrict__ c_nat,
-                                                        uint8_t* __restrict__ c_cls) {
+                                                        uint8_t* __restrict__ c_cls, unsigned long long* __restrict__ c_digits) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= n_long) return;
     const uint64_t row = rows[wave];
@@ -718,7 +757,13 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
         Fr cv;
         acc.from_mont().store(&cv);
         store_folded_c(c_nat, c_cls, row, (uint64_t)1 << log_m, cv);
-    } else if (lane == 0) {
+        if (c_digits) {   // (R1csMats::c_digits: the tiled kernel counted this row as zero)
+            const bool two = cv.l[0] == 2 && (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0;
+            const uint32_t cnt = two ? 0u : digits16(cv);
+            if (cnt) atomicAdd(c_digits, (unsigned long long)cnt);
+        }
+    }
+    if (lane == 0 && (!c_nat || c_digits)) {
         // the tiled kernel's destination: row = (ta, mid, tb) -> (ta, bitrev(mid), tb) with ta / tb swapped and reversed
         const uint32_t ta = (uint32_t)(row >> (log_m - 4)), tb = (uint32_t)(row & 15);
         const uint32_t mid = (uint32_t)((row >> 4) & (((uint64_t)1 << (log_m - 8)) - 1));
@@ -1504,11 +1549,15 @@ static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   /
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     ZG_HIP(ctx, ws.wcls.reserve(nv + ((size_t)2 << r->log_m)));   // (behind the witness: the classes of the C rows' values, c_fold_buffers)
     if (!ws.bad_host) {
-        ZG_HIP(ctx, ws.bad.reserve(8));
-        ZG_HIP(ctx, hipHostMalloc((void**)&ws.bad_host, 8, hipHostMallocDefault));
+        // [0, 8) the validation words; [8, 16) the digit sum of the C rows and [16, 20) the fold flag of the proof in flight
+        // (k_fold_decide); host: the two validation words, then the flag of the last guarded proof
+        ZG_HIP(ctx, ws.bad.reserve(32));
+        ZG_HIP(ctx, hipHostMalloc((void**)&ws.bad_host, 16, hipHostMallocDefault));
+        ws.bad_host[2] = 0;
         ZG_HIP(ctx, hipEventCreateWithFlags(&ws.bad_ev, hipEventDisableTiming));
     }
     ZG_HIP(ctx, hipMemsetAsync(ws.bad.p, 0xff, 8, ctx->stream));   // "nothing wrong" = all ones in both words
+    ZG_HIP(ctx, hipMemsetAsync((uint8_t*)ws.bad.p + 8, 0, 16, ctx->stream));
     ZG_LAUNCH(ctx, k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
                        ws.wcls.as<uint8_t>(), ws.bad.as<uint32_t>());
     ZG_HIP(ctx, hipGetLastError());
@@ -1535,8 +1584,9 @@ static int witness_verdict(zg_ctx* ctx) {
 // d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
 // stored at index bitrev(i) (what h_poly_dev consumes)
 // c_nat / c_cls (both or neither; needs the tiled path: bitrev, log_m >= 8, at least one constraint): see R1csMats
+// c_digits (with c_nat; needs d_abc[2] too): the guarded form -- the C rows in both forms and their digit sum (R1csMats::c_digits)
 static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev, Fr* c_nat = nullptr,
-                         uint8_t* c_cls = nullptr) {
+                         uint8_t* c_cls = nullptr, unsigned long long* c_digits = nullptr) {
     const size_t m = (size_t)1 << r->log_m;
     hipStream_t st = ctx->stream;
     const int rev_bits = bitrev ? (int)r->log_m : 0;
@@ -1557,6 +1607,7 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
         }
         M.c_nat = c_nat;
         M.c_cls = c_cls;
+        M.c_digits = c_nat && d_abc[2] ? c_digits : nullptr;
         ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8), 3), dim3(256), 0, st, M, d_w, ws.wcls.as<uint8_t>(),
                            r->n_constraints, (int)r->log_m);
         for (int k = 0; k < 3; k++)
@@ -1565,7 +1616,7 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
                                    r->long_rows[k].as<uint32_t>(), r->n_long[k], r->row_ptr[k].as<uint64_t>(),
                                    r->col[k].as<uint32_t>(), r->coeff[k].as<Fr>(), r->ccls[k].as<uint8_t>(), d_w,
                                    ws.wcls.as<uint8_t>(), d_abc[k], (int)r->log_m, k == 2 ? c_nat : nullptr,
-                                   k == 2 ? c_cls : nullptr);
+                                   k == 2 ? c_cls : nullptr, k == 2 ? M.c_digits : nullptr);
         ZG_LAUNCH(ctx, k_input_rows, dim3((r->n_inputs + 255) / 256), dim3(256), 0, st, d_w, r->n_inputs,
                            r->n_constraints, d_abc[0], rev_bits);
         ZG_HIP(ctx, hipGetLastError());
@@ -1811,13 +1862,16 @@ static int gate_events(zg_ctx* ctx) {
 // queue R1CS evaluation + the H pipeline on ctx->stream without waiting for it
 // c_nat / c_cls (evaluation form only): the C rows' values leave as multiexp scalars (R1csMats::c_nat) and the pipeline
 // transforms a and b only (h_eval_dev with d_c == NULL)
+// guard (with c_nat): whether THIS proof runs folded is decided on the device from its rows' digits (k_fold_decide); without
+// it the rows are folded whatever they hold (ZG_OPT_C_FOLD = 2, and the builders of the folded query's table)
 static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out, hipEvent_t ev_eval_done = nullptr,
-                           bool eval_form = false, int h_split = 0, Fr* c_nat = nullptr, uint8_t* c_cls = nullptr) {
+                           bool eval_form = false, int h_split = 0, Fr* c_nat = nullptr, uint8_t* c_cls = nullptr, bool guard = false) {
     const size_t m = (size_t)1 << r->log_m;
     ProveWs& ws = prove_ws(ctx);
+    if (!c_nat) guard = false;
     Fr* abc[3];
     for (int k = 0; k < 3; k++) {
-        if (k == 2 && c_nat) {
+        if (k == 2 && c_nat && !guard) {
             abc[k] = nullptr;
             continue;
         }
@@ -1825,9 +1879,19 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
         abc[k] = ws.abc[k].as<Fr>();
     }
     if (c_nat && !eval_form) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows without the evaluation form");
-    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0, c_nat, c_cls));
+    unsigned long long* d_digits = guard ? (unsigned long long*)((uint8_t*)ws.bad.p + 8) : nullptr;
+    uint32_t* d_flag = guard ? (uint32_t*)((uint8_t*)ws.bad.p + 16) : nullptr;
+    ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0, c_nat, c_cls, d_digits));
+    ctx->fold_guarded = guard;
+    if (guard) {
+        ZG_LAUNCH(ctx, k_fold_decide, dim3((unsigned)std::min<size_t>((2 * m + 255) / 256, 2048)), dim3(256), 0, ctx->stream, d_digits,
+                  (unsigned long long)m * 2, d_flag, c_nat, c_cls, 2 * m);
+        ZG_HIP(ctx, hipGetLastError());
+        ZG_HIP(ctx, hipMemcpyAsync(&ws.bad_host[2], d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));   // (zg_last_stats)
+    }
     if (ev_eval_done) ZG_HIP(ctx, hipEventRecord(ev_eval_done, ctx->stream));
-    if (eval_form) return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out, h_split, h_split ? ctx->h_split_ev : nullptr);
+    if (eval_form)
+        return h_eval_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out, h_split, h_split ? ctx->h_split_ev : nullptr, d_flag);
     return h_poly_dev(ctx, abc[0], abc[1], abc[2], r->log_m, (Fr*)d_h_out);
 }
 extern "C" int zg_prove_h_dev(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness, void* d_h_out) try {
@@ -2515,7 +2579,7 @@ extern "C" int zg_prove_h_eval_enqueue_fold_dev(zg_ctx* ctx, const zg_params* p,
     ZG_HIP(ctx, hipEventRecord(ctx->gate_w, ctx->stream));
     ctx->witness_gate_armed = true;
     ZG_TRY(prove_h_enqueue(ctx, r, d_witness, d_e_out, ctx->tm_ev[1], /*eval_form=*/true, 0, fold ? cfb.c_nat : nullptr,
-                           fold ? cfb.c_cls : nullptr));
+                           fold ? cfb.c_cls : nullptr, /*guard=*/ctx->opt_c_fold == 1));
     if (fold) {
         ctx->fold_armed_key = p;
         ctx->fold_armed_r1cs = r;
@@ -2734,8 +2798,12 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ctx->last_share_mask = share.mask;
     ctx->last_follow_g2 = d1[3].follow_g2 && !(share.mask >> 3 & 3u);
+    // (a guarded proof: what k_fold_decide decided for it -- its 4-byte copy was queued in front of the l job's gate, and the
+    // multiexps below have been waited for by the time this is read: set again at the end)
     ctx->last_c_fold = c_fold != nullptr;
+    const bool fold_guarded = c_fold != nullptr && ctx->fold_guarded;
     ZG_TRY(msm_batch5(ctx, d1, d2, g1out, &b2_acc, ev_wit, ctx->ev_h, share.mask ? &share : nullptr));
+    if (fold_guarded) ctx->last_c_fold = prove_ws(ctx).bad_host[2] != 0u;
     const G1XYZZ &h_acc = g1out[0], &l_acc = g1out[1], &a_acc = g1out[2], &b1_acc = g1out[3];
     jac_bytes(partials, h_acc);
     jac_bytes(partials + 96, l_acc);
@@ -2950,7 +3018,7 @@ extern "C" int zg_prove_dev(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, c
     }
     const bool trace = trace_level() != 0;
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: classes queued      +%.3f ms\n", now_ms() - t0);
-    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split, cfb.c_nat, cfb.c_cls));
+    ZG_TRY(prove_h_enqueue(ctx, r, d_witness, dh.p, ctx->tm_ev[1], eval_form, h_split, cfb.c_nat, cfb.c_cls, /*guard=*/ctx->opt_c_fold == 1));
     if (trace) fprintf(stderr, "[za_amd trace] prove_dev: R1CS + H queued     +%.3f ms\n", now_ms() - t0);
     ZG_HIP(ctx, hipEventRecord(ctx->tm_ev[2], ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ctx->gate_h, ctx->stream));
