@@ -185,3 +185,40 @@ def test_msm_linearity_with_index_indirection(ctx):
     assert jac_to_affine_bytes(got, 32) == exp
     for p in (d_b, d_s, d_i):
         ctx.free(p)
+
+
+@pytest.mark.parametrize("group,log_n,share", [("g1", 21, 1.0), ("g1", 21, 0.25), ("g1", 20, 0.6), ("g2", 18, 1.0), ("g2", 18, 0.3)])
+def test_skewed_scalars_one_value_in_most_positions(ctx, group, log_n, share):
+    """A witness it did not choose: `share` of the scalars hold ONE non-bit constant (65537 * 2^40 + 3: every digit position
+    of those scalars lands in one bucket per window -- up to two million entries), the rest are uniform.  The sort's last
+    level (wave-aggregated counters for a segment that is mostly one bucket), the item map (a big bucket's items written by
+    its wave) and the heavy-bucket fold (units of 1024 items, the last workgroup to arrive folds the units' sums) must give
+    (sum s_i k_i) G -- per call and through resident bases with a window table."""
+    from za_amd import synth
+    n = 1 << log_n
+    g2 = group == "g2"
+    d_b = (synth.synth_bases_g2 if g2 else synth.synth_bases_g1)(ctx, n, 9301)
+    d_s = synth.synth_scalars(ctx, n, 9302)
+    sc = np.frombuffer(ctx.d2h(d_s, 32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    rng = np.random.default_rng(log_n * 100 + int(share * 10))
+    idx = np.arange(n) if share >= 1.0 else rng.choice(n, size=int(n * share), replace=False)
+    v = (65537 << 40) + 3
+    sc[idx, :] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+    k = synth.splitmix64_array(9301, n).tolist()
+    words = sc.view("<u8").reshape(n, 4).tolist()
+    tot = 0
+    for i in range(n):
+        wi = words[i]
+        tot += (wi[0] | (wi[1] << 64) | (wi[2] << 128) | (wi[3] << 192)) * k[i]
+    gen = bn.g2_to_mont_bytes(bn.G2_GEN) if g2 else bn.g1_to_mont_bytes(bn.G1_GEN)
+    exp = (co.g2_mul if g2 else co.g1_mul)(gen, tot % bn.R)
+    fb = 64 if g2 else 32
+    ctx.h2d(d_s, sc.reshape(-1))
+    got = (ctx.msm_g2_dev if g2 else ctx.msm_g1_dev)(d_b, d_s, n)
+    assert jac_to_affine_bytes(got, fb) == exp
+    if not g2:
+        H = ctx.msm_bases_g1_dev(d_b, n, table_budget_gb=4.0)
+        assert jac_to_affine_bytes(ctx.msm_resident_dev(H, d_s, n, False), fb) == exp
+        assert jac_to_affine_bytes(ctx.msm_resident(H, sc.reshape(-1), n, True), fb) == exp
+        ctx.msm_bases_free(H)
+    ctx.free(d_b); ctx.free(d_s)

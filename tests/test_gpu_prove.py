@@ -1355,6 +1355,39 @@ def test_c_rows_folded_into_the_l_multiexp(ctx, opts, lg, bitf, n_in):
     sr.close()
 
 
+@pytest.mark.parametrize("lg,share", [(16, 0.25), (18, 1.0), (20, 0.25)])
+def test_witness_with_one_constant_in_many_positions(ctx, lg, share):
+    """a prover service takes witnesses it does not choose.  `share` of the aux values overwritten by
+    ONE non-bit constant (65537): every such scalar is the same digits in the same buckets of all four witness queries (and an
+    unsatisfied witness, which bellman proves all the same).  Bytes against the C oracle's, host and device witness, twice
+    (cached tables)."""
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, 2, 0.97, 5150 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 270 + lg)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    nv = sr.n_inputs + sr.n_aux
+    w = np.array(sr.witness, copy=True).reshape(nv, 32)
+    ctx.prove(P, R, w.reshape(-1), 3, 4)                     # the key's tables are made for the circuit's own witness
+    rng = np.random.default_rng(lg)
+    idx = np.arange(sr.n_inputs, nv) if share >= 1.0 else sr.n_inputs + rng.choice(sr.n_aux, size=int(sr.n_aux * share), replace=False)
+    w[idx, :] = 0
+    w[idx, 0] = 1
+    w[idx, 2] = 1                                            # 65537
+    wb = w.reshape(-1)
+    pk = download_params(ctx, P)
+    r, s = 0x1717 + lg, 0x2828 + lg
+    exp = co.prove(pk, csr, wb, r, s, threads=16)
+    for _ in range(2):
+        assert ctx.prove(P, R, wb, r, s) == exp
+    d_w = ctx.upload(wb)
+    assert ctx.prove_dev(P, R, d_w, r, s) == exp
+    ctx.free(d_w)
+    assert ctx.prove(P, R, sr.witness, 3, 4) == co.prove(pk, csr, sr.witness, 3, 4, threads=16)
+    P.close(); R.close(); sr.close()
+
+
 @pytest.mark.parametrize("lg", [12, 16, 20])
 def test_the_fold_is_decided_per_proof_on_the_device(ctx, opts, lg):
     """VERDICT r5 / ADVICE r5: a key folds its C rows because the FIRST witness it saw had rows of bits; a later witness whose

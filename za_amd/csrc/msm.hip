@@ -66,6 +66,7 @@ static constexpr uint32_t T_ONES = 64;  // points per item of the ones bucket (u
 
 struct MsmScratch {
     DevBuf counts, offsets, item_off, tile_tab, abuf, sorted, item_key, perm, ihist, partial, lvl[2], ones[2], bsum, meta, heavy;
+    DevBuf heavy_tmp;          // k_heavy_fold: the unit sums of buckets folded by several workgroups
     DevBuf abuf2, tab2, p2m;   // staged partition: level-2 output, its [segment][sub-bin][chunk] table, its plan
     static constexpr size_t HOST_BYTES = 256 * 1024;
     unsigned char* host = nullptr;  // pinned read-back buffer (class counts, totals, window sums)
@@ -1011,6 +1012,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_one(const uint32_t* __res
 // entries also still sit in the 256 MB Infinity Cache when this kernel reads them).  Staged, with the counting pass's loads
 // eight deep and the next tile prefetched: 7.5 ms (counting 1.8, tiles 3.7, writes 2.0); the multiexp 103 -> 86 ms.
 static constexpr uint32_t PART_STAGE_TILE = 8192;
+// ctr[b] += 1 for every lane that is `on`, with ONE LDS atomic per distinct bucket among the wave's lanes; returns the lane's
+// rank (the value an atomicAdd of its own would have returned, in lane order).  For SKEWED segments only: when one bucket
+// holds most of a segment (a quarter of a witness equal to one constant: a million entries in one bucket) the 64 lanes of
+// every wave take turns on its counter -- 2.5 ms for such a segment; on evenly spread entries the loop below would run once
+// per lane instead.  Executed by whole waves (the shuffles read every lane).
+__device__ __forceinline__ uint32_t wave_agg_add(uint32_t* ctr, uint32_t b, bool on) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t r = 0;
+    unsigned long long todo = __ballot(on);
+    while (todo) {   // (wave-uniform)
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t lead = __shfl(b, first);
+        const unsigned long long same = __ballot(on && b == lead) & todo;
+        uint32_t base = 0;
+        if ((int)lane == first) base = atomicAdd(&ctr[lead], (uint32_t)__popcll(same));
+        base = __shfl(base, first);
+        if ((same >> lane) & 1ull) r = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return r;
+}
 // (p2m != nullptr: the segments are those of the staged three-level partition, see p3_start)
 __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A, const uint32_t* __restrict__ tile_off,
                                                     uint32_t ntiles, uint32_t nbins, int lb, uint32_t stage_min,
@@ -1066,7 +1088,26 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
         for (uint32_t pos = threadIdx.x; pos < len; pos += 1024) sorted[start + pos] = stv[pos];
         return;
     }
-    {   // (eight loads in flight per thread: a long segment is otherwise a chain of 96 load -> atomic round trips)
+    // Is one bucket most of this segment?  1024 samples, each compared with its wave's first: from a quarter of them equal the
+    // segment takes the wave-aggregated counters (wave_agg_add) in its three passes; every other segment the plain atomics.
+    bool skew = false;
+    if (end - start >= 16u * 1024u) {
+        const uint32_t y0 = A[start + (uint32_t)(((uint64_t)(end - start) * threadIdx.x) >> 10)].y;
+        const uint32_t eq = (uint32_t)__popcll(__ballot(y0 == __shfl(y0, 0)));
+        if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = eq;
+        __syncthreads();
+        uint32_t tot_eq = 0;
+        for (uint32_t k = 0; k < blockDim.x / 64; k++) tot_eq += scratch[k];
+        skew = tot_eq >= blockDim.x / 4;
+        __syncthreads();
+    }
+    if (skew) {   // (whole-block rounds: the ballots need whole waves)
+        for (uint32_t i0 = start; i0 < end; i0 += blockDim.x) {
+            const uint32_t i = i0 + threadIdx.x;
+            const bool on = i < end;
+            (void)wave_agg_add(lds_l, on ? A[i].y : 0u, on);
+        }
+    } else {   // (eight loads in flight per thread: a long segment is otherwise a chain of 96 load -> atomic round trips)
         constexpr uint32_t U = 8;
         uint32_t i = start + threadIdx.x;
         for (; i + (U - 1) * blockDim.x < end; i += U * blockDim.x) {
@@ -1097,6 +1138,16 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
     }
     __syncthreads();
     if (end - start < stage_min || nl > blockDim.x) {
+        if (skew) {
+            for (uint32_t i0 = start; i0 < end; i0 += blockDim.x) {
+                const uint32_t i = i0 + threadIdx.x;
+                const bool on = i < end;
+                const uint2 e = on ? A[i] : make_uint2(0u, 0u);
+                const uint32_t pos = wave_agg_add(lds_l, e.y, on);
+                if (on) sorted[pos] = e.x;
+            }
+            return;
+        }
         for (uint32_t i = start + threadIdx.x; i < end; i += blockDim.x) {
             uint2 e = A[i];
             sorted[atomicAdd(&lds_l[e.y], 1u)] = e.x;
@@ -1129,9 +1180,14 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
             const uint32_t i = t0 + TILE + k * 1024 + threadIdx.x;
             if (i < end) nx[k] = A[i];
         }
+        if (skew) {
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++)
-            if (k * 1024 + threadIdx.x < n_t) rk[k] = atomicAdd(&th[e[k].y], 1u);
+            for (uint32_t k = 0; k < PER; k++) rk[k] = wave_agg_add(th, e[k].y, k * 1024 + threadIdx.x < n_t);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++)
+                if (k * 1024 + threadIdx.x < n_t) rk[k] = atomicAdd(&th[e[k].y], 1u);
+        }
         __syncthreads();
         uint32_t tot_t;
         const uint32_t ex_t = block_excl_scan(threadIdx.x < nl ? th[threadIdx.x] : 0u, scratch, tot_t);
@@ -1182,9 +1238,25 @@ __global__ void __launch_bounds__(256) k_build_items(const uint32_t* __restrict_
         const uint32_t lo = item_off[nkeys - 1], hi = item_off[nkeys];
         for (uint32_t t = lo + key; t < hi; t += gridDim.x * blockDim.x) item_key[t] = nkeys - 1;
     }
-    if (key + 1u >= nkeys) return;
-    uint32_t lo = item_off[key], hi = item_off[key + 1];
-    for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
+    uint32_t lo = 0, hi = 0;
+    if (key + 1u < nkeys) {
+        lo = item_off[key];
+        hi = item_off[key + 1];
+    }
+    // A bucket of a few items is written by its own thread; a big one (skewed scalars: a quarter of the witness holding one
+    // constant puts a million entries into one bucket -- one thread then wrote 10^5 items, 1.1 ms at the head of the job's
+    // chain) by the 64 lanes of its wave, one such bucket after the other.
+    constexpr uint32_t OWN = 16;
+    if (hi - lo <= OWN)
+        for (uint32_t t = lo; t < hi; t++) item_key[t] = key;
+    unsigned long long big = __ballot(hi - lo > OWN);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t blo = __shfl(lo, src), bhi = __shfl(hi, src), bkey = __shfl(key, src);
+        for (uint32_t t = blo + lane; t < bhi; t += 64) item_key[t] = bkey;
+    }
 }
 
 // Items sorted by their number of points (counting sort, longest first): a wave of k_accumulate then holds 64
@@ -1207,8 +1279,21 @@ __global__ void __launch_bounds__(256) k_item_hist(const uint32_t* __restrict__ 
     for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const uint32_t total = item_off[nkeys];
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x)
-        atomicAdd(&h[item_size(t, item_key, item_off, offsets, T, ones_key)], 1u);
+    // (grid-stride in whole-block rounds: the ballots below need whole waves.  A wave whose items all have one size --
+    // the items of a heavy bucket are all T points long -- makes ONE atomic instead of 64 on one word)
+    for (uint32_t t0 = blockIdx.x * blockDim.x; t0 < total; t0 += gridDim.x * blockDim.x) {
+        const uint32_t t = t0 + threadIdx.x;
+        const bool on = t < total;
+        const uint32_t sz = on ? item_size(t, item_key, item_off, offsets, T, ones_key) : 0u;
+        const unsigned long long act = __ballot(on);
+        const int first = __ffsll((long long)act) - 1;
+        const uint32_t lead = __shfl(sz, first < 0 ? 0 : first);
+        if (act && __ballot(on && sz == lead) == act) {
+            if ((int)(threadIdx.x & 63u) == first) atomicAdd(&h[lead], (uint32_t)__popcll(act));
+        } else if (on) {
+            atomicAdd(&h[sz], 1u);
+        }
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
         if (h[i]) atomicAdd(&hist[i], h[i]);
@@ -1243,9 +1328,20 @@ __global__ void __launch_bounds__(256) k_item_scatter(const uint32_t* __restrict
         __syncthreads();
         const uint32_t t = t0 + threadIdx.x;
         uint32_t sz = 0, rank = 0;
-        if (t < total) {
-            sz = item_size(t, item_key, item_off, offsets, T, ones_key);
-            rank = atomicAdd(&h[sz], 1u);
+        {   // (as k_item_hist: one atomic for a wave of equal sizes, ranks by lane order)
+            const bool on = t < total;
+            if (on) sz = item_size(t, item_key, item_off, offsets, T, ones_key);
+            const unsigned long long act = __ballot(on);
+            const int first = __ffsll((long long)act) - 1;
+            const uint32_t lead = __shfl(sz, first < 0 ? 0 : first);
+            if (act && __ballot(on && sz == lead) == act) {
+                uint32_t base0 = 0;
+                if ((int)(threadIdx.x & 63u) == first) base0 = atomicAdd(&h[lead], (uint32_t)__popcll(act));
+                base0 = __shfl(base0, first);
+                rank = base0 + (uint32_t)__popcll(act & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            } else if (on) {
+                rank = atomicAdd(&h[sz], 1u);
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < ITEM_CLASSES; i += blockDim.x)
@@ -1392,29 +1488,48 @@ __global__ void __launch_bounds__(256) k_accumulate(Batch<F> batch,
 // twice the mean bucket load serially, see MsmJob::phase_b).  force_key (or ~0u): a key listed whenever it holds an item --
 // the ones bucket of a job queued without read-backs, whose fold k_heavy_fold also copies to ones_out.
 static constexpr uint32_t HEAVY_ITEMS = 4;
+// A heavy bucket is folded in UNITS of HEAVY_CH items, one workgroup each: a bucket of a million entries (skewed scalars) was
+// ONE workgroup's 10^5 dependent-ish additions, 1.5 ms at the tail of its job.  A bucket of several units: every unit's sum
+// goes to fold_tmp, and the workgroup that finishes LAST (a counter per bucket) folds those -- one launch, no host round trip.
+// unit = {key, chunk, chunks of the key, first slot of the key in fold_tmp / its counter in hdone}.
+// heavy_cnt[0] counts units, heavy_cnt[1] the slots handed out to buckets of more than one unit.
+static constexpr uint32_t HEAVY_CH = 1024;
 __global__ void __launch_bounds__(256) k_heavy_collect(const uint32_t* __restrict__ item_off, uint32_t nkeys_listed,
                                                        uint32_t heavy_items, uint32_t force_key,
-                                                       uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
+                                                       uint32_t* __restrict__ heavy_cnt, uint4* __restrict__ units,
+                                                       uint32_t* __restrict__ hdone, uint32_t nb, uint32_t tmp_stride) {
     uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys_listed) return;
     const uint32_t items = item_off[key + 1] - item_off[key];
-    if (items > heavy_items || (key == force_key && items > 0)) heavy_list[atomicAdd(heavy_cnt, 1u)] = key;
+    if (!(items > heavy_items || (key == force_key && items > 0))) return;
+    const uint32_t nch = (items + HEAVY_CH - 1) / HEAVY_CH;
+    const uint32_t u0 = atomicAdd(&heavy_cnt[0], nch);
+    uint32_t t0 = 0;
+    if (nch > 1) {
+        t0 = atomicAdd(&heavy_cnt[1], nch);
+        for (uint32_t y = 0; y < nb; y++) hdone[(size_t)y * tmp_stride + t0] = 0;
+    }
+    for (uint32_t c = 0; c < nch; c++) units[u0 + c] = make_uint4(key, c, nch, t0);
 }
 template <class F, class L = typename LazyOf<F>::L, int LP = 1>
 __global__ void __launch_bounds__(128 * LP) k_heavy_fold(Batch<F> batch, const uint32_t* __restrict__ item_off,
                                                          const uint32_t* __restrict__ heavy_cnt,
-                                                         const uint32_t* __restrict__ heavy_list, uint32_t ones_key) {
+                                                         const uint4* __restrict__ units, uint32_t ones_key,
+                                                         XYZZ<F>* __restrict__ fold_tmp, uint32_t* __restrict__ hdone,
+                                                         uint32_t tmp_stride) {
     XYZZ<F>* __restrict__ partial = batch.q[blockIdx.y].partial;
     XYZZ<F>* __restrict__ ones_out = batch.q[blockIdx.y].ones_out;
+    XYZZ<F>* __restrict__ ftmp = fold_tmp + (size_t)blockIdx.y * tmp_stride;
+    uint32_t* __restrict__ dn = hdone + (size_t)blockIdx.y * tmp_stride;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
     XYZZ<F>* lds = reinterpret_cast<XYZZ<F>*>(smem_h);
+    __shared__ uint32_t last_unit;
     const uint32_t tid = threadIdx.x / LP, bdim = blockDim.x / LP;   // points, not lanes
-    const uint32_t cnt = *heavy_cnt;
-    for (uint32_t slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
-        const uint32_t key = heavy_list[slot];
-        const uint32_t lo = item_off[key], hi = item_off[key + 1];
+    const uint32_t cnt = heavy_cnt[0];
+    // sum of src[lo .. hi) over the workgroup; the result is thread 0's (all of its LP lanes)
+    auto fold = [&](const XYZZ<F>* __restrict__ src, uint32_t lo, uint32_t hi) {
         XYZZd<L> acc = XYZZd<L>::inf();
-        for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&partial[i]));
+        for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&src[i]));
         acc.store(&lds[tid]);
         __syncthreads();
         for (uint32_t st = bdim >> 1; st > 0; st >>= 1) {
@@ -1424,9 +1539,34 @@ __global__ void __launch_bounds__(128 * LP) k_heavy_fold(Batch<F> batch, const u
             }
             __syncthreads();
         }
-        if (tid == 0) {
-            acc.store(&partial[lo]);
-            if (key == ones_key) acc.store(ones_out);
+        return acc;
+    };
+    for (uint32_t slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const uint4 u = units[slot];
+        const uint32_t key = u.x, nch = u.z, t0 = u.w;
+        const uint32_t lo0 = item_off[key], hi0 = item_off[key + 1];
+        const uint32_t lo = lo0 + u.y * HEAVY_CH, hi = lo + HEAVY_CH < hi0 ? lo + HEAVY_CH : hi0;
+        XYZZd<L> acc = fold(partial, lo, hi);
+        if (nch == 1) {
+            if (tid == 0) {
+                acc.store(&partial[lo0]);
+                if (key == ones_key) acc.store(ones_out);
+            }
+            __syncthreads();
+            continue;
+        }
+        if (tid == 0) acc.store(&ftmp[t0 + u.y]);
+        __threadfence();   // the unit's sum is out before its arrival is counted (the units of a bucket run on any XCD)
+        __syncthreads();
+        if (threadIdx.x == 0) last_unit = atomicAdd(&dn[t0], 1u) == nch - 1 ? 1u : 0u;
+        __syncthreads();
+        if (last_unit) {   // (uniform over the workgroup) every other unit of this bucket has arrived
+            __threadfence();
+            acc = fold(ftmp, t0, t0 + nch);
+            if (tid == 0) {
+                acc.store(&partial[lo0]);
+                if (key == ones_key) acc.store(ones_out);
+            }
         }
         __syncthreads();
     }
@@ -2023,16 +2163,16 @@ struct MsmJob : MsmJobBase {
         if (!src) ZG_HIP(ctx, S.item_key.reserve((size_t)total_items * 4));
         if (!sort_only) ZG_HIP(ctx, S.partial.reserve((size_t)total_items * sizeof(XYZZ<F>)));
         trace_point("phase_c reserved items");
-        // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] claimed per size (k_item_scatter), [1] the heavy-bucket counter
-        ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 1) * 4));
+        // one zeroed block: [ITEM_CLASSES] histogram, [ITEM_CLASSES] claimed per size (k_item_scatter), [2] the heavy-bucket counters
+        ZG_HIP(ctx, S.ihist.reserve((2 * ITEM_CLASSES + 2) * 4));
         if (src) {
-            ZG_HIP(ctx, hipMemsetAsync(S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES, 0, 4, st));   // (its own heavy-bucket counter)
+            ZG_HIP(ctx, hipMemsetAsync(S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES, 0, 8, st));   // (its own heavy-bucket counters)
             ZG_HIP(ctx, hipStreamWaitEvent(st, src->ev_items, 0));
         } else {
             ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
             uint32_t* hist = S.ihist.as<uint32_t>();
             ZG_LAUNCH(ctx, k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
-                               nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0, hist, 2 * ITEM_CLASSES + 1);
+                               nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0, hist, 2 * ITEM_CLASSES + 2);
             if (ones_hi > ones_lo)
                 ZG_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(S.item_key.as<uint32_t>() + ones_lo), (int)ones_key,
                                               ones_hi - ones_lo, st));
@@ -2120,9 +2260,15 @@ struct MsmJob : MsmJobBase {
         ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
         {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
-            ZG_HIP(ctx, S.heavy.reserve(((size_t)P.nkeys + 1) * 4));
+            // units of HEAVY_CH items (k_heavy_collect): at most one per listed bucket plus one per HEAVY_CH items; slots for the
+            // sums of the buckets of several units: at most twice the latter
+            const size_t max_units = (size_t)nkeys + 1 + total_items / HEAVY_CH + 1;
+            const uint32_t tmp_stride = 2 * (uint32_t)(total_items / HEAVY_CH) + 2;
+            ZG_HIP(ctx, S.heavy.reserve(max_units * sizeof(uint4) + (size_t)nb * tmp_stride * 4));
+            ZG_HIP(ctx, S.heavy_tmp.reserve((size_t)nb * tmp_stride * sizeof(XYZZ<F>)));
             uint32_t* hcnt = S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES;   // zeroed with the histogram above
-            uint32_t* hlist = S.heavy.as<uint32_t>();
+            uint4* hlist = S.heavy.as<uint4>();
+            uint32_t* hdone = reinterpret_cast<uint32_t*>(hlist + max_units);
             // a job queued without read-backs folds its ones bucket here too (listed whenever it holds an item)
             // (a small job's ones bucket has at most n / t_ones + 1 items: if they fit a row of the leaf level they are
             // summed there, see k_bits_level)
@@ -2138,9 +2284,10 @@ struct MsmJob : MsmJobBase {
             const uint32_t listed = fold_ones ? nkeys : P.nkeys;
             // (the list of heavy buckets depends on the items only: one for the whole batch)
             ZG_LAUNCH(ctx, k_heavy_collect, dim3((listed + 255) / 256), dim3(256), 0, st, SS.item_off.as<uint32_t>(),
-                               listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist);
+                               listed, heavy_items, fold_ones ? ones_key : ~0u, hcnt, hlist, hdone, nb, tmp_stride);
             ZG_LAUNCH(ctx, (k_heavy_fold<F, typename ChainCfg<F>::L, ChainCfg<F>::LP>), dim3(1024, nb), dim3(128 * ChainCfg<F>::LP),
-                               128 * sizeof(XYZZ<F>), st, B, SS.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u);
+                               128 * sizeof(XYZZ<F>), st, B, SS.item_off.as<uint32_t>(), hcnt, hlist, fold_ones ? ones_key : ~0u,
+                               S.heavy_tmp.template as<XYZZ<F>>(), hdone, tmp_stride);
         }
         const int bits = P.c - 1;
         red_nlev = 0;
