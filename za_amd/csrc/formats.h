@@ -92,6 +92,8 @@ struct KeyStage {   // the raw bytes' way through HBM: two chunk buffers used in
 int key_decode_query_dev(Ctx* ctx, int which, const uint8_t* host_raw, uint64_t n, bool checked, uint64_t lo, uint64_t hi,
                          void* d_out, unsigned long long* d_verdict, KeyStage* stage);
 int key_verdict_to_error(Ctx* ctx, const unsigned long long verdict[5]);
+// Parameters::write of one query on the device: n resident points -> n * 64 / 128 bytes of pairing_ce's uncompressed encoding
+int key_encode_query_dev(Ctx* ctx, int which, const void* d_points, uint64_t n, uint8_t* host_out, KeyStage* stage);
 
 Fq2 g2_coeff_b();                       // 3/(9+u), Montgomery
 bool g2_in_subgroup(const G2Affine& p); // [r]P == identity (the twist has a large cofactor; G1's is 1)

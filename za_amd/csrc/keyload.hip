@@ -174,6 +174,41 @@ __global__ void __launch_bounds__(256, 2) k_key_decode_g2(const uint4* __restric
     }
 }
 
+// ---- the way back: Parameters::write (prover/src/groth16/format.rs:250).  Resident points (device form, identity = all
+// zero) -> pairing_ce's uncompressed encoding: canonical coordinates, big-endian, G2 as x.c1 | x.c0 | y.c1 | y.c0, the
+// identity as 0x40 followed by zeros.
+__device__ __forceinline__ void be_store(uint4* dst, const uint32_t w[8]) {   // 8 x u32 little-endian words -> 32 bytes big-endian
+    dst[0] = make_uint4(__builtin_bswap32(w[7]), __builtin_bswap32(w[6]), __builtin_bswap32(w[5]), __builtin_bswap32(w[4]));
+    dst[1] = make_uint4(__builtin_bswap32(w[3]), __builtin_bswap32(w[2]), __builtin_bswap32(w[1]), __builtin_bswap32(w[0]));
+}
+template <int NC>   // coordinates per point: 2 (G1) or 4 (G2)
+__global__ void __launch_bounds__(256) k_key_encode(const Fq* __restrict__ pts, uint64_t n, uint4* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per coordinate
+    if (t >= n * NC) return;
+    const uint64_t i = t / NC;
+    const uint32_t k = (uint32_t)(t % NC);
+    // file order of the coordinates of a G2 point: x.c1, x.c0, y.c1, y.c0 (memory: x.c0, x.c1, y.c0, y.c1)
+    const uint32_t src = NC == 4 ? (k ^ 1u) : k;
+    uint32_t any = 0;
+    for (int q = 0; q < NC; q++) {
+        const Fq& c = pts[i * NC + q];
+#pragma unroll
+        for (int j = 0; j < 8; j++) any |= c.l[j];
+    }
+    uint32_t w[8];
+    if (any == 0) {   // the identity
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = 0;
+        if (k == 0) w[7] = 0x40000000u;
+    } else {
+        Fq c;
+        FqD::load_canon(&pts[i * NC + src]).from_mont().store(&c);
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[j] = c.l[j];
+    }
+    be_store(out + 2 * t, w);
+}
+
 Fq2 fq2_pow(Fq2 a, const uint32_t e[8]) {
     Fq2 r{Fq::one(), Fq::zero()};
     for (int i = 255; i >= 0; i--) {
@@ -248,6 +283,29 @@ int key_decode_query_dev(Ctx* ctx, int which, const uint8_t* host_raw, uint64_t 
                       stage->buf[s].as<uint4>(), cnt, at, lo, hi, (G1Affine*)d_out, checked ? 1 : 0, kc, d_verdict);
         ZG_HIP(ctx, hipGetLastError());
     }
+    return ZG_OK;
+}
+
+// Queue-and-copy: the n resident points of one query (device form) -> their uncompressed encoding in host_out (n * 64 or
+// n * 128 bytes).  Blocking.
+int key_encode_query_dev(Ctx* ctx, int which, const void* d_points, uint64_t n, uint8_t* host_out, KeyStage* stage) {
+    const bool g2 = which == 4;
+    const size_t elem = g2 ? 128 : 64;
+    const uint64_t chunk_pts = KeyStage::CHUNK_BYTES / elem;
+    for (uint64_t at = 0; at < n; at += chunk_pts) {
+        const uint64_t cnt = std::min<uint64_t>(chunk_pts, n - at);
+        const int s = stage->next;
+        stage->next ^= 1;
+        ZG_HIP(ctx, stage->buf[s].reserve(KeyStage::CHUNK_BYTES));
+        const Fq* src = (const Fq*)((const uint8_t*)d_points + at * elem);
+        if (g2)
+            ZG_LAUNCH(ctx, (k_key_encode<4>), dim3((unsigned)((cnt * 4 + 255) / 256)), dim3(256), 0, ctx->stream, src, cnt, stage->buf[s].as<uint4>());
+        else
+            ZG_LAUNCH(ctx, (k_key_encode<2>), dim3((unsigned)((cnt * 2 + 255) / 256)), dim3(256), 0, ctx->stream, src, cnt, stage->buf[s].as<uint4>());
+        ZG_HIP(ctx, hipGetLastError());
+        ZG_HIP(ctx, hipMemcpyAsync(host_out + at * elem, stage->buf[s].p, cnt * elem, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZG_OK;
 }
 

@@ -128,8 +128,18 @@ struct Csc {
 }  // namespace
 
 // Parameters::write (format.rs:250) of a resident, unsharded key: vk (alpha_g1, beta_g1, beta_g2, gamma_g2, delta_g1,
-// delta_g2, ic), then h, l, a, b_g1, b_g2 fetched from HBM and taken out of the device's M261 form
-static int params_write_bytes(zg_ctx* ctx, const zg_params* p, std::vector<uint8_t>* bytes) {
+// delta_g2, ic) from the host copy, then h, l, a, b_g1, b_g2: every query is ENCODED ON THE DEVICE (keyload.hip
+// k_key_encode: out of Montgomery form, big-endian, identity flag) and copied straight into the caller's buffer -- at 2^22
+// constraints 0.96 GB in ~0.1 s where the host loop (two Montgomery products and 32 byte stores per coordinate on one thread)
+// took 4 s, twice per `setup` (size query + write).
+static size_t params_write_size(const zg_params* p, size_t vk_bytes) {
+    size_t n = vk_bytes;
+    for (int k = 0; k < 5; k++) n += 4 + (size_t)p->q[k].total * (k == 4 ? 128 : 64);
+    return n;
+}
+extern "C" int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, size_t cap, size_t* written) try {
+    if (!ctx || !p || !written) return ZG_E_INVALID_ARG;
+    ZG_HIP(ctx, hipSetDevice(ctx->device));
     if (p->world != 1) return fail(ctx, ZG_E_INVALID_ARG, "Parameters::write needs an unsharded key (world = 1)");
     if (p->ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "this key was built without gamma_g2 / ic");
     ParsedParams pp;
@@ -137,32 +147,22 @@ static int params_write_bytes(zg_ctx* ctx, const zg_params* p, std::vector<uint8
     pp.gamma_g2 = p->gamma_g2;
     pp.delta_g1 = p->delta_g1; pp.delta_g2 = p->delta_g2;
     pp.ic = p->ic;
-    auto fetch1 = [&](const zg_params::Query& q, std::vector<G1Affine>& v) -> hipError_t {
-        v.resize(q.total);
-        if (!q.total) return hipSuccess;
-        hipError_t e = hipMemcpy(v.data(), q.buf.p, (size_t)q.total * 64, hipMemcpyDeviceToHost);
-        for (auto& x : v) x = m261_to_host(x);
-        return e;
-    };
+    std::vector<uint8_t> vk;
+    write_bellman_vk(pp, &vk);
+    const size_t need = params_write_size(p, vk.size());
+    *written = need;
+    if (!out || cap < need) return ZG_E_BUFFER_TOO_SMALL;
+    memcpy(out, vk.data(), vk.size());
+    size_t at = vk.size();
+    KeyStage stage;
     ZG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ZG_HIP(ctx, fetch1(p->q[0], pp.h));
-    ZG_HIP(ctx, fetch1(p->q[1], pp.l));
-    ZG_HIP(ctx, fetch1(p->q[2], pp.a));
-    ZG_HIP(ctx, fetch1(p->q[3], pp.b_g1));
-    pp.b_g2.resize(p->q[4].total);
-    if (p->q[4].total) ZG_HIP(ctx, hipMemcpy(pp.b_g2.data(), p->q[4].buf.p, (size_t)p->q[4].total * 128, hipMemcpyDeviceToHost));
-    for (auto& x : pp.b_g2) x = m261_to_host(x);
-    write_bellman_params(pp, bytes);
-    return ZG_OK;
-}
-extern "C" int zg_params_write(zg_ctx* ctx, const zg_params* p, uint8_t* out, size_t cap, size_t* written) try {
-    if (!ctx || !p || !written) return ZG_E_INVALID_ARG;
-    ZG_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<uint8_t> bytes;
-    ZG_TRY(params_write_bytes(ctx, p, &bytes));
-    *written = bytes.size();
-    if (!out || cap < bytes.size()) return ZG_E_BUFFER_TOO_SMALL;
-    memcpy(out, bytes.data(), bytes.size());
+    for (int k = 0; k < 5; k++) {
+        const uint32_t cnt = (uint32_t)p->q[k].total;
+        out[at] = (uint8_t)(cnt >> 24); out[at + 1] = (uint8_t)(cnt >> 16); out[at + 2] = (uint8_t)(cnt >> 8); out[at + 3] = (uint8_t)cnt;
+        at += 4;
+        ZG_TRY(key_encode_query_dev(ctx, k, p->q[k].buf.p, p->q[k].total, out + at, &stage));
+        at += (size_t)p->q[k].total * (k == 4 ? 128 : 64);
+    }
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(ctx);
@@ -354,13 +354,10 @@ extern "C" int zg_setup(zg_ctx* ctx, const zg_r1cs* r, const uint8_t toxic[160],
     if (ni) ZG_HIP(ctx, hipMemcpy(p->ic.data(), ext_pts.p, (size_t)ni * 64, hipMemcpyDeviceToHost));
     for (auto& x : p->ic) x = m261_to_host(x);
     if (params_out || written) {
-        std::vector<uint8_t> bytes;
-        ZG_TRY(params_write_bytes(ctx, p.get(), &bytes));
-        if (written) *written = bytes.size();
-        if (params_out) {
-            if (bytes.size() > cap) return ZG_E_BUFFER_TOO_SMALL;
-            memcpy(params_out, bytes.data(), bytes.size());
-        }
+        size_t need = 0;
+        const int rc = zg_params_write(ctx, p.get(), params_out, params_out ? cap : 0, &need);   // (device-side encoding)
+        if (written) *written = need;
+        if (rc != ZG_OK && !(rc == ZG_E_BUFFER_TOO_SMALL && !params_out)) return rc;
     }
     *out = p.release();
     return ZG_OK;
