@@ -222,16 +222,21 @@ VALU_PEAK_NOTE = ("tools/ubench_valu.hip on this chip (profiles/r02_ubench_fmul.
 VALU_ISSUE_NOMINAL = 1024 * 2.4e9 / 4 * 64   # lane multiply-adds / s at the nominal clock, quarter rate
 
 
-def _acc_class(prof, key):
+def _acc_class(prof, key, hbm=True):
+    """hbm = False (the witness queries' launches): no HBM fraction -- SURVEY 8(d)'s 96 B are per point that is multiplied,
+    and a launch of a witness job is credited every POSITION of its query although a zero scalar never reaches the kernel
+    (and, for a folded key, the 2 m positions of the C rows, which are not survey points at all)."""
     ms, n, nbytes, units = prof.get(key, (0.0, 0, 0, 0))
     if not n:
         return None
     achieved = nbytes / (ms * 1e-3) / 1e9
     mads = units * MADS_PER_MIXED_ADD
-    return {"launches": n, "avg_launch_ms": ms / n, "algorithmic_bytes_per_launch": nbytes / n,
-            "mixed_adds_per_launch": units / n, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-            "alu_frac_of_measured_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_PEAK,
-            "alu_frac_of_nominal_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_NOMINAL}
+    out = {"launches": n, "avg_launch_ms": ms / n, "mixed_adds_per_launch": units / n,
+           "alu_frac_of_measured_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_PEAK,
+           "alu_frac_of_nominal_issue_rate": mads / (ms * 1e-3) / VALU_ISSUE_NOMINAL}
+    if hbm:
+        out.update({"algorithmic_bytes_per_launch": nbytes / n, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS})
+    return out
 
 
 def acc_roofline(prof, pmc=None):
@@ -240,8 +245,8 @@ def acc_roofline(prof, pmc=None):
     the top-level fields carry) and the witness queries' G1 jobs (`witness`: credited 96 B for every position of the
     query although a zero scalar never reaches the kernel).  `blended` is round 2's single number over both.
     pmc: {"traffic": bytes per launch, "valu_per_add": ..., "source": ...} measured for THIS workload, or None."""
-    dense, wit = _acc_class(prof, "msm_accumulate_g1_dense"), _acc_class(prof, "msm_accumulate_g1")
-    main = dense or wit
+    dense, wit = _acc_class(prof, "msm_accumulate_g1_dense"), _acc_class(prof, "msm_accumulate_g1", hbm=False)
+    main = dense or _acc_class(prof, "msm_accumulate_g1")
     if not main:
         return None
     roof = {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation), launches of the h multiexp" if dense
@@ -256,10 +261,11 @@ def acc_roofline(prof, pmc=None):
         ms = prof["msm_accumulate_g1_dense"][0] + prof["msm_accumulate_g1"][0]
         nb = prof["msm_accumulate_g1_dense"][2] + prof["msm_accumulate_g1"][2]
         nl = prof["msm_accumulate_g1_dense"][1] + prof["msm_accumulate_g1"][1]
-        roof["by_job_class"]["blended"] = {"launches": nl, "avg_launch_ms": ms / nl, "achieved": nb / (ms * 1e-3) / 1e9,
-                                           "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "note": "both classes are ONE kernel name: this average is the one a rocprofv3 --stats "
-                                                   "summary of the same command shows for k_accumulate<Fq> (%s)" % blended_note()}
+        roof["by_job_class"]["blended"] = {"launches": nl, "avg_launch_ms": ms / nl,
+                                           "note": "both classes are ONE kernel name: this average launch time is the one a "
+                                                   "rocprofv3 --stats summary of the same command shows for k_accumulate<Fq> (%s); "
+                                                   "no HBM fraction is given for it or for the witness class: only the h launches' "
+                                                   "points all reach the kernel" % blended_note()}
     # secondary, integer-issue ceiling: the kernel is VALU bound.  One mixed add = 8 mul + 2 sqr
     # in the 9x29 field = 8*162 + 2*126 v_mad_u64_u32 (minus 81 where two products share a reduction).
     roof["alu_secondary"] = {"unit": "lane v_mad_u64_u32 / s", "peak_measured": VALU_ISSUE_PEAK, "peak_nominal": VALU_ISSUE_NOMINAL,
@@ -304,7 +310,7 @@ def pmc_for(args):
     were taken on: the default one.  Any other workload gets None -- nothing is pasted across workloads."""
     if not (args.workload == "synthetic" and args.log_m == 22 and abs(args.bit_fraction - 0.97) < 1e-9 and args.seed == 0x5A):
         return None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)))
             vi = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_valu_instructions.json" % rnd)))

@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 uptime > $out/uptime.txt
-Q="--no-msm --no-dense --no-sha --shard-model 0 --no-cpu-baseline"
+Q="--no-msm --no-dense --no-sha --shard-model 0 --no-cpu-baseline --no-outer"
 run() { name=$1; shift; timeout 1500 python bench.py $Q "$@" 2>$out/$name.err | tail -1 > $out/bench_$name.json; }
 run eddsa_poseidon --workload eddsa --steps 100 --warmup 10
 run poseidon_2p14 --workload poseidon --log-m 14 --steps 100 --warmup 10

@@ -11,7 +11,7 @@ B=$GRAFT_REPO_ROOT/bench.py
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $out/pytest_gpu.txt
 timeout 900 python bench.py 2>$out/bench_stderr.txt | tail -1 > $out/bench_default.json
 cd /tmp && export TMPDIR=/tmp
-PROF="--no-cpu-baseline --no-msm --no-dense --no-sha --provers 1 --shard-model 0"
+PROF="--no-cpu-baseline --no-msm --no-dense --no-sha --provers 1 --shard-model 0 --no-outer"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $B $PROF > $out/bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $B $PROF --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $B $PROF --steps 2 --warmup 1 > /dev/null 2>&1

@@ -2128,6 +2128,9 @@ static int ensure_tables(Ctx* ctx, const zg_params* p, const QueryUse use[5], un
         reserve += (size_t)use[0].n * 32 * 8;
         const size_t avail = free_b > reserve ? free_b - reserve : 0;
         size_t budget = (size_t)((double)avail * 0.6);
+        // (round 6: letting b_g1's table -- the last one built, and the one that lets its multiexp ride the G2 job's sort --
+        // take 95 % of what is left instead of 60 % made it fit at 2^26 (34 GB) and the first proof ran out of memory in its
+        // staged sort buffers: the 60 % stays)
         if (ctx->opt_tables_max_mb) budget = std::min<size_t>(budget, (size_t)ctx->opt_tables_max_mb * 1000000u);
         const size_t elem = k == 4 ? sizeof(G2Affine) : sizeof(G1Affine);
         // latency bound (msm.hip small-job mode: always a window table): a dense query up to 2^16 points; a witness query up
