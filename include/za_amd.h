@@ -145,6 +145,13 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */
 #define ZG_OPT_C_FOLD 22
 #define ZG_OPT_C_FOLD_MIN_LOG_M 23
+/*   ZG_OPT_UPLOAD_GATES    value = log2 of the smallest witness it applies to (default 23; 0 = never): zg_prove hands a witness of
+ *                          2^value values or more that does not pack (field elements) over in three chunks, each classified
+ *                          behind its copy, and the l multiexp runs in three parts gated on them: its first parts sort and
+ *                          accumulate while the rest of the witness is on the bus -- the one stretch of such a proof in which
+ *                          the GPU idled.  A lone context only.  Measured, values alternated in one process: 2^24 uniform witness
+ *                          124.5 -> 119.1 ms; 2^22 33.33 vs 33.34 (three jobs' tails cost what the 2.3 ms window buys). */
+#define ZG_OPT_UPLOAD_GATES 24
 int zg_set_option(zg_ctx* ctx, int option, int64_t value);
 int zg_sync(zg_ctx* ctx);
 
@@ -453,7 +460,8 @@ int zg_last_timings(const zg_ctx* ctx, double ms[6]);
 int zg_last_load_timings(const zg_ctx* ctx, double ms[4]);
 /* ---- what the last zg_prove* call (or, for the phase API, everything since the last one) queued on the GPU:
  * [0] kernel launches (a key's FIRST proof also counts its one-time work: table builds, the group transforms of the h query), [1] bit mask of the witness queries (bit 1 l, 2 a, 3 b_g1, 4 b_g2) whose multiexps shared one digit
- * sort over the witness positions in the last batch of multiexps (0 = none), [2] 1 if the b_g1 multiexp ran over the b_g2
+ * sort over the witness positions in the last batch of multiexps (0 = none); bit 8: the l multiexp ran in parts behind a
+ * witness that was handed over in chunks (ZG_OPT_UPLOAD_GATES), [2] 1 if the b_g1 multiexp ran over the b_g2
  * multiexp's sorted entries (same scalars, same positions, tables of one layout), [3] 1 if the proof ran with four
  * transforms and its C rows folded into the l multiexp (ZG_OPT_C_FOLD). */
 int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]);

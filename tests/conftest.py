@@ -40,7 +40,7 @@ def opts(ctx):
                 za_amd.OPT_PACK_RAW_PERMILLE: 400, za_amd.OPT_COMBINE_EARLY: 1, za_amd.OPT_SMALL_LOG_N: 16,
                 za_amd.OPT_SMALL_W_LOG_N: -1, za_amd.OPT_SORT_STAGED: -1, za_amd.OPT_PART_STAGE_MIN: -1, za_amd.OPT_SUBSET_W: 8,
                 za_amd.OPT_COMPACT_TABLE: 1, za_amd.OPT_H_PARTS: 0, za_amd.OPT_H_PIPE: -1, za_amd.OPT_SHARE_SORT: 1, za_amd.OPT_NTT_BATCH_LOG_M: 21,
-                za_amd.OPT_C_FOLD: 1, za_amd.OPT_C_FOLD_MIN_LOG_M: 20}
+                za_amd.OPT_C_FOLD: 1, za_amd.OPT_C_FOLD_MIN_LOG_M: 20, za_amd.OPT_UPLOAD_GATES: 23}
     # (a whole-suite run with a schedule forced through ZA_AMD_OPTIONS keeps it after a test that touched the option)
     defaults.update(dict(za_amd._options_from_env()))
     touched = set()

@@ -1355,6 +1355,44 @@ def test_c_rows_folded_into_the_l_multiexp(ctx, opts, lg, bitf, n_in):
     sr.close()
 
 
+@pytest.mark.parametrize("lg,bitf,pack", [(20, 0.0, 1), (20, 0.97, 0), (21, 0.5, 1)])
+def test_l_multiexp_in_parts_behind_a_witness_handed_over_in_chunks(ctx, opts, lg, bitf, pack):
+    """ZG_OPT_UPLOAD_GATES: a witness of 2^20 values or more that goes over as it is (field elements; or bits with the
+    packing switched off, which puts subset-sum tables under the range jobs) is copied in three chunks, each classified behind
+    its copy, and the l multiexp runs in three parts gated on them.  Bytes against the C oracle's with the gates on and
+    off, twice each (cached tables, the second hand-over), and zg_last_stats says which way the proof ran; a witness with a
+    value >= r in the LAST chunk is still refused."""
+    from za_amd import synth
+    sr = synth.SynthR1CS(lg, 2, bitf, 7300 + lg)
+    R = sr.load(ctx)
+    m = 1 << lg
+    P = synth.synth_params(ctx, m - 1, sr.n_aux, sr.n_inputs + R.a_aux_total, R.b_input_total + R.b_aux_total, 370 + lg)
+    csr = co.CsrR1CS(sr.n_inputs, sr.n_aux, sr.n_constraints, sr.row_ptr, sr.col, sr.coeff)
+    pk = download_params(ctx, P)
+    r, s = 0x3131 + lg, 0x4242 + lg
+    exp = co.prove(pk, csr, sr.witness, r, s, threads=16)
+    opts(za_amd.OPT_PACK, pack)
+    opts(za_amd.OPT_C_FOLD, 0)                      # (a folded l query waits for the evaluation anyway: not this path)
+    pin = ctx.host_alloc(len(sr.witness))
+    pin[:] = sr.witness
+    for gates in (20, 0, 20):                       # (the default applies it from 2^23 values: A/B in profiles/r06_exp_upload_gates.txt)
+        opts(za_amd.OPT_UPLOAD_GATES, gates)
+        for src in (pin, sr.witness):               # pinned and pageable host memory
+            assert ctx.prove(P, R, src, r, s) == exp
+            assert ctx.last_stats()["l_in_parts_behind_the_upload"] == bool(gates)
+    bad = np.array(sr.witness, copy=True)
+    nv = sr.n_inputs + sr.n_aux
+    bad[32 * (nv - 5):32 * (nv - 4)] = np.frombuffer((bn.R + 1).to_bytes(32, "little"), dtype=np.uint8)
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.prove(P, R, bad, r, s)
+    assert e.value.code == za_amd.ZG_E_BAD_FORMAT
+    assert ctx.prove(P, R, pin, r, s) == exp        # ... and the context is fine afterwards
+    d_w = ctx.upload(sr.witness)
+    assert ctx.prove_dev(P, R, d_w, r, s) == exp and not ctx.last_stats()["l_in_parts_behind_the_upload"]
+    ctx.free(d_w); ctx.host_free(pin)
+    P.close(); R.close(); sr.close()
+
+
 @pytest.mark.parametrize("lg,share", [(16, 0.25), (18, 1.0), (20, 0.25)])
 def test_witness_with_one_constant_in_many_positions(ctx, lg, share):
     """a prover service takes witnesses it does not choose.  `share` of the aux values overwritten by

@@ -136,7 +136,7 @@ OPT_ONE_SHOT, OPT_PACK, OPT_PACK_THREADS, OPT_PACK_MIN_LOG_N, OPT_PACK_PIN, OPT_
     OPT_PACK_BUDGET_PERMILLE, OPT_PACK_RAW_PERMILLE, OPT_COMBINE_EARLY = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 # schedule switches (tests, fuzzer, A/B tools)
 OPT_SMALL_LOG_N, OPT_SMALL_W_LOG_N, OPT_SORT_STAGED, OPT_PART_STAGE_MIN, OPT_SUBSET_W, OPT_COMPACT_TABLE, OPT_H_PARTS, \
-    OPT_H_PIPE, OPT_SHARE_SORT, OPT_NTT_BATCH_LOG_M, OPT_C_FOLD, OPT_C_FOLD_MIN_LOG_M = 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23
+    OPT_H_PIPE, OPT_SHARE_SORT, OPT_NTT_BATCH_LOG_M, OPT_C_FOLD, OPT_C_FOLD_MIN_LOG_M, OPT_UPLOAD_GATES = 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24
 
 
 def _options_from_env():
@@ -484,7 +484,8 @@ class Context:
         """zg_last_stats: kernel launches of the last zg_prove* call, bit mask of the witness queries that shared a digit sort."""
         st = (C.c_uint64 * 4)()
         self._check(self.lib.zg_last_stats(self.h, st))
-        return {"launches": int(st[0]), "shared_sort_mask": int(st[1]), "b_g1_behind_b_g2": bool(st[2]), "c_folded": bool(st[3])}
+        return {"launches": int(st[0]), "shared_sort_mask": int(st[1]) & 0xff, "b_g1_behind_b_g2": bool(st[2]), "c_folded": bool(st[3]),
+                "l_in_parts_behind_the_upload": bool(int(st[1]) & 0x100)}
 
 
 class R1CS:

@@ -56,6 +56,8 @@ struct Ctx {
     int opt_c_fold = 1;               // ZG_OPT_C_FOLD: 0 six transforms; 1 four where the C rows evaluate to bits (decided per key, when
                                       // its tables are built); 2 four for every key that has the evaluation form (tests)
     int opt_c_fold_min_log_m = 20;    // ZG_OPT_C_FOLD_MIN_LOG_M: mode 1 only from domains of 2^value rows
+    int opt_upload_gates = 23;        // ZG_OPT_UPLOAD_GATES: a witness of 2^value values or more that does not pack goes over in chunks, the
+                                      // l multiexp in parts behind them (0 = never)
     // msm_batch5 calls it (on the thread that finished the last witness job) once the sums of l, a, b_g1 (g1[1..3]) and b_g2
     // are final and the h job is still running; set and cleared by zg_prove_dev
     std::function<void(const XYZZ<Fq>* g1, const XYZZ<Fq2>* g2)> witness_hook;
@@ -86,6 +88,7 @@ struct Ctx {
     // that shared one digit sort (bit k = query k)
     uint64_t n_launches = 0;
     unsigned last_share_mask = 0;
+    int last_l_parts = 1;       // the l multiexp ran in this many parts behind a witness handed over in chunks (ZG_OPT_UPLOAD_GATES)
     bool last_follow_g2 = false;
     bool last_c_fold = false;
     bool fold_guarded = false;   // the pipeline queued last left the fold to k_fold_decide (prover.hip)

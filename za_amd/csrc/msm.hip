@@ -2771,21 +2771,52 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     if (parts < 1) parts = 1;
     if (parts > HP) parts = HP;
     if (g1[0].n < (size_t)parts * 4096) parts = 1;
+    // witness queries
+    const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
+    const int* w_slot = &job_slot[1];
+    // The l multiexp in parts behind the chunks of a witness that is still arriving (MsmDesc::part_gate, prover.hip
+    // witness_handover): part 0 on the l query's own side stream, the others on the streams that further h parts would take --
+    // so only while those are free, and not for a query that reads a shared sort.  Each part is a job of its own over a
+    // range of the query (make_range_job); their sums are added before the witness hook sees them.
+    int lparts = 1, lslot[HP] = {w_slot[0], 0, 0, 0};
+    if (g1[1].part_gate && g1[1].part_gate_only && g1[1].part_bounds && g1[1].parts > 1 && g1[1].parts <= HP && g1[1].n &&
+        !(share && (share->mask & 2u)) && g1[1].parts - 1 <= 3 - (parts - 1)) {
+        lparts = g1[1].parts;
+        for (int k = 1; k < lparts; k++) lslot[k] = 4 + parts + (k - 1);   // the slots after the h parts': 5 .. 7
+    }
+    auto is_l_part_slot = [&](int k) {
+        for (int q = 0; q < lparts; q++)
+            if (lparts > 1 && lslot[q] == k) return true;
+        return false;
+    };
     ZG_HIP(ctx, hipEventRecord(ctx->side_ev, ctx->stream));
     for (int k = 0; k < NS; k++) {
+        if (is_l_part_slot(k)) continue;   // gated per part below
         if (k >= 5 && k <= 7 && k - 4 >= parts) continue;
         hipEvent_t ev = is_h_slot(k) ? ev_h : ev_witness;
         if (is_h_slot(k) && g1[0].part_gate && g1[0].part_gate_only) continue;   // gated per part below
         ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[k], ev ? ev : ctx->side_ev, 0));
     }
-    // witness queries
-    const MsmDesc* wq[4] = {&g1[1], &g1[2], &g1[3], &g2};
-    const int* w_slot = &job_slot[1];
     for (int q = 0; q < 4; q++)
         if (wq[q]->gate && wq[q]->n) ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[w_slot[q]], wq[q]->gate, 0));
     std::unique_ptr<MsmJob<Fq>> wj1[3];
     std::unique_ptr<MsmJob<Fq2>> wj2;
-    for (int q = 0; q < 3; q++) wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);
+    std::unique_ptr<MsmJob<Fq>> lpj[HP];   // l parts 1 .. (part 0 is wj1[0])
+    G1XYZZ lout[HP];
+    for (int q = 0; q < 3; q++) {
+        if (q == 0 && lparts > 1) {
+            for (int k = 0; k < lparts; k++) {
+                const size_t lo = std::min(wq[0]->n, wq[0]->part_bounds[k]), hi = std::min(wq[0]->n, wq[0]->part_bounds[k + 1]);
+                // (the part's own gate and nothing else: "everything queued so far" would be the whole H pipeline)
+                ZG_HIP(ctx, hipStreamWaitEvent(ctx->side[lslot[k]], wq[0]->part_gate[k] ? wq[0]->part_gate[k] : ctx->side_ev, 0));
+                auto j = make_range_job<Fq>(ctx, lslot[k], *wq[0], lo, hi, &lout[k]);
+                j->witness = true;
+                if (k == 0) wj1[0] = std::move(j); else lpj[k] = std::move(j);
+            }
+            continue;
+        }
+        wj1[q] = make_range_job<Fq>(ctx, w_slot[q], *wq[q], 0, wq[q]->n, &out1[q + 1]);
+    }
     wj2 = make_range_job<Fq2>(ctx, w_slot[3], *wq[3], 0, wq[3]->n, out2);
     for (int q = 0; q < 3; q++) wj1[q]->witness = true;
     wj2->witness = true;
@@ -2878,11 +2909,25 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     if (b1_follows) jobs[nj++] = wj1[2].get();
     if (small)   // second: queueing a job takes the host ~80 us, and the NTT pipeline of a small proof is done in 0.3 ms
         for (int k = 0; k < parts; k++) jobs[nj++] = hp[k].get();
-    for (int q = 0; q < 3; q++)
+    for (int q = 0; q < 3; q++) {
         if (!(q == 2 && b1_follows)) jobs[nj++] = wj1[q].get();
+        if (q == 0)
+            for (int k = 1; k < lparts; k++) jobs[nj++] = lpj[k].get();
+    }
+    auto sum_l_parts = [&] {   // (every part has finished: called from the witness hook and again, harmlessly, below)
+        if (lparts <= 1) return;
+        G1XYZZ acc = lout[0];
+        for (int k = 1; k < lparts; k++) acc = acc.add(lout[k]);
+        out1[1] = acc;
+    };
     std::function<void()> on_witness;
-    if (ctx->witness_hook) on_witness = [&] { ctx->witness_hook(out1, out2); };
+    if (ctx->witness_hook)
+        on_witness = [&] {
+            sum_l_parts();
+            ctx->witness_hook(out1, out2);
+        };
     ZG_TRY(run_jobs(ctx, jobs, nj, on_witness));
+    sum_l_parts();
     G1XYZZ h = hout[0];
     for (int k = 1; k < parts; k++) h = h.add(hout[k]);
     out1[0] = h;

@@ -103,10 +103,12 @@ __global__ void __launch_bounds__(256) k_coeff_prepare(Fr* __restrict__ c, size_
 // `Fr` cannot hold a value >= r and its variable 0 is the constant ONE (CS::one(), prover.rs:66), so a raw 32-byte
 // witness that breaks either would give a silently wrong proof (next_digit assumes scalars below 2^254).
 // bad[0] = lowest index of a non-canonical value, bad[1] = 0 if w[0] != 1; both words start as 0xffffffff.
-__global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ w, size_t n, uint8_t* __restrict__ cls,
+// (the values [i0, i0 + n) of the witness: a hand-over in chunks classifies each chunk behind its copy)
+__global__ void __launch_bounds__(256) k_witness_classes(const Fr* __restrict__ w, size_t i0, size_t n, uint8_t* __restrict__ cls,
                                                          uint32_t* __restrict__ bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    i += i0;
     const Fr v = w[i];
     const uint32_t hi = v.l[1] | v.l[2] | v.l[3] | v.l[4] | v.l[5] | v.l[6] | v.l[7];
     const bool small = hi == 0 && v.l[0] <= 1;
@@ -547,6 +549,16 @@ struct ProveWs {
     // zg_prove_h_enqueue_dev -> zg_prove_partials_ex)
     const void* wcls_for = nullptr;
     bool wcls_fresh = false, wcls_armed = false;
+    // A hand-over in chunks (witness_handover): gate_ev[k] = "the values below gate_var[k + 1] are in HBM and classified";
+    // the l multiexp of the proof that follows runs in gate_n parts, part k over the aux values of chunk k, so its first
+    // parts sort and accumulate while the rest of the witness is still on the bus.  gate_for: the device witness they
+    // describe (NULL: none); classes_done_for: the class bytes were already made for it, chunk by chunk.
+    static constexpr int GATES = 3;
+    int gate_n = 0;
+    size_t gate_var[GATES + 1] = {0, 0, 0, 0};
+    hipEvent_t gate_ev[GATES] = {nullptr, nullptr, nullptr};
+    const void* gate_for = nullptr;
+    const void* classes_done_for = nullptr;
     // k_witness_classes' validation result: device words, their pinned host copy, the event behind the copy
     DevBuf bad;
     uint32_t* bad_host = nullptr;
@@ -560,6 +572,8 @@ struct ProveWs {
         }
         if (bad_host) (void)hipHostFree(bad_host);
         if (bad_ev) (void)hipEventDestroy(bad_ev);
+        for (auto& e : gate_ev)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 static ProveWs& prove_ws(Ctx* ctx) {
@@ -943,6 +957,10 @@ extern "C" int zg_set_option(zg_ctx* ctx, int option, int64_t value) try {
             if (value < 0 || value > 28) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_C_FOLD_MIN_LOG_M: 0 .. 28");
             ctx->opt_c_fold_min_log_m = (int)value;
             return ZG_OK;
+        case ZG_OPT_UPLOAD_GATES:
+            if (value < 0 || value > 31) return fail(ctx, ZG_E_INVALID_ARG, "ZG_OPT_UPLOAD_GATES: 0 (off) or the log2 of the smallest witness, up to 31");
+            ctx->opt_upload_gates = (int)value;
+            return ZG_OK;
         default: return fail(ctx, ZG_E_INVALID_ARG, "unknown option %d", option);
     }
 } catch (...) {
@@ -990,7 +1008,7 @@ extern "C" int zg_d2h(zg_ctx* ctx, void* dst, const void* d_src, size_t bytes) t
 extern "C" int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]) try {
     if (!ctx || !stats) return ZG_E_INVALID_ARG;
     stats[0] = ctx->n_launches;
-    stats[1] = ctx->last_share_mask;
+    stats[1] = ctx->last_share_mask | (ctx->last_l_parts > 1 ? 0x100u : 0u);
     stats[2] = ctx->last_follow_g2 ? 1 : 0;
     stats[3] = ctx->last_c_fold ? 1 : 0;
     return ZG_OK;
@@ -1544,7 +1562,8 @@ extern "C" int zg_r1cs_info(const zg_r1cs* r, uint64_t info[7]) try {
     return zg::on_exception(nullptr);
 }
 
-static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   // queued on ctx->stream
+// (begin: buffers and the cleared verdict words; range: the class bytes of [lo, hi); end: the verdict's way to the host)
+static int witness_classes_begin(zg_ctx* ctx, const zg_r1cs* r) {
     ProveWs& ws = prove_ws(ctx);
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     ZG_HIP(ctx, ws.wcls.reserve(nv + ((size_t)2 << r->log_m)));   // (behind the witness: the classes of the C rows' values, c_fold_buffers)
@@ -1558,14 +1577,35 @@ static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   /
     }
     ZG_HIP(ctx, hipMemsetAsync(ws.bad.p, 0xff, 8, ctx->stream));   // "nothing wrong" = all ones in both words
     ZG_HIP(ctx, hipMemsetAsync((uint8_t*)ws.bad.p + 8, 0, 16, ctx->stream));
-    ZG_LAUNCH(ctx, k_witness_classes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, nv,
+    return ZG_OK;
+}
+static int witness_classes_range(zg_ctx* ctx, const void* d_w, size_t lo, size_t hi) {
+    ProveWs& ws = prove_ws(ctx);
+    if (hi <= lo) return ZG_OK;
+    ZG_LAUNCH(ctx, k_witness_classes, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, ctx->stream, (const Fr*)d_w, lo, hi - lo,
                        ws.wcls.as<uint8_t>(), ws.bad.as<uint32_t>());
     ZG_HIP(ctx, hipGetLastError());
+    return ZG_OK;
+}
+static int witness_classes_end(zg_ctx* ctx, const void* d_w) {
+    ProveWs& ws = prove_ws(ctx);
     ZG_HIP(ctx, hipMemcpyAsync(ws.bad_host, ws.bad.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(ctx, hipEventRecord(ws.bad_ev, ctx->stream));
     ws.bad_pending = true;
     ws.wcls_for = d_w;
     return ZG_OK;
+}
+static int witness_classes(zg_ctx* ctx, const zg_r1cs* r, const void* d_w) {   // queued on ctx->stream
+    ProveWs& ws = prove_ws(ctx);
+    if (ws.classes_done_for == d_w && d_w) {   // made chunk by chunk behind the hand-over's copies (witness_handover)
+        ws.classes_done_for = nullptr;
+        return ZG_OK;
+    }
+    ws.classes_done_for = nullptr;
+    ws.gate_for = nullptr;   // (whatever gates an earlier hand-over left do not describe this witness's classes)
+    ZG_TRY(witness_classes_begin(ctx, r));
+    ZG_TRY(witness_classes_range(ctx, d_w, 0, (size_t)r->n_inputs + r->n_aux));
+    return witness_classes_end(ctx, d_w);
 }
 // The verdict of the last witness_classes pass (waits for its 8-byte read-back only, not for the stream): a witness
 // with a value >= r or with variable 0 != ONE is refused, as bellman's typed assignment cannot express it.
@@ -2714,6 +2754,24 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
         }
         if (k < 4) d1[k] = d; else d2 = d;
     }
+    // The l multiexp of a witness that was handed over in chunks (witness_handover): part k over the aux values of chunk k,
+    // gated on that chunk's event alone.  Not for the folded l query (its job waits for the evaluation anyway) nor a
+    // latency-bound one; a query in a shared sort is left whole by msm_batch5.
+    size_t l_bounds[ProveWs::GATES + 1];
+    {
+        ProveWs& ws = prove_ws(ctx);
+        const size_t n_l = (size_t)use[1].n, var0 = (size_t)r->n_inputs + (size_t)p->q[1].lo;   // variable of l position 0
+        if (ws.gate_n > 1 && ws.gate_for == d_witness && d_witness && !c_fold && n_l >= ((size_t)1 << 19) && d1[1].small_hint != 1) {
+            for (int g = 0; g <= ws.gate_n; g++) {
+                const size_t v = ws.gate_var[g];
+                l_bounds[g] = g == ws.gate_n ? n_l : std::min(n_l, v > var0 ? (v - var0) & ~(size_t)63 : 0);
+            }
+            d1[1].parts = ws.gate_n;
+            d1[1].part_gate = ws.gate_ev;
+            d1[1].part_bounds = l_bounds;
+            d1[1].part_gate_only = true;
+        }
+    }
     // (b_g1 may only ride b_g2's sorted entries when both jobs cover the SAME positions: equal lengths, the same start of the
     // shard, the same index list and scalars -- true of every key cut by shard_range from equal totals, asserted here)
     if (ctx->opt_share_sort && use[3].n && use[3].n == use[4].n && p->q[3].lo == p->q[4].lo && use[3].index == use[4].index &&
@@ -2800,6 +2858,7 @@ static int prove_partials_impl(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] partials: jobs described         +%.3f ms (since partials entry)\n", now_ms() - t0);
     ctx->last_share_mask = share.mask;
+    ctx->last_l_parts = d1[1].part_gate && !(share.mask & 2u) ? d1[1].parts : 1;
     ctx->last_follow_g2 = d1[3].follow_g2 && !(share.mask >> 3 & 3u);
     // (a guarded proof: what k_fold_decide decided for it -- its 4-byte copy was queued in front of the l job's gate, and the
     // multiexps below have been waited for by the time this is read: set again at the end)
@@ -3087,17 +3146,46 @@ static int pack_and_upload(zg_ctx* ctx, const uint8_t* witness32, size_t nv, boo
 // witness is mostly zeros and ones, which cross PCIe in packed form (pack_and_upload).
 // (A two-part upload with the l / a / b multiexps over the first half's positions started early was built and
 // measured in round 2: slower, and eleven streams on eight hardware queues can deadlock -- DESIGN.md section 4.2.)
-static int witness_handover(zg_ctx* ctx, const uint8_t* witness32, size_t nv, void** d_w, size_t* sent) {
-    DevBuf& dw = prove_ws(ctx).w;
+// r (zg_prove): a witness that goes over as it is (it does not pack: field elements) and is large is handed over in
+// ProveWs::GATES chunks, each classified behind its copy, with an event per chunk: the l multiexp of the proof then runs
+// in parts gated on them (msm_batch5), sorting and accumulating the first chunks' aux values while the rest is still on
+// the bus -- the one stretch of such a proof in which the GPU idled (9.4 ms of 124 at 2^24, 37 of 483 at 2^26).  No new
+// streams: the l parts take the side streams that further h parts would (a lone context).  From 2^23 values
+// (ZG_OPT_UPLOAD_GATES): at 2^22 the 2.3 ms window buys what three jobs' latency-bound tails cost (33.33 vs 33.34 ms), at
+// 2^24 124.5 -> 119.1 ms (profiles/r06_exp_upload_gates.txt).
+static int witness_handover(zg_ctx* ctx, const uint8_t* witness32, size_t nv, void** d_w, size_t* sent, const zg_r1cs* r = nullptr) {
+    ProveWs& ws = prove_ws(ctx);
+    DevBuf& dw = ws.w;
     ZG_HIP(ctx, dw.reserve(nv * 32));
     bool packed = false;
     size_t first = 0;   // values already queued as they are by pack_and_upload (see there)
     *sent = nv * 32;
+    ws.gate_for = ws.classes_done_for = nullptr;
+    ws.gate_n = 0;
     ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, sent, &first));
+    *d_w = dw.p;
+    if (!packed && first == 0 && r && ctx->opt_upload_gates > 0 && nv >= ((size_t)1 << ctx->opt_upload_gates) && nv == (size_t)r->n_inputs + r->n_aux &&
+        live_contexts() == 1) {
+        constexpr int K = ProveWs::GATES;
+        ZG_TRY(witness_classes_begin(ctx, r));
+        for (int k = 0; k < K; k++) {
+            if (!ws.gate_ev[k]) ZG_HIP(ctx, hipEventCreateWithFlags(&ws.gate_ev[k], hipEventDisableTiming));
+            const size_t lo = k == 0 ? 0 : ws.gate_var[k];
+            const size_t hi = k + 1 == K ? nv : ((nv * (size_t)(k + 1) / K) & ~(size_t)255);   // (multiples of the subset-sum groups)
+            ws.gate_var[k] = lo;
+            ws.gate_var[k + 1] = hi;
+            ZG_HIP(ctx, hipMemcpyAsync((uint8_t*)dw.p + lo * 32, witness32 + lo * 32, (hi - lo) * 32, hipMemcpyHostToDevice, ctx->stream));
+            ZG_TRY(witness_classes_range(ctx, dw.p, lo, hi));
+            ZG_HIP(ctx, hipEventRecord(ws.gate_ev[k], ctx->stream));
+        }
+        ZG_TRY(witness_classes_end(ctx, dw.p));
+        ws.gate_n = K;
+        ws.gate_for = ws.classes_done_for = dw.p;
+        return ZG_OK;
+    }
     if (!packed && first < nv)
         ZG_HIP(ctx, hipMemcpyAsync((uint8_t*)dw.p + first * 32, witness32 + first * 32, (nv - first) * 32, hipMemcpyHostToDevice,
                                    ctx->stream));
-    *d_w = dw.p;
     return ZG_OK;
 }
 extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const uint8_t* witness32,
@@ -3113,7 +3201,7 @@ extern "C" int zg_prove(zg_ctx* ctx, const zg_params* p, const zg_r1cs* r, const
     ctx->stats_keep = true;   // (zg_prove_dev below counts on)
     // (a key with its C rows folded into the l query: their values are written behind the witness, c_fold_buffers)
     if (ctx->opt_c_fold && c_fold_ready(p, r)) ZG_HIP(ctx, prove_ws(ctx).w.reserve((nv + ((size_t)2 << r->log_m)) * 32));
-    ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent));
+    ZG_TRY(witness_handover(ctx, witness32, nv, &d_w, &sent, r));
     if (trace_level() != 0)
         fprintf(stderr, "[za_amd trace] zg_prove: witness handed over  +%.3f ms\n", now_ms() - t0);
     int rc = zg_prove_dev(ctx, p, r, d_w, r_le, s_le, proof_out);
