@@ -21,6 +21,9 @@ ctx.set_option(za_amd.OPT_C_FOLD_MIN_LOG_M, 8)
 while time.time() - t0 < budget:
     c_fold = rng.choice([0, 1, 2, 2])      # four transforms with the C rows folded into the l multiexp: never / by the rows' values / always
     ctx.set_option(za_amd.OPT_C_FOLD, c_fold)
+    # the hand-over of a witness that does not pack: in chunks with the class bytes made chunk by chunk (from 2^9 values here;
+    # the l multiexp itself is only split for large jobs: tests/test_gpu_prove.py), or in one copy
+    ctx.set_option(za_amd.OPT_UPLOAD_GATES, rng.choice([0, 9, 23]))
     if rng.random() < 0.3:
         lg = rng.choice([1, 2, 3, 5, 8, 10, 12, 13])
         m = 1 << lg
@@ -83,6 +86,12 @@ while time.time() - t0 < budget:
         # group element and the oracle computes the same one.
         w2 = np.array(sr.witness, copy=True).reshape(-1, 32)
         nv = w2.shape[0]
+        if rng.random() < 0.25:      # skew: one constant in a large share of the positions (one bucket per digit takes them all)
+            const = rng.choice([2, 3, 65537, (65537 << 40) + 3, bn.R - 1])
+            share = rng.choice([0.25, 0.6, 1.0])
+            for v in range(1, nv):
+                if rng.random() < share:
+                    w2[v, :] = np.frombuffer(const.to_bytes(32, "little"), dtype=np.uint8)
         for _ in range(rng.choice([1, 5, 40, 400])):
             v = rng.randrange(1, nv)
             kind = rng.random()
