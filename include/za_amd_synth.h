@@ -86,6 +86,10 @@ int zg_selftest_pack_mt(const uint8_t* witness32, size_t n, int threads, uint8_t
  * >= first.  ZG_E_BAD_FORMAT if the pieces were not handed over in order from value 0. */
 int zg_selftest_pack_split(const uint8_t* witness32, size_t n, int threads, int cap_permille, int ready_every, uint8_t* raw_out,
                            uint8_t* classes, uint32_t* other_index, uint8_t* others32, size_t* n_others, size_t* first);
+/* prod_i e(P_i, Q_i) with the library's host pairing (csrc/pairing.hip): slow = 1 the definition (points untwisted into Fq12,
+ * plain powers), 0 = the path zg_verify runs.  g1: n x 64 B, g2: n x 128 B (Montgomery LE affine), n <= 4; gt_out (384 B,
+ * nullable): the product's value in the library's tower representation; *is_one = 1 iff it is 1. */
+int zg_selftest_pairing_product(const uint8_t* g1, const uint8_t* g2, size_t n, int slow, uint8_t* gt_out, int* is_one);
 /* Parse + validate a bellman Parameters body on the host (no GPU) and check write(read(x)) == x.
  * counts: |ic|, |h|, |l|, |a|, |b_g1|, |b_g2|, bytes consumed. */
 int zg_params_inspect(const uint8_t* buf, size_t len, int checked, uint64_t counts[7], char* err, size_t err_cap);

@@ -276,6 +276,9 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
                hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr, const MsmShare* share = nullptr);
 void msm_scratch_free(Ctx* ctx);
 
+// ---- pairing.hip (host): prod_i e(P_i, Q_i) == 1 ?  slow = the definition; gt_out (optional, 384 bytes): the product's value
+bool pairing_product_is_one(const G2Affine* qs, const G1Affine* ps, int n, bool slow, uint8_t* gt_out = nullptr);
+
 // ---- ntt.hip
 int ntt_fr_dev(Ctx* ctx, Fr* d_data, uint32_t log_m, bool inverse, bool coset);
 // a,b,c: m device-form elements each in HBM, zero padded, row i at index bitrev(i); d_h_out: m plain

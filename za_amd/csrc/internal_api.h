@@ -19,5 +19,6 @@ struct zg_internal_api {
                                const zg::G1Affine* d_h_eval_full);
     int (*parse_bellman_params)(zg::Ctx* ctx, const uint8_t* buf, size_t len, bool checked, zg::ParsedParams* out, size_t* consumed);
     void (*write_bellman_params)(const zg::ParsedParams& p, std::vector<uint8_t>* out);
+    bool (*pairing_product_is_one)(const zg::G2Affine* qs, const zg::G1Affine* ps, int n, bool slow, uint8_t* gt_out);
 };
 extern "C" const zg_internal_api zg_internal_v1;

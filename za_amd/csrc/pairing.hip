@@ -1,9 +1,14 @@
 // Groth16 verification on the host CPU.
 //
 // Replaces bellman_ce::groth16::{prepare_verifying_key, verify_proof} as za uses them to self-verify every proof
-// (prover/src/groth16/prover.rs:191-200) and in helper::verify (helper.rs:149-159).  Not on the GPU hot path: a
-// straightforward optimal-ate pairing over the tower Fq2[v]/(v^3 - (9+u)), Fq6[w]/(w^2 - v), with the Miller loop in
-// affine coordinates over Fq12 and a plain final exponentiation by (q^12 - 1)/r.  ~60 ms per verification.
+// (prover/src/groth16/prover.rs:191-200) and in helper::verify (helper.rs:149-159).  Not on the GPU hot path -- but inside
+// every prove() of the outer boundary (the reference self-verifies each proof), where the first version's 60-200 ms were a
+// fifth of the call at 2^22.  Tower Fq2[v]/(v^3 - (9+u)), Fq6[w]/(w^2 - v).  Two implementations:
+//   * the DEFINITION (round 1): points untwisted into Fq12, the Miller loop in affine coordinates over Fq12, Frobenius and the
+//     final exponentiation as plain powers (q, (q^12 - 1)/r).  Kept as the cross-check (pairing_product_slow, tests).
+//   * the one zg_verify runs (round 6): the Miller loops of all pairs in lockstep on the twist (affine over Fq2, ONE batched
+//     inversion per step), sparse line values  -y_P + (lambda x_P) w + (y_T - lambda x_T) w^3,  Frobenius by constants
+//     gamma^k = xi^(k (q-1)/6), and the final exponentiation as (q^6 - 1)(q^2 + 1) x the hard part by three powers of u.
 //   e(A, B) = e(alpha, beta) * e(sum ic_i x_i, gamma) * e(C, delta)
 #include <cstring>
 #include <string>
@@ -158,6 +163,175 @@ static const uint64_t FINAL_EXP[44] = {
     0xe1e30a73bb94fec0ull, 0x6a1c71015f3f7be2ull, 0x842d43bf6369b1ffull,
     0x20fddadf107d20bcull, 0x0000002f4b6dc970ull};   // (q^12 - 1) / r
 
+// ---------------------------------------------------------------- the fast path
+static Fq2 fq2_pow_words(Fq2 a, const uint32_t e[8]) {
+    Fq2 r = Fq2::one();
+    for (int i = 255; i >= 0; i--) {
+        r = r.sqr();
+        if ((e[i >> 5] >> (i & 31)) & 1) r = r * a;
+    }
+    return r;
+}
+static Fq2 conj2(const Fq2& a) { return Fq2{a.c0, a.c1.neg()}; }
+// gamma[k] = xi^(k (q - 1) / 6), k = 0 .. 5: what w^k picks up under Frobenius (w^6 = xi)
+struct FrobConsts {
+    Fq2 g[6];
+    FrobConsts() {
+        uint32_t w[8], e[8];
+        for (int i = 0; i < 8; i++) w[i] = FqParams::MOD[i];
+        w[0] -= 1;
+        uint64_t rem = 0;
+        for (int i = 7; i >= 0; i--) {   // (q - 1) / 6
+            const uint64_t cur = (rem << 32) | w[i];
+            e[i] = (uint32_t)(cur / 6);
+            rem = cur % 6;
+        }
+        const Fq2 xi{Fq::from_u64(9), Fq::from_u64(1)};
+        g[0] = Fq2::one();
+        g[1] = fq2_pow_words(xi, e);
+        for (int k = 2; k < 6; k++) g[k] = g[k - 1] * g[1];
+    }
+};
+static const FrobConsts& frob_consts() {
+    static const FrobConsts c;
+    return c;
+}
+// a^q: coefficient of v^i w^j is conjugated and multiplied by gamma[2 i + j]
+static Fq12 frob1(const Fq12& a) {
+    const FrobConsts& F = frob_consts();
+    Fq12 r;
+    r.c0.c0 = conj2(a.c0.c0);
+    r.c0.c1 = conj2(a.c0.c1) * F.g[2];
+    r.c0.c2 = conj2(a.c0.c2) * F.g[4];
+    r.c1.c0 = conj2(a.c1.c0) * F.g[1];
+    r.c1.c1 = conj2(a.c1.c1) * F.g[3];
+    r.c1.c2 = conj2(a.c1.c2) * F.g[5];
+    return r;
+}
+static Fq12 frob2(const Fq12& a) { return frob1(frob1(a)); }
+static Fq12 conj12(const Fq12& a) { return Fq12{a.c0, a.c1.neg()}; }   // a^(q^6)
+static Fq12 pow_u(const Fq12& a) {                                      // a^u, u = 4965661367192848881
+    const uint64_t u = 4965661367192848881ull;
+    Fq12 acc = a;
+    for (int i = 61; i >= 0; i--) {   // (bit 62 is the top bit of u)
+        acc = acc.sqr();
+        if ((u >> i) & 1) acc = acc * a;
+    }
+    return acc;
+}
+// f^((q^12 - 1) / r) as (q^6 - 1)(q^2 + 1) and the hard part (q^4 - q^2 + 1) / r through f^u, f^(u^2), f^(u^3) and
+// Frobenius maps (the addition chain of Scott et al., "On the final exponentiation for calculating pairings on ordinary
+// elliptic curves", as used for this curve by the common bn256 implementations)
+static Fq12 final_exp_fast(const Fq12& in) {
+    Fq12 t1 = conj12(in) * in.inv();
+    t1 = frob2(t1) * t1;
+    const Fq12 fp = frob1(t1), fp2 = frob2(t1), fp3 = frob1(fp2);
+    const Fq12 fu = pow_u(t1), fu2 = pow_u(fu), fu3 = pow_u(fu2);
+    const Fq12 y3 = conj12(frob1(fu)), fu2p = frob1(fu2), fu3p = frob1(fu3), y2 = frob2(fu2);
+    const Fq12 y0 = fp * fp2 * fp3, y1 = conj12(t1), y5 = conj12(fu2), y4 = conj12(fu * fu2p), y6 = conj12(fu3 * fu3p);
+    Fq12 t0 = y6.sqr() * y4 * y5;
+    Fq12 s1 = y3 * y5 * t0;
+    t0 = t0 * y2;
+    s1 = (s1.sqr() * t0).sqr();
+    t0 = s1 * y1;
+    s1 = s1 * y0;
+    return t0.sqr() * s1;
+}
+// psi on the twist: (x, y) -> (conj(x) gamma[2], conj(y) gamma[3])  (= Frobenius on the untwisted point)
+static G2Affine psi_twist(const G2Affine& q) {
+    const FrobConsts& F = frob_consts();
+    return G2Affine{conj2(q.x) * F.g[2], conj2(q.y) * F.g[3]};
+}
+// the value at P of the line through T1, T2 (both on the twist, slope lambda already known) : -y_P + lambda x_P w + (y1 - lambda x1) w^3
+static Fq12 line_value(const Fq2& lambda, const G2Affine& t1, const G1Affine& p) {
+    Fq12 l = Fq12::zero();
+    l.c0.c0 = Fq2{p.y.neg(), Fq::zero()};
+    l.c1.c0 = Fq2{lambda.c0 * p.x, lambda.c1 * p.x};
+    l.c1.c1 = t1.y - lambda * t1.x;
+    return l;
+}
+// prod_i miller(Q_i, P_i) for up to MAXP pairs in lockstep: one shared squaring and ONE inversion (Montgomery's trick over
+// the pairs) per step.  Pairs with an identity contribute 1.  The points met in the loop are multiples of Q below 6u + 2 < r,
+// so for Q in G2 no step degenerates (T = +-Q, 2T = O); a degenerate step is reported (false) and the caller falls back on the
+// definition.
+static constexpr int MAXP = 4;
+static bool batch_inverse(Fq2* d, int n) {   // d[i] <- 1 / d[i]; false if one of them is zero
+    Fq2 pre[MAXP];
+    Fq2 acc = Fq2::one();
+    for (int i = 0; i < n; i++) {
+        if (d[i].is_zero()) return false;
+        pre[i] = acc;
+        acc = acc * d[i];
+    }
+    Fq2 inv = acc.inv();
+    for (int i = n - 1; i >= 0; i--) {
+        const Fq2 di = d[i];
+        d[i] = inv * pre[i];
+        inv = inv * di;
+    }
+    return true;
+}
+static bool multi_miller_fast(const G2Affine* qs, const G1Affine* ps, int n_in, Fq12* out) {
+    G2Affine q[MAXP], t[MAXP];
+    G1Affine p[MAXP];
+    int n = 0;
+    for (int i = 0; i < n_in; i++)
+        if (!qs[i].is_inf() && !ps[i].is_inf()) {
+            q[n] = t[n] = qs[i];
+            p[n] = ps[i];
+            n++;
+        }
+    Fq12 f = Fq12::one();
+    if (n == 0) {
+        *out = f;
+        return true;
+    }
+    const unsigned __int128 ate = ((unsigned __int128)1 << 64) | 0x9d797039be763ba8ull;   // 6u + 2
+    Fq2 d[MAXP], lam[MAXP];
+    auto dbl_step = [&]() {
+        for (int i = 0; i < n; i++) d[i] = t[i].y.dbl();
+        if (!batch_inverse(d, n)) return false;
+        for (int i = 0; i < n; i++) {
+            const Fq2 xx = t[i].x.sqr();
+            lam[i] = (xx.dbl() + xx) * d[i];
+            f = f * line_value(lam[i], t[i], p[i]);
+            const Fq2 nx = lam[i].sqr() - t[i].x.dbl();
+            t[i] = G2Affine{nx, lam[i] * (t[i].x - nx) - t[i].y};
+        }
+        return true;
+    };
+    auto add_step = [&](const G2Affine* s) {
+        for (int i = 0; i < n; i++) d[i] = s[i].x - t[i].x;
+        if (!batch_inverse(d, n)) return false;
+        for (int i = 0; i < n; i++) {
+            lam[i] = (s[i].y - t[i].y) * d[i];
+            f = f * line_value(lam[i], t[i], p[i]);
+            const Fq2 nx = lam[i].sqr() - t[i].x - s[i].x;
+            t[i] = G2Affine{nx, lam[i] * (t[i].x - nx) - t[i].y};
+        }
+        return true;
+    };
+    for (int b = 63; b >= 0; b--) {
+        f = f.sqr();
+        if (!dbl_step()) return false;
+        if ((ate >> b) & 1)
+            if (!add_step(q)) return false;
+    }
+    G2Affine q1[MAXP], nq2[MAXP];
+    for (int i = 0; i < n; i++) {
+        q1[i] = psi_twist(q[i]);
+        nq2[i] = psi_twist(q1[i]);
+        nq2[i].y = nq2[i].y.neg();
+    }
+    if (!add_step(q1)) return false;
+    // the last line only (the point is not needed any more)
+    for (int i = 0; i < n; i++) d[i] = nq2[i].x - t[i].x;
+    if (!batch_inverse(d, n)) return false;
+    for (int i = 0; i < n; i++) f = f * line_value((nq2[i].y - t[i].y) * d[i], t[i], p[i]);
+    *out = f;
+    return true;
+}
+
 struct Vk {
     G1Affine alpha_g1, beta_g1, delta_g1;
     G2Affine beta_g2, gamma_g2, delta_g2;
@@ -165,6 +339,22 @@ struct Vk {
 };
 
 }  // namespace
+
+// prod_i e(P_i, Q_i) == 1 ?  slow = the definition (Fq12 points, plain powers); otherwise the fast path, which falls back
+// on the definition if a step of its loops degenerates (it cannot for Q in G2).  gt_out (optional): the product's value.
+bool pairing_product_is_one(const G2Affine* qs, const G1Affine* ps, int n, bool slow, uint8_t* gt_out) {
+    Fq12 e;
+    Fq12 f = Fq12::one();
+    if (!slow && n <= MAXP && multi_miller_fast(qs, ps, n, &f)) {
+        e = final_exp_fast(f);
+    } else {
+        f = Fq12::one();
+        for (int i = 0; i < n; i++) f = f * miller_loop(qs[i], ps[i]);
+        e = f.pow(FINAL_EXP, 44);
+    }
+    if (gt_out) memcpy(gt_out, &e, sizeof(Fq12));
+    return e == Fq12::one();
+}
 
 static int parse_vk(Ctx* ctx, const uint8_t* buf, size_t len, Vk* vk) {
     ParsedParams pp;
@@ -226,11 +416,9 @@ extern "C" int zg_verify(const uint8_t* vk_bytes, size_t vk_len, const uint8_t p
         if (!scalar_is_canonical(k)) return ZG_E_BAD_FORMAT;
         acc = acc.add(G1XYZZ::from_affine(vk.ic[i + 1]).mul(k));
     }
-    Fq12 f = miller_loop(B, A);
-    f = f * miller_loop(vk.beta_g2, vk.alpha_g1.neg());
-    f = f * miller_loop(vk.gamma_g2, acc.to_affine().neg());
-    f = f * miller_loop(vk.delta_g2, C.neg());
-    *ok = f.pow(FINAL_EXP, 44) == Fq12::one() ? 1 : 0;
+    const G2Affine qs[4] = {B, vk.beta_g2, vk.gamma_g2, vk.delta_g2};
+    const G1Affine ps[4] = {A, vk.alpha_g1.neg(), acc.to_affine().neg(), C.neg()};
+    *ok = pairing_product_is_one(qs, ps, 4, /*slow=*/false) ? 1 : 0;
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(nullptr);

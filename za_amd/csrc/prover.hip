@@ -3571,5 +3571,6 @@ extern "C" int zg_proof_json(const uint8_t proof[256], const uint8_t* public_inp
 extern "C" const zg_internal_api zg_internal_v1 = {
     zg::fail_msg,           zg::on_exception,           zg::convert_mont_dev,     zg::host_pack_for_test,
     zg::host_pack_split_for_test, zg::params_h_eval_slice, zg::parse_bellman_params, zg::write_bellman_params,
+    zg::pairing_product_is_one,
 };
 #endif

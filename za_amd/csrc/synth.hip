@@ -265,6 +265,21 @@ extern "C" int zg_synth_pk_container_write(const char* path, uint32_t n_inputs, 
 } catch (...) {
     return zg::on_exception(nullptr);
 }
+// prod_i e(P_i, Q_i) through the library's host pairing: slow = 1 the definition (Fq12 points, plain powers), 0 = what zg_verify
+// runs.  g1: n x 64 bytes, g2: n x 128 bytes (Montgomery LE affine, all zero = identity); gt_out: the value (384 bytes).
+extern "C" int zg_selftest_pairing_product(const uint8_t* g1, const uint8_t* g2, size_t n, int slow, uint8_t* gt_out, int* is_one) try {
+    if (!g1 || !g2 || !is_one || n == 0 || n > 4) return ZG_E_INVALID_ARG;
+    G1Affine ps[4];
+    G2Affine qs[4];
+    for (size_t i = 0; i < n; i++) {
+        memcpy(&ps[i], g1 + 64 * i, 64);
+        memcpy(&qs[i], g2 + 128 * i, 128);
+    }
+    *is_one = zg_internal_v1.pairing_product_is_one(qs, ps, (int)n, slow != 0, gt_out) ? 1 : 0;
+    return ZG_OK;
+} catch (...) {
+    return zg::on_exception(nullptr);
+}
 extern "C" int zg_synth_binwitness_write(const char* path, const uint8_t* witness32, size_t n) try {
     if (!path || !witness32) return ZG_E_INVALID_ARG;
     FileOut o(path);

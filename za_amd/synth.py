@@ -13,7 +13,8 @@ SYNTH_SYMBOLS = ["zg_synth_r1cs_new", "zg_synth_r1cs_info", "zg_synth_ptr", "zg_
                  "zg_synth_bases_g1_dev", "zg_synth_bases_g2_dev", "zg_synth_params_dev", "zg_synth_dlog",
                  "zg_synth_scalars_dev", "zg_params_download", "zg_params_shard",
                  "zg_selftest_field_host", "zg_selftest_field_dev", "zg_selftest_curve_host", "zg_selftest_curve_dev", "zg_params_inspect",
-                 "zg_selftest_pack_mt", "zg_selftest_pack_split", "zg_synth_pk_container_write", "zg_synth_binwitness_write"]
+                 "zg_selftest_pack_mt", "zg_selftest_pack_split", "zg_synth_pk_container_write", "zg_synth_binwitness_write",
+                 "zg_selftest_pairing_product"]
 
 MASK64 = (1 << 64) - 1
 
