@@ -328,7 +328,8 @@ def ntt_roofline(m, passes, kernel_ms, launches, h_ms_live, eval_form=True, c_fo
     n_transforms = (4 if c_folded else 6) if eval_form else 7
     alg = n_transforms * 64 * m
     out = {"bound": "hbm", "kernel": ("k_ntt_pass / k_ntt_mid / k_ntt_tail3 (H in evaluation form%s: %%d transforms in %%d launches)"
-                                      % (", C rows folded into the l multiexp" if c_folded else "")
+                                      % (", C rows folded into the l multiexp; the launch count includes c's passes, which are queued and "
+                                         "leave at once when the device decides that the proof folds" if c_folded else "")
                                       if eval_form else "k_ntt_pass (H in coefficient form, bellman's %d transforms, in %d launches)")
            % (n_transforms, passes), "algorithmic_bytes": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "h_pipeline_ms_in_proof": h_ms_live,
