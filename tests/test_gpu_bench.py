@@ -46,6 +46,11 @@ def test_bench_line_contract_single_gpu():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and "proof bytes equal to the GPU's: True" in c["sample"]
     assert 20 < d["launches_per_proof"] < 400 and "b_g1_behind_b_g2" in d["digit_sort_sharing"]
+    # the reference's own per-proof flow (read the key checked, prove once): key_load, one_shot, outer_prove
+    kl, osh, op = d["key_load"], d["one_shot"], d["outer_prove"]
+    assert kl["bytes"] > 0 and 0 < kl["checked_s"] < 5 and 0 < kl["unchecked_s"] < 5
+    assert osh["ms"] > 0 and op.get("proof_verifies") is True and op["total_s"] > 0 and op["pk_read_s"] > 0, op
+    assert d["per_key_preparation"]["prepare_s"] >= 0
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
