@@ -289,6 +289,12 @@ int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset) {
     if (!rd.u32be(&nc)) return ZG_E_IO;
     for (uint32_t i = 0; i < nc; i++) {
         if (!rd.u32be(&n) || !rd.take(n, &b)) return ZG_E_IO;
+        if (rd.pos + 4096 < len) {   // (as pk_walk)
+            __builtin_prefetch(pk + rd.pos + 1024);
+            __builtin_prefetch(pk + rd.pos + 2048);
+            __builtin_prefetch(pk + rd.pos + 3072);
+            __builtin_prefetch(pk + rd.pos + 4096);
+        }
     }
     uint32_t ni;
     if (!rd.u32be(&ni) || !rd.take((size_t)ni * 4, &b)) return ZG_E_IO;
@@ -393,6 +399,14 @@ int pk_walk(Ctx* ctx, const uint8_t* pk, size_t len, PkWalk* w) {
     for (uint32_t i = 0; i < nc; i++) {
         if (!rd.u32be(&n) || !rd.take(n, &b)) return fail(ctx, ZG_E_IO, "pk: truncated constraint %u", i);
         w->at[i] = (size_t)(b - pk);
+        // (the next prefixes lie a few hundred bytes ahead: ask for those lines now -- the chain is otherwise one cache miss
+        // per constraint)
+        if (rd.pos + 4096 < len) {
+            __builtin_prefetch(pk + rd.pos + 1024);
+            __builtin_prefetch(pk + rd.pos + 2048);
+            __builtin_prefetch(pk + rd.pos + 3072);
+            __builtin_prefetch(pk + rd.pos + 4096);
+        }
     }
     w->at[nc] = rd.pos + 4;   // (constraint i spans [at[i], at[i + 1] - 4): the next one's length prefix lies in between)
     uint32_t ni;
