@@ -399,7 +399,11 @@ int zg_params_query_total(const zg_params* p, int which, uint64_t* total);
  * free HBM); the library reads no environment variable for either.  Without room the plain per-window schedule is
  * used.  Results are identical either way. */
 int zg_params_prepare(zg_ctx* ctx, const zg_params* params, const zg_r1cs* r1cs, const void* d_witness);
-/* Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2; 5 = the l query with the C rows folded in, ZG_OPT_C_FOLD --
+/* (A key whose C rows are folded builds the folded query's table, 5, and NOT the plain l query's: zg_prove* never reads the
+ * latter for such a key -- a proof the per-proof guard runs with six transforms takes the folded query with its rows struck
+ * out.  The plain l table is built on demand only if the plain phase API, zg_prove_partials_ex without an armed fold, is used
+ * on the key; then both stay resident.)
+ * Which table query `which` (0 h, 1 l, 2 a, 3 b_g1, 4 b_g2; 5 = the l query with the C rows folded in, ZG_OPT_C_FOLD --
  * a key that has it builds no table for the plain l query) currently has: kind 0 none, 1 window table (dense
  * assignment), 2 subset-sum table (sums over groups of four positions, for an assignment that is at least 90 % zeros
  * and ones: a group of four 0/1 scalars costs one mixed add instead of one per 1; 3.75x the query's footprint), and
