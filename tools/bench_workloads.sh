@@ -1,5 +1,5 @@
 # The other workloads' bench lines (one JSON line each): bash tools/bench_workloads.sh <tag>  -> gpurun_out/<tag>/bench_*.json
-# (SKIP_BIG=1: without the 2^24 / 2^26 configurations, which take ten minutes of set-up)
+# (SKIP_BIG=1: without the 2^24 / 2^26 configurations, which take ten minutes of set-up; ONLY=<name>: that line alone)
 tag=${1:-r0x_w}
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -9,7 +9,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 uptime > $out/uptime.txt
 Q="--no-msm --no-dense --no-sha --shard-model 0 --no-cpu-baseline --no-outer"
-run() { name=$1; shift; timeout 1500 python bench.py $Q "$@" 2>$out/$name.err | tail -1 > $out/bench_$name.json; }
+run() { name=$1; shift; if [ -n "${ONLY:-}" ] && [ "$ONLY" != "$name" ]; then return; fi; timeout 1500 python bench.py $Q "$@" 2>$out/$name.err | tail -1 > $out/bench_$name.json; }
 run eddsa_poseidon --workload eddsa --steps 100 --warmup 10
 run poseidon_2p14 --workload poseidon --log-m 14 --steps 100 --warmup 10
 run poseidon_2p20 --workload poseidon --log-m 20 --steps 30 --warmup 5

@@ -1,7 +1,8 @@
 """One workload proved a few times through zg_prove (pinned host witness) -- for wall times, ZA_AMD_TRACE host stamps
 (set the variable: the last proof is announced on stderr) and rocprofv3 kernel traces.
-    python tools/proof_run.py [eddsa | poseidon:<log_m> | dense:<log_m> | <log_m>] [proofs]
-eddsa = the EdDSA-Poseidon verifier circuit (config 2), poseidon:<n> = a Poseidon chain (config 3), dense:<n> = uniform
+    python tools/proof_run.py [eddsa | poseidon:<log_m> | sha:<depth> | dense:<log_m> | <log_m>] [proofs]
+eddsa = the EdDSA-Poseidon verifier circuit (config 2), poseidon:<n> = a Poseidon chain (config 3), sha:<d> = the bit-level
+SHA-256 Merkle inclusion circuit of d levels (config 4 as named: 32; 90 fills the 2^22 domain), dense:<n> = uniform
 field elements (config 5's shape), <n> = the config-4 shape (97 % bits) at 2^n."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,11 @@ from za_amd import synth, workloads
 what = sys.argv[1] if len(sys.argv) > 1 else "eddsa"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ctx = za_amd.Context(0)
-if what == "eddsa" or what.startswith("poseidon:"):
+if what.startswith("sha:"):
+    n_in, n_aux, n_cons, rp, cl, cf, wit, _ = workloads.sha256_merkle(int(what.split(":")[1]))
+    R = ctx.r1cs_load(n_in, n_aux, n_cons, rp, cl, cf)
+    wb = np.frombuffer(wit, dtype=np.uint8)
+elif what == "eddsa" or what.startswith("poseidon:"):
     if what == "eddsa":
         n_in, n_aux, cons, wit = workloads.eddsa_poseidon_verifier()
     else:

@@ -275,6 +275,7 @@ struct MsmShare {
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
                hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr, const MsmShare* share = nullptr);
 void msm_scratch_free(Ctx* ctx);
+size_t msm_scratch_bytes(Ctx* ctx, int slot);   // device bytes the slot's sort buffers hold
 
 // ---- pairing.hip (host): prod_i e(P_i, Q_i) == 1 ?  slow = the definition; gt_out (optional, 384 bytes): the product's value
 bool pairing_product_is_one(const G2Affine* qs, const G1Affine* ps, int n, bool slow, uint8_t* gt_out = nullptr);

@@ -2665,6 +2665,29 @@ static MsmScratch& scratch_slot(Ctx* ctx, int slot) {
     return *ctx->msm_scratch[slot];
 }
 
+// Device bytes a slot's (grow-only) scratch holds, and their release.  The l parts behind a chunked witness (msm_batch5) sort on
+// the slots further h parts would use: two more sets of sort buffers of a third of the query each.  At 2^26 that is 11 GB, kept
+// beside an unsplit l job's 16 GB if proofs of both kinds alternate -- more than a key of that size leaves free.  So the split
+// is only taken while the memory is there (msm_scratch_bytes, prover.hip witness_handover) and an unsplit proof drops what
+// the parts left behind (msm_scratch_trim).
+template <class Fn>
+static void scratch_bufs(MsmScratch& S, Fn fn) {
+    DevBuf* all[] = {&S.counts, &S.offsets, &S.item_off, &S.tile_tab, &S.abuf, &S.sorted, &S.item_key, &S.perm, &S.ihist,
+                     &S.partial, &S.lvl[0], &S.lvl[1], &S.ones[0], &S.ones[1], &S.bsum, &S.meta, &S.heavy, &S.heavy_tmp,
+                     &S.abuf2, &S.tab2, &S.p2m};
+    for (DevBuf* b : all) fn(*b);
+}
+size_t msm_scratch_bytes(Ctx* ctx, int slot) {
+    if (slot < 0 || slot > Ctx::MSM_SLOTS || !ctx->msm_scratch[slot]) return 0;
+    size_t total = 0;
+    scratch_bufs(*ctx->msm_scratch[slot], [&](DevBuf& b) { total += b.bytes; });
+    return total;
+}
+static void msm_scratch_trim(Ctx* ctx, int slot) {
+    if (!ctx->msm_scratch[slot]) return;
+    scratch_bufs(*ctx->msm_scratch[slot], [&](DevBuf& b) { b.release(); });
+}
+
 int msm_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index, size_t n,
            G1XYZZ* out) {
     MsmJob<Fq> job(ctx, scratch_slot(ctx, 0), ctx->stream, d_bases, d_scalars, d_index, n, out);
@@ -2784,6 +2807,9 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
         lparts = g1[1].parts;
         for (int k = 1; k < lparts; k++) lslot[k] = 4 + parts + (k - 1);   // the slots after the h parts': 5 .. 7
     }
+    if (lparts == 1)
+        for (int k = 4 + parts; k <= 7; k++)   // (nothing of this proof is queued on these slots)
+            if (msm_scratch_bytes(ctx, k) > ((size_t)1 << 30)) msm_scratch_trim(ctx, k);
     auto is_l_part_slot = [&](int k) {
         for (int q = 0; q < lparts; q++)
             if (lparts > 1 && lslot[q] == k) return true;

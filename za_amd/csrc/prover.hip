@@ -3164,8 +3164,17 @@ static int witness_handover(zg_ctx* ctx, const uint8_t* witness32, size_t nv, vo
     ws.gate_n = 0;
     ZG_TRY(pack_and_upload(ctx, witness32, nv, &packed, sent, &first));
     *d_w = dw.p;
-    if (!packed && first == 0 && r && ctx->opt_upload_gates > 0 && nv >= ((size_t)1 << ctx->opt_upload_gates) && nv == (size_t)r->n_inputs + r->n_aux &&
-        live_contexts() == 1) {
+    bool chunked = !packed && first == 0 && r && ctx->opt_upload_gates > 0 && nv >= ((size_t)1 << ctx->opt_upload_gates) &&
+                   nv == (size_t)r->n_inputs + r->n_aux && live_contexts() == 1;
+    if (chunked) {
+        // the l parts sort on two more slots (msm.hip msm_scratch_bytes): about 128 bytes per value and part that have to be
+        // free, or held by those slots already -- at 2^26 beside a key of that size they may not be
+        size_t free_b = 0, total_b = 0;
+        ZG_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        const size_t have = msm_scratch_bytes(ctx, 6) + msm_scratch_bytes(ctx, 7);
+        if (have + free_b < (size_t)256 * nv + ((size_t)4 << 30)) chunked = false;
+    }
+    if (chunked) {
         constexpr int K = ProveWs::GATES;
         ZG_TRY(witness_classes_begin(ctx, r));
         for (int k = 0; k < K; k++) {
