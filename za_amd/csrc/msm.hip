@@ -1092,7 +1092,9 @@ __global__ void __launch_bounds__(1024) k_part_local(const uint2* __restrict__ A
     // segment takes the wave-aggregated counters (wave_agg_add) in its three passes; every other segment the plain atomics.
     bool skew = false;
     if (end - start >= 16u * 1024u) {
-        const uint32_t y0 = A[start + (uint32_t)(((uint64_t)(end - start) * threadIdx.x) >> 10)].y;
+        // (four runs of 256 consecutive entries at the quarter points: 8 KB in whole lines -- 1024 scattered samples were 64 KB of
+        // lines for a segment of 128 KB, 0.05 ms per sort of a SHA-256 proof)
+        const uint32_t y0 = A[start + (uint32_t)(((uint64_t)(end - start - 256u) * (threadIdx.x >> 8)) / 3u) + (threadIdx.x & 255u)].y;
         const uint32_t eq = (uint32_t)__popcll(__ballot(y0 == __shfl(y0, 0)));
         if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = eq;
         __syncthreads();
@@ -1526,47 +1528,46 @@ __global__ void __launch_bounds__(128 * LP) k_heavy_fold(Batch<F> batch, const u
     __shared__ uint32_t last_unit;
     const uint32_t tid = threadIdx.x / LP, bdim = blockDim.x / LP;   // points, not lanes
     const uint32_t cnt = heavy_cnt[0];
-    // sum of src[lo .. hi) over the workgroup; the result is thread 0's (all of its LP lanes)
-    auto fold = [&](const XYZZ<F>* __restrict__ src, uint32_t lo, uint32_t hi) {
-        XYZZd<L> acc = XYZZd<L>::inf();
-        for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&src[i]));
-        acc.store(&lds[tid]);
-        __syncthreads();
-        for (uint32_t st = bdim >> 1; st > 0; st >>= 1) {
-            if (tid < st) {
-                acc = acc.add(XYZZd<L>::load(&lds[tid + st]));
-                acc.store(&lds[tid]);
-            }
-            __syncthreads();
-        }
-        return acc;
-    };
     for (uint32_t slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
         const uint4 u = units[slot];
         const uint32_t key = u.x, nch = u.z, t0 = u.w;
         const uint32_t lo0 = item_off[key], hi0 = item_off[key + 1];
-        const uint32_t lo = lo0 + u.y * HEAVY_CH, hi = lo + HEAVY_CH < hi0 ? lo + HEAVY_CH : hi0;
-        XYZZd<L> acc = fold(partial, lo, hi);
-        if (nch == 1) {
-            if (tid == 0) {
-                acc.store(&partial[lo0]);
-                if (key == ones_key) acc.store(ones_out);
-            }
+        // ONE copy of the summation in the code (the second round, for the workgroup that arrives last at a bucket of several
+        // units, re-enters it with the units' sums as its source: two inlined copies cost 248 registers and 344 bytes of scratch
+        // against 166 and none, and a normal proof's fold 0.2 ms instead of 0.08)
+        const XYZZ<F>* src = partial;
+        uint32_t lo = lo0 + u.y * HEAVY_CH, hi = lo + HEAVY_CH < hi0 ? lo + HEAVY_CH : hi0;
+        bool final_round = nch == 1;
+        for (;;) {
+            XYZZd<L> acc = XYZZd<L>::inf();
+            for (uint32_t i = lo + tid; i < hi; i += bdim) acc = acc.add(XYZZd<L>::load(&src[i]));
+            acc.store(&lds[tid]);
             __syncthreads();
-            continue;
-        }
-        if (tid == 0) acc.store(&ftmp[t0 + u.y]);
-        __threadfence();   // the unit's sum is out before its arrival is counted (the units of a bucket run on any XCD)
-        __syncthreads();
-        if (threadIdx.x == 0) last_unit = atomicAdd(&dn[t0], 1u) == nch - 1 ? 1u : 0u;
-        __syncthreads();
-        if (last_unit) {   // (uniform over the workgroup) every other unit of this bucket has arrived
-            __threadfence();
-            acc = fold(ftmp, t0, t0 + nch);
-            if (tid == 0) {
-                acc.store(&partial[lo0]);
-                if (key == ones_key) acc.store(ones_out);
+            for (uint32_t st = bdim >> 1; st > 0; st >>= 1) {
+                if (tid < st) {
+                    acc = acc.add(XYZZd<L>::load(&lds[tid + st]));
+                    acc.store(&lds[tid]);
+                }
+                __syncthreads();
             }
+            if (final_round) {
+                if (tid == 0) {
+                    acc.store(&partial[lo0]);
+                    if (key == ones_key) acc.store(ones_out);
+                }
+                break;
+            }
+            if (tid == 0) acc.store(&ftmp[t0 + u.y]);
+            __threadfence();   // the unit's sum is out before its arrival is counted (the units of a bucket run on any XCD)
+            __syncthreads();
+            if (threadIdx.x == 0) last_unit = atomicAdd(&dn[t0], 1u) == nch - 1 ? 1u : 0u;
+            __syncthreads();
+            if (!last_unit) break;   // (uniform over the workgroup)
+            __threadfence();         // every other unit of this bucket has arrived: fold their sums
+            src = ftmp;
+            lo = t0;
+            hi = t0 + nch;
+            final_round = true;
         }
         __syncthreads();
     }

@@ -193,19 +193,37 @@ __global__ void __launch_bounds__(256) k_count_digits16(const Fr* __restrict__ v
 // The per-proof guard of the folded form (ZG_OPT_C_FOLD = 1).  A key folds its C rows because the FIRST witness it saw had
 // rows of bits and small integers; a later witness whose rows hold field elements would send m dense scalars into the l
 // multiexp (Poseidon's shape forced: 7.5 -> 8.4 ms at 2^20).  The evaluator has summed the non-zero 16-bit digits of this
-// witness's rows (R1csMats::c_digits) and written them in both forms; this kernel takes the key's own rule -- at most two
-// digits per row -- for THIS proof: *flag = 1: folded (c's transform passes, already queued, leave at once: ntt.hip
-// SkipC); *flag = 0: six transforms, and the rows' values are struck from the l multiexp (class 0 = a zero scalar, which no
-// pass of the multiexp reads).  No host round trip: the launches behind it are queued before it runs.
+// witness's rows (R1csMats::c_digits); this kernel takes the key's own rule -- at most two digits per row -- for THIS proof:
+// *flag = 1: folded (c's transform passes, already queued, leave at once: ntt.hip SkipC); *flag = 0: six transforms -- the
+// rows' values are written where c's transform reads them and struck from the l multiexp (class 0 = a zero scalar, which
+// no pass of the multiexp reads).  No host round trip: the launches behind it are queued before it runs.
+__device__ __forceinline__ uint32_t rev4(uint32_t x) { return __brev(x) >> 28; }
+static constexpr uint32_t DIGIT_SLOTS = 64;   // (a wave's worth: k_fold_decide adds them with shuffles)
 __global__ void __launch_bounds__(256) k_fold_decide(const unsigned long long* __restrict__ digits, unsigned long long limit,
                                                      uint32_t* __restrict__ flag, Fr* __restrict__ c_nat, uint8_t* __restrict__ c_cls,
-                                                     size_t n2) {
-    const bool fold = *digits <= limit;
+                                                     Fr* __restrict__ c_out, int log_m) {
+    // (DIGIT_SLOTS counters: a SHA-256 circuit's ~10^5 long rows each add theirs, and on one word those atomics took 0.15 ms)
+    unsigned long long sum = digits[threadIdx.x & (DIGIT_SLOTS - 1)];
+#pragma unroll
+    for (int d = DIGIT_SLOTS / 2; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    const bool fold = sum <= limit;
     if (blockIdx.x == 0 && threadIdx.x == 0) *flag = fold ? 1u : 0u;
     if (fold) return;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
-        c_cls[i] = 0;
-        c_nat[i] = Fr::zero();
+    // Six transforms: the rows go where the evaluator would have put them for c's transform (k_r1cs_eval_tiled's order, in
+    // Montgomery form) and leave the l multiexp.  Only here -- a proof that folds pays nothing for the other form.
+    const size_t m = (size_t)1 << log_m;
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < m; row += (size_t)gridDim.x * blockDim.x) {
+        Fr v = c_nat[row];
+        if (c_nat[m + row].l[0]) v.l[0] = 2;   // (store_folded_c: a row equal to 2 is a one on the doubled bases)
+        const uint32_t ta = (uint32_t)(row >> (log_m - 4)), tb = (uint32_t)(row & 15);
+        const uint32_t mid = (uint32_t)((row >> 4) & (((uint64_t)1 << (log_m - 8)) - 1));
+        const uint32_t rmid = log_m > 8 ? (__brev(mid) >> (32 - (log_m - 8))) : 0u;
+        const uint64_t dst = ((uint64_t)rev4(tb) << (log_m - 4)) | ((uint64_t)rmid << 4) | rev4(ta);
+        FrD::to_mont(FrD::load_canon(&v)).reduce().store(&c_out[dst]);
+        c_nat[row] = Fr::zero();
+        c_nat[m + row] = Fr::zero();
+        c_cls[row] = 0;
+        c_cls[m + row] = 0;
     }
 }
 
@@ -587,7 +605,6 @@ static ProveWs& prove_ws(Ctx* ctx) {
 // fastest) touch 512-byte runs instead of one 32-byte element per DRAM page.
 // Terms whose coefficient is +-2^s and whose witness value is 0 or 1 are summed in two 128-bit integers (no gather
 // of the 32-byte operands, no field multiplication); everything else takes the Montgomery path.
-__device__ __forceinline__ uint32_t rev4(uint32_t x) { return __brev(x) >> 28; }
 static constexpr uint64_t R1CS_LONG_ROW = 32;   // terms; longer rows go to k_r1cs_eval_long
 // (the three matrices A, B, C in ONE launch: blockIdx.y picks the matrix -- two launches fewer on a small proof's critical path)
 struct R1csMats {
@@ -602,9 +619,9 @@ struct R1csMats {
     // bases, heval.hip)
     Fr* c_nat = nullptr;
     uint8_t* c_cls = nullptr;
-    // The per-proof guard of the folded form (k_fold_decide): with c_digits the rows are ALSO written as out[2] (what c's
-    // transforms would read) and the non-zero 16-bit digits of their values are summed into *c_digits -- what their
-    // multiexp costs in additions; the decision "folded or six transforms" is then taken on the device, for this witness.
+    // The per-proof guard of the folded form (k_fold_decide): with c_digits the non-zero 16-bit digits of the rows' values are
+    // summed into c_digits[DIGIT_SLOTS] -- what their multiexp costs in additions; the decision "folded or six transforms" is
+    // then taken on the device, for this witness, and only a proof that does not fold gets the rows in c's transform order.
     unsigned long long* c_digits = nullptr;
 };
 __device__ __forceinline__ uint32_t digits16(const Fr& x) {
@@ -687,8 +704,7 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* _
         acc.reduce().from_mont().store(&cv);
         store_folded_c(M.c_nat, M.c_cls, row, (uint64_t)1 << log_m, cv);
         if (!M.c_digits) return;
-        // guarded: count the digits (a row equal to 2 is a one on the doubled bases: no digit) and write the row for the
-        // transforms as well
+        // guarded: count the digits (a row equal to 2 is a one on the doubled bases: no digit)
         const bool two = cv.l[0] == 2 && (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0;
         uint32_t cnt = two ? 0u : digits16(cv);
         __shared__ uint32_t part[4];
@@ -696,7 +712,9 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_tiled(R1csMats M, const Fr* _
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
         if ((t & 63) == 0) part[t >> 6] = cnt;
         __syncthreads();
-        if (t == 0 && (part[0] | part[1] | part[2] | part[3])) atomicAdd(M.c_digits, (unsigned long long)part[0] + part[1] + part[2] + part[3]);
+        if (t == 0 && (part[0] | part[1] | part[2] | part[3]))
+            atomicAdd(&M.c_digits[blockIdx.x & (DIGIT_SLOTS - 1)], (unsigned long long)part[0] + part[1] + part[2] + part[3]);
+        return;
     }
     acc.reduce().store(&tile[t]);
     __syncthreads();
@@ -774,10 +792,10 @@ __global__ void __launch_bounds__(256) k_r1cs_eval_long(const uint32_t* __restri
         if (c_digits) {   // (R1csMats::c_digits: the tiled kernel counted this row as zero)
             const bool two = cv.l[0] == 2 && (cv.l[1] | cv.l[2] | cv.l[3] | cv.l[4] | cv.l[5] | cv.l[6] | cv.l[7]) == 0;
             const uint32_t cnt = two ? 0u : digits16(cv);
-            if (cnt) atomicAdd(c_digits, (unsigned long long)cnt);
+            if (cnt) atomicAdd(&c_digits[wave & (DIGIT_SLOTS - 1)], (unsigned long long)cnt);
         }
     }
-    if (lane == 0 && (!c_nat || c_digits)) {
+    if (lane == 0 && !c_nat) {
         // the tiled kernel's destination: row = (ta, mid, tb) -> (ta, bitrev(mid), tb) with ta / tb swapped and reversed
         const uint32_t ta = (uint32_t)(row >> (log_m - 4)), tb = (uint32_t)(row & 15);
         const uint32_t mid = (uint32_t)((row >> 4) & (((uint64_t)1 << (log_m - 8)) - 1));
@@ -1568,15 +1586,15 @@ static int witness_classes_begin(zg_ctx* ctx, const zg_r1cs* r) {
     const size_t nv = (size_t)r->n_inputs + r->n_aux;
     ZG_HIP(ctx, ws.wcls.reserve(nv + ((size_t)2 << r->log_m)));   // (behind the witness: the classes of the C rows' values, c_fold_buffers)
     if (!ws.bad_host) {
-        // [0, 8) the validation words; [8, 16) the digit sum of the C rows and [16, 20) the fold flag of the proof in flight
-        // (k_fold_decide); host: the two validation words, then the flag of the last guarded proof
-        ZG_HIP(ctx, ws.bad.reserve(32));
+        // [0, 8) the validation words; [16, 20) the fold flag of the proof in flight and [64, 64 + 8 DIGIT_SLOTS) the digit sums of
+        // its C rows (k_fold_decide); host: the two validation words, then the flag of the last guarded proof
+        ZG_HIP(ctx, ws.bad.reserve(64 + 8 * DIGIT_SLOTS));
         ZG_HIP(ctx, hipHostMalloc((void**)&ws.bad_host, 16, hipHostMallocDefault));
         ws.bad_host[2] = 0;
         ZG_HIP(ctx, hipEventCreateWithFlags(&ws.bad_ev, hipEventDisableTiming));
     }
     ZG_HIP(ctx, hipMemsetAsync(ws.bad.p, 0xff, 8, ctx->stream));   // "nothing wrong" = all ones in both words
-    ZG_HIP(ctx, hipMemsetAsync((uint8_t*)ws.bad.p + 8, 0, 16, ctx->stream));
+    ZG_HIP(ctx, hipMemsetAsync((uint8_t*)ws.bad.p + 8, 0, 56 + 8 * DIGIT_SLOTS, ctx->stream));
     return ZG_OK;
 }
 static int witness_classes_range(zg_ctx* ctx, const void* d_w, size_t lo, size_t hi) {
@@ -1624,7 +1642,7 @@ static int witness_verdict(zg_ctx* ctx) {
 // d_abc[k]: m device-form elements (zero padded), rows = n_constraints + n_inputs; with `bitrev` row i is
 // stored at index bitrev(i) (what h_poly_dev consumes)
 // c_nat / c_cls (both or neither; needs the tiled path: bitrev, log_m >= 8, at least one constraint): see R1csMats
-// c_digits (with c_nat; needs d_abc[2] too): the guarded form -- the C rows in both forms and their digit sum (R1csMats::c_digits)
+// c_digits (with c_nat): the guarded form -- the folded C rows and their digit sum (R1csMats::c_digits)
 static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc[3], bool bitrev, Fr* c_nat = nullptr,
                          uint8_t* c_cls = nullptr, unsigned long long* c_digits = nullptr) {
     const size_t m = (size_t)1 << r->log_m;
@@ -1647,7 +1665,7 @@ static int r1cs_eval_dev(zg_ctx* ctx, const zg_r1cs* r, const Fr* d_w, Fr* d_abc
         }
         M.c_nat = c_nat;
         M.c_cls = c_cls;
-        M.c_digits = c_nat && d_abc[2] ? c_digits : nullptr;
+        M.c_digits = c_nat ? c_digits : nullptr;
         ZG_LAUNCH(ctx, k_r1cs_eval_tiled, dim3((unsigned)(m >> 8), 3), dim3(256), 0, st, M, d_w, ws.wcls.as<uint8_t>(),
                            r->n_constraints, (int)r->log_m);
         for (int k = 0; k < 3; k++)
@@ -1919,13 +1937,14 @@ static int prove_h_enqueue(zg_ctx* ctx, const zg_r1cs* r, const void* d_witness,
         abc[k] = ws.abc[k].as<Fr>();
     }
     if (c_nat && !eval_form) return fail(ctx, ZG_E_INVALID_ARG, "internal: folded C rows without the evaluation form");
-    unsigned long long* d_digits = guard ? (unsigned long long*)((uint8_t*)ws.bad.p + 8) : nullptr;
+    unsigned long long* d_digits = guard ? (unsigned long long*)((uint8_t*)ws.bad.p + 64) : nullptr;
     uint32_t* d_flag = guard ? (uint32_t*)((uint8_t*)ws.bad.p + 16) : nullptr;
     ZG_TRY(r1cs_eval_dev(ctx, r, (const Fr*)d_witness, abc, /*bitrev=*/r->log_m > 0, c_nat, c_cls, d_digits));
     ctx->fold_guarded = guard;
     if (guard) {
-        ZG_LAUNCH(ctx, k_fold_decide, dim3((unsigned)std::min<size_t>((2 * m + 255) / 256, 2048)), dim3(256), 0, ctx->stream, d_digits,
-                  (unsigned long long)m * 2, d_flag, c_nat, c_cls, 2 * m);
+        // (a proof that folds -- nearly all of them -- only reads the counters: a small grid)
+        ZG_LAUNCH(ctx, k_fold_decide, dim3((unsigned)std::min<size_t>((m + 255) / 256, 512)), dim3(256), 0, ctx->stream, d_digits,
+                  (unsigned long long)m * 2, d_flag, c_nat, c_cls, abc[2], (int)r->log_m);
         ZG_HIP(ctx, hipGetLastError());
         ZG_HIP(ctx, hipMemcpyAsync(&ws.bad_host[2], d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));   // (zg_last_stats)
     }
