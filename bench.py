@@ -932,6 +932,13 @@ def main():
             "digit_sort_sharing": {"b_g1_behind_b_g2": proof_stats["b_g1_behind_b_g2"],
                                    "one_sort_over_witness_positions_mask": proof_stats["shared_sort_mask"]} if proof_stats else None,
             "kernel_ms_per_step": {k: v[0] / n_break for k, v in prof_all.items()},
+            # the h multiexp's phases (HIP events on its streams inside the profiled proofs; from 2^22 points the job runs as two
+            # parts on two streams, whose times are ADDED here: they overlap each other and the end of the transforms)
+            "h_msm": {"sort_ms": prof_all["msm_digit_sort_dense"][0] / n_break,
+                      "accumulate_ms": prof_all["msm_accumulate_g1_dense"][0] / n_break,
+                      "reduce_ms": prof_all["msm_bucket_reduce_dense"][0] / n_break,
+                      "accumulate_launches_per_proof": prof_all["msm_accumulate_g1_dense"][1] / n_break}
+                     if "msm_digit_sort_dense" in prof_all else None,
             "setup_s": t_setup,
             "per_key_preparation": {"prepare_s": t_prep, "first_proof_ms": 1e3 * t_first,
                                     "tables_gb": sum(t["gb"] for t in key_tables.values()),

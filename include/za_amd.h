@@ -473,10 +473,11 @@ int zg_last_stats(const zg_ctx* ctx, uint64_t stats[4]);
 /* ---- optional per-kernel timing (HIP events on the ctx stream), used by bench.py for the roofline
  * line.  id: 0 msm_accumulate_g1 (the witness queries' G1 jobs), 1 msm_accumulate_g2, 2 msm_digit_sort,
  * 3 msm_bucket_reduce, 4 ntt_pass, 5 ntt_pointwise, 6 r1cs_eval, 7 msm_accumulate_g1_dense (the h query's job and
- * dense-hinted standalone multiexps: every point reaches the kernel).  alg_bytes = algorithmic HBM bytes of the timed launches.
+ * dense-hinted standalone multiexps: every point reaches the kernel), 8 msm_digit_sort_dense and 9 msm_bucket_reduce_dense (the
+ * same jobs' sort and reduction: they are not in 2 and 3).  alg_bytes = algorithmic HBM bytes of the timed launches.
  * zg_profile_enable: 0 off, 1 = classes 0, 1 and 7 only (the dominant kernels: about five event pairs per proof),
  * 2 = every class (about a hundred event pairs per proof, which cost 0.5 ms of a proof's wall time). */
-#define ZG_PROFILE_KERNELS 8
+#define ZG_PROFILE_KERNELS 10
 int zg_profile_enable(zg_ctx* ctx, int on);
 int zg_profile_reset(zg_ctx* ctx);
 int zg_profile_get(zg_ctx* ctx, int id, double* ms, uint64_t* launches, uint64_t* alg_bytes);

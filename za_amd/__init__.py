@@ -462,7 +462,9 @@ class Context:
         """{kernel class: (total ms, launches, algorithmic bytes, work units)} since the last reset."""
         self.lib.zg_profile_name.restype = C.c_char_p
         out = {}
-        for i in range(8):
+        for i in range(10):
+            if not self.lib.zg_profile_name(C.c_int(i)):   # (an older build of the library: ZA_AMD_LIB)
+                break
             ms, n, b = C.c_double(), C.c_uint64(), C.c_uint64()
             self._check(self.lib.zg_profile_get(self.h, C.c_int(i), C.byref(ms), C.byref(n), C.byref(b)))
             u = C.c_uint64()

@@ -116,7 +116,8 @@ int host_pack_split_for_test(const uint8_t* witness32, size_t nv, int threads, i
 
 // kernel classes timed by the profiling facility
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,
-              PROF_R1CS_EVAL, PROF_MSM_ACC_G1_DENSE /* the h job: every point reaches the kernel */, PROF_COUNT };
+              PROF_R1CS_EVAL, PROF_MSM_ACC_G1_DENSE /* the h job: every point reaches the kernel */,
+              PROF_MSM_SORT_DENSE, PROF_MSM_REDUCE_DENSE /* the h job's digit sort and bucket reduction */, PROF_COUNT };
 struct ProfScope {
     Ctx* c; int idx = -1;
     hipStream_t st;

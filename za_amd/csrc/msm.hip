@@ -1886,7 +1886,7 @@ struct MsmJob : MsmJobBase {
             return ZG_OK;
         }
         ZG_HIP(ctx, hipMemsetAsync(S.meta.p, 0, 64, st));
-        ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
+        ProfScope ps(ctx, dense ? PROF_MSM_SORT_DENSE : PROF_MSM_SORT, n * 32, st);
         ZG_LAUNCH(ctx, k_classify, dim3(grid), dim3(256), 0, st, d_scalars, d_index, d_cls, n, S.meta.as<uint32_t>() + 8,
                            cw_rank);
         ZG_HIP(ctx, hipMemcpyAsync(S.host, S.meta.as<uint32_t>() + 8, 12, hipMemcpyDeviceToHost, st));
@@ -2026,7 +2026,7 @@ struct MsmJob : MsmJobBase {
         // free memory that queued kernels still use)
         ZG_HIP(ctx, S.bsum.reserve(std::max<size_t>(std::max<size_t>((tab_n + 1 + SCAN_TILE - 1) / SCAN_TILE, (n2 + 1 + SCAN_TILE - 1) / SCAN_TILE),
                                                     (size_t)2 * ((nkeys + 1 + SCAN_TILE - 1) / SCAN_TILE)) * 4));
-        ProfScope ps(ctx, PROF_MSM_SORT, n * 32, st);
+        ProfScope ps(ctx, dense ? PROF_MSM_SORT_DENSE : PROF_MSM_SORT, n * 32, st);
         const size_t lds1 = (size_t)nbins * 4;
         const uint32_t vstride = use_cw ? cw_n : P.kw == 1 ? (uint32_t)fbw_stride : 0u;
         const uint32_t* rank = use_cw ? cw_rank : (const uint32_t*)nullptr;
@@ -2170,7 +2170,7 @@ struct MsmJob : MsmJobBase {
             ZG_HIP(ctx, hipMemsetAsync(S.ihist.as<uint32_t>() + 2 * ITEM_CLASSES, 0, 8, st));   // (its own heavy-bucket counters)
             ZG_HIP(ctx, hipStreamWaitEvent(st, src->ev_items, 0));
         } else {
-            ProfScope ps(ctx, PROF_MSM_SORT, 0, st);
+            ProfScope ps(ctx, dense ? PROF_MSM_SORT_DENSE : PROF_MSM_SORT, 0, st);
             uint32_t* hist = S.ihist.as<uint32_t>();
             ZG_LAUNCH(ctx, k_build_items, dim3((nkeys + 255) / 256), dim3(256), 0, st, S.item_off.as<uint32_t>(),
                                nkeys, S.item_key.as<uint32_t>(), eager_small ? 1 : 0, hist, 2 * ITEM_CLASSES + 2);
@@ -2258,7 +2258,7 @@ struct MsmJob : MsmJobBase {
             if (ev_acc) ZG_HIP(ctx, hipEventRecord(ev_acc, st));
         }
         trace_point("phase_c accumulate queued");
-        ProfScope ps(ctx, PROF_MSM_REDUCE, 0, st);
+        ProfScope ps(ctx, dense ? PROF_MSM_REDUCE_DENSE : PROF_MSM_REDUCE, 0, st);
         // ---- bit-plane reduction over the regular keys (see k_bits_level)
         {   // fold heavy buckets first (list built on the device; the fold grid is fixed and strides over it)
             // units of HEAVY_CH items (k_heavy_collect): at most one per listed bucket plus one per HEAVY_CH items; slots for the

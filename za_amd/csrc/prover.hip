@@ -1100,7 +1100,8 @@ extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) try {
 }
 extern "C" const char* zg_profile_name(int id) {
     static const char* names[] = {"msm_accumulate_g1", "msm_accumulate_g2", "msm_digit_sort", "msm_bucket_reduce",
-                                  "ntt_pass", "ntt_pointwise", "r1cs_eval", "msm_accumulate_g1_dense"};
+                                  "ntt_pass", "ntt_pointwise", "r1cs_eval", "msm_accumulate_g1_dense",
+                                  "msm_digit_sort_dense", "msm_bucket_reduce_dense"};
     return id >= 0 && id < PROF_COUNT ? names[id] : "";
 }
 
