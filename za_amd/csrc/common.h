@@ -28,7 +28,8 @@ struct Ctx {
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_pool;   // recycled timing events (creating two per scope cost 0.3 ms per proof)
     std::mutex prof_mu;                  // the MSM jobs of a proof run on their own host threads
-    struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[8];
+    static constexpr int PROF_SLOTS = 10;   // = PROF_COUNT (ProfId below; checked there)
+    struct ProfStat { double ms = 0; uint64_t launches = 0, bytes = 0, units = 0; } prof[PROF_SLOTS];
     // cached NTT tables per log_m (device pointers), see ntt.hip
     struct NttTables* ntt[28] = {nullptr};
     bool one_shot = false;       // zg_set_option(ZG_OPT_ONE_SHOT): no per-key precomputation
@@ -118,6 +119,7 @@ int host_pack_split_for_test(const uint8_t* witness32, size_t nv, int threads, i
 enum ProfId { PROF_MSM_ACC_G1 = 0, PROF_MSM_ACC_G2, PROF_MSM_SORT, PROF_MSM_REDUCE, PROF_NTT_PASS, PROF_NTT_POINTWISE,
               PROF_R1CS_EVAL, PROF_MSM_ACC_G1_DENSE /* the h job: every point reaches the kernel */,
               PROF_MSM_SORT_DENSE, PROF_MSM_REDUCE_DENSE /* the h job's digit sort and bucket reduction */, PROF_COUNT };
+static_assert(PROF_COUNT == Ctx::PROF_SLOTS, "Ctx::prof holds one slot per ProfId");
 struct ProfScope {
     Ctx* c; int idx = -1;
     hipStream_t st;

@@ -1098,6 +1098,7 @@ extern "C" int zg_profile_get_units(zg_ctx* ctx, int id, uint64_t* units) try {
 } catch (...) {
     return zg::on_exception(ctx);
 }
+static_assert(ZG_PROFILE_KERNELS == PROF_COUNT, "include/za_amd.h lists every profile class");
 extern "C" const char* zg_profile_name(int id) {
     static const char* names[] = {"msm_accumulate_g1", "msm_accumulate_g2", "msm_digit_sort", "msm_bucket_reduce",
                                   "ntt_pass", "ntt_pointwise", "r1cs_eval", "msm_accumulate_g1_dense",
