@@ -1,5 +1,6 @@
 # Round artefacts: GPU tests, default bench line, rocprofv3 kernel stats, timeline, PMC passes (separate runs).
 # usage (on the GPU box, from the repo root): bash tools/final_artifacts.sh <tag>      -> gpurun_out/<tag>/
+# (SKIP_TESTS=1: without the GPU test suite)
 tag=${1:-r02_x}
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,7 +9,7 @@ cd "$GRAFT_REPO_ROOT"
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 B=$GRAFT_REPO_ROOT/bench.py
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $out/pytest_gpu.txt
+if [ -z "${SKIP_TESTS:-}" ]; then timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $out/pytest_gpu.txt; fi
 timeout 900 python bench.py 2>$out/bench_stderr.txt | tail -1 > $out/bench_default.json
 cd /tmp && export TMPDIR=/tmp
 PROF="--no-cpu-baseline --no-msm --no-dense --no-sha --provers 1 --shard-model 0 --no-outer"
