@@ -48,6 +48,16 @@ def test_library_exports_every_declared_symbol(lib_built):
     assert sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip()) == ["prove", "setup", "verbose", "verify"]
 
 
+def test_profile_classes_of_the_header_all_have_names(lib_built):
+    """ZG_PROFILE_KERNELS of include/za_amd.h = the classes the library knows (a mismatch once overran the context's table)."""
+    n = int(re.search(r"#define\s+ZG_PROFILE_KERNELS\s+(\d+)", open(os.path.join(ROOT, "include", "za_amd.h")).read()).group(1))
+    lib_built.zg_profile_name.restype = C.c_char_p
+    names = [lib_built.zg_profile_name(C.c_int(i)).decode() for i in range(n)]
+    assert all(names) and len(set(names)) == n, names
+    assert lib_built.zg_profile_name(C.c_int(n)) == b"" and lib_built.zg_profile_name(C.c_int(-1)) == b""
+    assert {"msm_accumulate_g1_dense", "msm_digit_sort_dense", "msm_bucket_reduce_dense"} <= set(names)
+
+
 def test_header_compiles_as_plain_c(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "za_amd.h"\n#include "za_amd_synth.h"\nint main(void){return ZG_OK;}\n')

@@ -51,6 +51,8 @@ def test_bench_line_contract_single_gpu():
     assert kl["bytes"] > 0 and 0 < kl["checked_s"] < 5 and 0 < kl["unchecked_s"] < 5
     assert osh["ms"] > 0 and op.get("proof_verifies") is True and op["total_s"] > 0 and op["pk_read_s"] > 0, op
     assert d["per_key_preparation"]["prepare_s"] >= 0
+    hm = d["h_msm"]   # the h multiexp's phases from HIP events
+    assert hm["sort_ms"] > 0 and hm["accumulate_ms"] > 0 and hm["reduce_ms"] > 0 and hm["accumulate_launches_per_proof"] >= 1
 
 
 def test_bench_two_ranks_on_one_gpu_over_gloo():
