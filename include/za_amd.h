@@ -139,7 +139,7 @@ int zg_set_stream(zg_ctx* ctx, void* hip_stream);
  *                          is checked on the device: the evaluator counts the digits of this witness's rows and a proof
  *                          whose rows hold field elements runs six transforms, its rows struck from the l multiexp (no host
  *                          round trip: 2^22, a dense witness through a key folded by a bit witness 34.5 -> 29.8 ms, six
- *                          transforms 29.6; the guard costs a bit witness 0.05 ms); 2 = for every such key whatever its
+ *                          transforms 29.6; the guard costs a bit witness about 0.1 ms); 2 = for every such key whatever its
  *                          witness and size, unguarded (tests); 0 = six transforms.  The proof is the same group element
  *                          either way; of the phase API only zg_prove_h_eval_enqueue_fold_dev folds.  Measured (config-4 shape, one box, alternated):
  *                          2^22 10.3 -> 9.4 ms, 2^21 5.0 -> 4.7, 2^20 2.97 -> 2.92, 2^19 and below slower (hence the limit). */

@@ -1422,6 +1422,33 @@ extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, con
 }
 
 // ------------------------------------------------------------------------------------------------ R1CS
+// fn(0) .. fn(n_tasks - 1) on up to 16 host threads (the calling one among them); a single task runs in place.  fn must not throw.
+template <class Fn>
+static void host_par_for(size_t n_tasks, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n_tasks);
+    if (T <= 1) {
+        for (size_t i = 0; i < n_tasks; i++) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_tasks) break;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+// rank[index[i]] = i (the inverse of a query's index list; the other entries stay ~0)
+__global__ void __launch_bounds__(256) k_rank_of_index(const uint32_t* __restrict__ index, uint32_t n, uint32_t* __restrict__ rank) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rank[index[i]] = i;
+}
 extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint64_t n_constraints,
                             const uint64_t* const row_ptr[3], const uint32_t* const col[3],
                             const uint8_t* const coeff[3], zg_r1cs** out) try {
@@ -1435,12 +1462,31 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
         return fail(ctx, ZG_E_POLYNOMIAL_DEGREE_TOO_LARGE, "%llu constraints + %u inputs need a domain >= 2^28",
                     (unsigned long long)n_constraints, n_inputs);
     const uint64_t nvars = (uint64_t)n_inputs + n_aux;
+    // The host passes over the CSR arrays (range check, densities by mention, index lists, long rows) run on a few threads from
+    // 2^16 entries: single-threaded they were 60 of the 105 ms this call took for the 2^22 circuit -- inside every prove() of
+    // the outer boundary, which loads the key's constraints anew (za2c.cpp).
     for (int k = 0; k < 3; k++) {
         if (!row_ptr[k]) return ZG_E_INVALID_ARG;
-        uint64_t nnz = row_ptr[k][n_constraints];
+        const uint64_t nnz = row_ptr[k][n_constraints];
         if (nnz && (!col[k] || !coeff[k])) return ZG_E_INVALID_ARG;
-        for (uint64_t e = 0; e < nnz; e++)
-            if (col[k][e] >= nvars) return fail(ctx, ZG_E_INVALID_ARG, "matrix %d: variable index %u out of range", k, col[k][e]);
+    }
+    constexpr size_t HCH = (size_t)1 << 16;   // entries per task
+    for (int k = 0; k < 3; k++) {             // (first offending entry in matrix, then entry order -- as the plain loop found it)
+        const uint64_t nnz = row_ptr[k][n_constraints];
+        const size_t nt = (size_t)((nnz + HCH - 1) / HCH);
+        std::vector<uint64_t> bad(nt, ~(uint64_t)0);
+        const uint32_t* ck = col[k];
+        host_par_for(nt, [&](size_t t) {
+            const uint64_t e1 = std::min<uint64_t>(nnz, (uint64_t)(t + 1) * HCH);
+            for (uint64_t e = (uint64_t)t * HCH; e < e1; e++)
+                if (ck[e] >= nvars) {
+                    bad[t] = e;
+                    break;
+                }
+        });
+        for (size_t t = 0; t < nt; t++)
+            if (bad[t] != ~(uint64_t)0)
+                return fail(ctx, ZG_E_INVALID_ARG, "matrix %d: variable index %u out of range", k, ck[bad[t]]);
     }
     std::unique_ptr<zg_r1cs> r(new zg_r1cs());
     r->n_inputs = n_inputs;
@@ -1448,51 +1494,77 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
     r->n_constraints = n_constraints;
     r->log_m = log_m;
     // densities by MENTION (bellman's DensityTracker::inc in ProvingAssignment::eval)
+    // (flag bytes set from several threads: relaxed atomic stores of the same value)
     std::vector<uint8_t> a_aux(n_aux, 0), b_in(n_inputs, 0), b_aux(n_aux, 0);
-    for (uint64_t e = 0, nnz = row_ptr[0][n_constraints]; e < nnz; e++) {
-        uint32_t v = col[0][e];
-        if (v >= n_inputs) a_aux[v - n_inputs] = 1;
+    for (int k = 0; k < 2; k++) {
+        const uint64_t nnz = row_ptr[k][n_constraints];
+        const uint32_t* ck = col[k];
+        uint8_t* aux = k == 0 ? a_aux.data() : b_aux.data();
+        uint8_t* in = k == 0 ? nullptr : b_in.data();
+        host_par_for((size_t)((nnz + HCH - 1) / HCH), [&](size_t t) {
+            const uint64_t e1 = std::min<uint64_t>(nnz, (uint64_t)(t + 1) * HCH);
+            for (uint64_t e = (uint64_t)t * HCH; e < e1; e++) {
+                const uint32_t v = ck[e];
+                if (v >= n_inputs) __atomic_store_n(&aux[v - n_inputs], (uint8_t)1, __ATOMIC_RELAXED);
+                else if (in) __atomic_store_n(&in[v], (uint8_t)1, __ATOMIC_RELAXED);
+            }
+        });
     }
-    for (uint64_t e = 0, nnz = row_ptr[1][n_constraints]; e < nnz; e++) {
-        uint32_t v = col[1][e];
-        if (v >= n_inputs) b_aux[v - n_inputs] = 1;
-        else b_in[v] = 1;
-    }
+    // dense position -> variable: the inputs (A: all of them; B: the mentioned ones), then the mentioned aux variables -- counted
+    // per slice, then written per slice
     std::vector<uint32_t> a_index, b_index;
-    for (uint32_t i = 0; i < n_inputs; i++) a_index.push_back(i);  // A inputs: full density
-    for (uint32_t i = 0; i < n_aux; i++)
-        if (a_aux[i]) { a_index.push_back(n_inputs + i); r->a_aux_total++; }
-    for (uint32_t i = 0; i < n_inputs; i++)
-        if (b_in[i]) { b_index.push_back(i); r->b_in_total++; }
-    for (uint32_t i = 0; i < n_aux; i++)
-        if (b_aux[i]) { b_index.push_back(n_inputs + i); r->b_aux_total++; }
+    auto build_index = [&](std::vector<uint32_t>& ix, const uint8_t* in_flags, const uint8_t* aux_flags, uint64_t* in_total,
+                           uint64_t* aux_total) {
+        const size_t nt = (size_t)((nvars + HCH - 1) / HCH);
+        std::vector<uint64_t> cnt(nt + 1, 0);
+        auto flag = [&](uint64_t v) -> bool { return v < n_inputs ? (in_flags ? in_flags[v] != 0 : true) : aux_flags[v - n_inputs] != 0; };
+        host_par_for(nt, [&](size_t t) {
+            const uint64_t v1 = std::min<uint64_t>(nvars, (uint64_t)(t + 1) * HCH);
+            uint64_t c = 0;
+            for (uint64_t v = (uint64_t)t * HCH; v < v1; v++) c += flag(v);
+            cnt[t + 1] = c;
+        });
+        for (size_t t = 0; t < nt; t++) cnt[t + 1] += cnt[t];
+        ix.resize(cnt[nt]);
+        host_par_for(nt, [&](size_t t) {
+            const uint64_t v1 = std::min<uint64_t>(nvars, (uint64_t)(t + 1) * HCH);
+            uint64_t o = cnt[t];
+            for (uint64_t v = (uint64_t)t * HCH; v < v1; v++)
+                if (flag(v)) ix[o++] = (uint32_t)v;
+        });
+        uint64_t n_in = 0;
+        for (uint32_t i = 0; i < n_inputs; i++) n_in += in_flags ? in_flags[i] != 0 : 1;
+        if (in_total) *in_total = n_in;
+        *aux_total = ix.size() - n_in;
+    };
+    build_index(a_index, nullptr, a_aux.data(), nullptr, &r->a_aux_total);
+    build_index(b_index, b_in.data(), b_aux.data(), &r->b_in_total, &r->b_aux_total);
     r->n_a = a_index.size();
     r->n_b = b_index.size();
     hipStream_t st = ctx->stream;
-    {   // the inverse maps (variable -> position in the a / b query, ~0 = not in its density): what a query reads the entries
-        // of a shared digit sort through (msm.hip ShQuery); a query of full density needs none
-        std::vector<uint32_t> rank(nvars);
-        for (int k = 0; k < 2; k++) {
-            const std::vector<uint32_t>& ix = k == 0 ? a_index : b_index;
-            zg::DevBuf& dst = k == 0 ? r->a_rank : r->b_rank;
-            if (ix.size() == nvars) continue;   // the identity
-            std::fill(rank.begin(), rank.end(), 0xffffffffu);
-            for (size_t i = 0; i < ix.size(); i++) rank[ix[i]] = (uint32_t)i;
-            ZG_HIP(ctx, dst.alloc(nvars * 4));
-            ZG_HIP(ctx, hipMemcpyAsync(dst.p, rank.data(), nvars * 4, hipMemcpyHostToDevice, st));
-            ZG_HIP(ctx, hipStreamSynchronize(st));   // (`rank` is reused / freed)
-        }
-        // the variables this process's shard of a query [lo, hi) spans are needed on the host when a sharded key is used
-        r->a_first = a_index.empty() ? 0 : a_index.front();
-        r->b_first = b_index.empty() ? 0 : b_index.front();
-        r->a_index_host = a_index;   // (4 bytes per dense position, like the device copy)
-        r->b_index_host = b_index;
-    }
     ZG_HIP(ctx, r->a_index.alloc(a_index.size() * 4));
     ZG_HIP(ctx, r->b_index.alloc(b_index.size() * 4));
     ZG_HIP(ctx, hipMemcpyAsync(r->a_index.p, a_index.data(), a_index.size() * 4, hipMemcpyHostToDevice, st));
     if (!b_index.empty())
         ZG_HIP(ctx, hipMemcpyAsync(r->b_index.p, b_index.data(), b_index.size() * 4, hipMemcpyHostToDevice, st));
+    // the inverse maps (variable -> position in the a / b query, ~0 = not in its density): what a query reads the entries
+    // of a shared digit sort through (msm.hip ShQuery); a query of full density needs none.  Scattered on the device from the
+    // index lists just uploaded.
+    for (int k = 0; k < 2; k++) {
+        const std::vector<uint32_t>& ix = k == 0 ? a_index : b_index;
+        zg::DevBuf& dst = k == 0 ? r->a_rank : r->b_rank;
+        if (ix.size() == nvars) continue;   // the identity
+        ZG_HIP(ctx, dst.alloc(nvars * 4));
+        ZG_HIP(ctx, hipMemsetAsync(dst.p, 0xff, nvars * 4, st));
+        if (!ix.empty())
+            ZG_LAUNCH(ctx, k_rank_of_index, dim3((unsigned)((ix.size() + 255) / 256)), dim3(256), 0, st,
+                      (k == 0 ? r->a_index : r->b_index).as<uint32_t>(), (uint32_t)ix.size(), dst.as<uint32_t>());
+    }
+    // the variables this process's shard of a query [lo, hi) spans are needed on the host when a sharded key is used
+    r->a_first = a_index.empty() ? 0 : a_index.front();
+    r->b_first = b_index.empty() ? 0 : b_index.front();
+    r->a_index_host = a_index;   // (4 bytes per dense position, like the device copy)
+    r->b_index_host = b_index;
     for (int k = 0; k < 3; k++) {
         uint64_t nnz = row_ptr[k][n_constraints];
         ZG_HIP(ctx, r->row_ptr[k].alloc((n_constraints + 1) * 8));
@@ -1509,8 +1581,15 @@ extern "C" int zg_r1cs_load(zg_ctx* ctx, uint32_t n_inputs, uint32_t n_aux, uint
     }
     std::vector<uint32_t> long_rows[3];   // (alive until the synchronize below)
     for (int k = 0; k < 3; k++) {
-        for (uint64_t i = 0; i < n_constraints; i++)
-            if (row_ptr[k][i + 1] - row_ptr[k][i] > R1CS_LONG_ROW) long_rows[k].push_back((uint32_t)i);
+        const size_t nt = (size_t)((n_constraints + HCH - 1) / HCH);
+        std::vector<std::vector<uint32_t>> part(nt);
+        const uint64_t* rp = row_ptr[k];
+        host_par_for(nt, [&](size_t t) {
+            const uint64_t i1 = std::min<uint64_t>(n_constraints, (uint64_t)(t + 1) * HCH);
+            for (uint64_t i = (uint64_t)t * HCH; i < i1; i++)
+                if (rp[i + 1] - rp[i] > R1CS_LONG_ROW) part[t].push_back((uint32_t)i);
+        });
+        for (auto& v : part) long_rows[k].insert(long_rows[k].end(), v.begin(), v.end());
         r->n_long[k] = (uint32_t)long_rows[k].size();
         if (r->n_long[k]) {
             ZG_HIP(ctx, r->long_rows[k].alloc(long_rows[k].size() * 4));
