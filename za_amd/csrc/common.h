@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <functional>
+#include <future>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -84,6 +85,7 @@ struct Ctx {
     hipEvent_t tm_ev[3] = {nullptr, nullptr, nullptr};  // timing of the H pipeline inside zg_prove_dev: start, R1CS evaluation done, H done
     bool witness_gate_armed = false;                   // zg_prove_h_enqueue_dev recorded gate_w for the next partials call
     bool side_ready = false;
+    std::future<bool> side_future;   // msm.hip msm_side_streams_begin: the side streams being created on a helper thread
     // zg_last_stats: kernel launches since the counter was last cleared (zg_prove* clear it on entry; the helper threads
     // of a proof only run host arithmetic, every launch comes from the calling thread), queries of the last multiexp batch
     // that shared one digit sort (bit k = query k)
@@ -278,6 +280,8 @@ struct MsmShare {
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2,
                hipEvent_t ev_witness = nullptr, hipEvent_t ev_h = nullptr, const MsmShare* share = nullptr);
 void msm_scratch_free(Ctx* ctx);
+void msm_side_streams_begin(Ctx* ctx);   // start creating the context's side streams on a helper thread (zg_init)
+int msm_side_streams_ready(Ctx* ctx);    // ... and wait for them (or create them now)
 size_t msm_scratch_bytes(Ctx* ctx, int slot);   // device bytes the slot's sort buffers hold
 
 // ---- pairing.hip (host): prod_i e(P_i, Q_i) == 1 ?  slow = the definition; gt_out (optional, 384 bytes): the product's value

@@ -2738,6 +2738,62 @@ static std::unique_ptr<MsmJob<F>> make_range_job(Ctx* ctx, int slot, const MsmDe
     return j;
 }
 
+// The side streams of a context (one per slot) and the events between them.  Creating them takes 70-80 ms (eight streams at
+// ~10 ms each): zg_init starts it on a helper thread (msm_side_streams_begin), so that it runs beside whatever the caller
+// does first -- reading a key, mostly -- instead of inside its first proof (one prove() of the outer boundary: 0.11 s of
+// "proof" of which 0.08 were this).
+// All side streams at the default priority.  Until round 4 the witness streams of a mostly-0/1 assignment ran at
+// high priority (short jobs beside the transforms).  With the stream assignment of msm_batch5 that is worth nothing for a
+// lone context (2^22, four alternated pairs of processes: 11.60 / 11.84 / 11.95 / 11.85 with, 11.08 / 11.53 / 11.81 /
+// 10.87 without) and with three contexts on the GPU it produced proofs of 60-470 ms every few runs -- mixed
+// priorities over 27 streams on 8 hardware queues; equal priorities: 10.0-10.1 ms per proof, every run
+// (profiles/r04_exp_stream_assignment.txt).
+// (Confining the witness streams to 16-128 of the 256 CUs with hipExtStreamCreateWithCUMask: measured, no gain --
+// they need few CUs; what they cost the NTT pipeline is memory passes and launches, not compute units.)
+static bool side_streams_create(Ctx* ctx) {   // (may run on a helper thread: reports nothing, leaves nothing behind on failure)
+    if (hipSetDevice(ctx->device) != hipSuccess) return false;
+    int lo_prio = 0, hi_prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
+    bool ok = true;
+    for (int k = 0; k < Ctx::MSM_SLOTS && ok; k++)
+        ok = hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, lo_prio) == hipSuccess;
+    hipEvent_t* evs[3] = {&ctx->side_ev, &ctx->share_ev, &ctx->follow_ev};
+    for (hipEvent_t* e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 * Ctx::H_PARTS_MAX && ok; k++) ok = hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (ok) return true;
+    for (int k = 0; k < Ctx::MSM_SLOTS; k++)
+        if (ctx->side[k]) {
+            (void)hipStreamDestroy(ctx->side[k]);
+            ctx->side[k] = nullptr;
+        }
+    for (hipEvent_t* e : evs)
+        if (*e) {
+            (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    for (int k = 0; k < 2 * Ctx::H_PARTS_MAX; k++)
+        if (ctx->part_ev[k]) {
+            (void)hipEventDestroy(ctx->part_ev[k]);
+            ctx->part_ev[k] = nullptr;
+        }
+    return false;
+}
+void msm_side_streams_begin(Ctx* ctx) {
+    if (ctx->side_ready || ctx->side_future.valid()) return;
+    ctx->side_future = std::async(std::launch::async, [ctx] { return side_streams_create(ctx); });
+}
+int msm_side_streams_ready(Ctx* ctx) {
+    if (ctx->side_ready) return ZG_OK;
+    const auto t_streams = std::chrono::steady_clock::now();
+    bool ok = ctx->side_future.valid() && ctx->side_future.get();
+    if (!ok) ok = side_streams_create(ctx);   // (not started, or it failed on the helper thread: once more, here, with the error reported)
+    if (!ok) return fail(ctx, ZG_E_HIP, "creating the multiexp streams failed: %s", hipGetErrorString(hipGetLastError()));
+    ctx->side_ready = true;
+    if (trace_level() != 0)
+        fprintf(stderr, "[za_amd trace] side streams and events ready after  %.3f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_streams).count());
+    return ZG_OK;
+}
 int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4], G2XYZZ* out2, hipEvent_t ev_witness,
                hipEvent_t ev_h, const MsmShare* share) {
     constexpr int NS = Ctx::MSM_SLOTS, HP = Ctx::H_PARTS_MAX;
@@ -2760,26 +2816,7 @@ int msm_batch5(Ctx* ctx, const MsmDesc g1[4], const MsmDesc& g2, G1XYZZ out1[4],
     const std::array<int, 5>& job_slot = whole ? whole_proof : in_order;
     const int h_slot0 = job_slot[0];
     auto is_h_slot = [h_slot0](int k) { return k == h_slot0 || (k >= 5 && k <= 7); };
-    if (!ctx->side_ready) {
-        int lo_prio = 0, hi_prio = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);   // numerically lower = higher priority
-        // All side streams at the default priority.  Until round 4 the witness streams of a mostly-0/1 assignment ran at
-        // high priority (short jobs beside the transforms).  With the stream assignment above that is worth nothing for a
-        // lone context (2^22, four alternated pairs of processes: 11.60 / 11.84 / 11.95 / 11.85 with, 11.08 / 11.53 / 11.81 /
-        // 10.87 without) and with three contexts on the GPU it produced proofs of 60-470 ms every few runs -- mixed
-        // priorities over 27 streams on 8 hardware queues; equal priorities: 10.0-10.1 ms per proof, every run
-        // (profiles/r04_exp_stream_assignment.txt).
-        const int w_prio = lo_prio, h_prio = lo_prio;
-        // (Confining the witness streams to 16-128 of the 256 CUs with hipExtStreamCreateWithCUMask: measured, no gain --
-        // they need few CUs; what they cost the NTT pipeline is memory passes and launches, not compute units.)
-        for (int k = 0; k < NS; k++)
-            ZG_HIP(ctx, hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, is_h_slot(k) ? h_prio : w_prio));
-        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
-        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->share_ev, hipEventDisableTiming));
-        ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->follow_ev, hipEventDisableTiming));
-        for (int k = 0; k < 2 * HP; k++) ZG_HIP(ctx, hipEventCreateWithFlags(&ctx->part_ev[k], hipEventDisableTiming));
-        ctx->side_ready = true;
-    }
+    ZG_TRY(msm_side_streams_ready(ctx));
     // The h job is split into parts over consecutive base ranges (see MsmJobBase::dep): part 0 on side[0], the
     // others on side[5..].  Two parts take 0.33 ms off a 2^22 proof (three: +0.1 ms); when several contexts share the
     // GPU their proofs already fill each other's sort and reduction phases and the split costs 0.37 ms, so it is
@@ -3111,6 +3148,7 @@ void msm_scratch_free(Ctx* ctx) {
             ctx->msm_scratch[k] = nullptr;
         }
     }
+    if (ctx->side_future.valid() && ctx->side_future.get()) ctx->side_ready = true;   // (created on the helper thread, never used)
     if (ctx->side_ready) {
         for (int k = 0; k < Ctx::MSM_SLOTS; k++) (void)hipStreamDestroy(ctx->side[k]);
         for (int k = 0; k < 2 * Ctx::H_PARTS_MAX; k++) (void)hipEventDestroy(ctx->part_ev[k]);
