@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <thread>
+#include <algorithm>
 #include <functional>
 #include <future>
 #include <mutex>
@@ -202,6 +205,29 @@ struct DevBuf {
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// fn(0) .. fn(n_tasks - 1) on up to 16 host threads (the calling one among them); a single task runs in place.  fn must not throw.
+template <class Fn>
+inline void host_par_for(size_t n_tasks, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n_tasks);
+    if (T <= 1) {
+        for (size_t i = 0; i < n_tasks; i++) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_tasks) break;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
 
 // ---- msm.hip
 int msm_g1(Ctx* ctx, const G1Affine* d_bases, const uint32_t* d_scalars, const uint32_t* d_index,

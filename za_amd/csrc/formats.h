@@ -1,5 +1,7 @@
 // Wire formats on the za side of the boundary (host only).
 #pragma once
+#include <sys/mman.h>
+#include <type_traits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -30,16 +32,52 @@ int pk_params_offset(const uint8_t* pk, size_t len, size_t* offset);
 // proof.json (format.rs:80-128)
 int proof_json(const uint8_t proof[256], const uint8_t* public_inputs32, size_t n_public, std::string* out);
 
-// a host array that is NOT zero-filled when it is sized (the threads that fill it touch it first)
+// A host array that is NOT zero-filled when it is sized (the threads that fill it touch it first).  From 4 MB on it is a
+// mapping of its own that asks for transparent huge pages: the constraints of a 2^22 circuit are 0.6 GB of such arrays, and in
+// 4 KB pages giving them back cost 0.13 s (150 000 pages unmapped one by one) of a 0.39 s key read.
 template <class T>
 struct RawBuf {
-    std::unique_ptr<T[]> p;
-    size_t n = 0;
+    T* ptr = nullptr;
+    size_t n = 0, mapped = 0;   // mapped: bytes of the mapping (0: from the heap)
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    RawBuf(RawBuf&& o) noexcept : ptr(o.ptr), n(o.n), mapped(o.mapped) { o.ptr = nullptr; o.n = o.mapped = 0; }
+    RawBuf& operator=(RawBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            ptr = o.ptr; n = o.n; mapped = o.mapped;
+            o.ptr = nullptr; o.n = o.mapped = 0;
+        }
+        return *this;
+    }
+    ~RawBuf() { release(); }
+    void release() {
+        if (ptr) {
+            if (mapped) (void)munmap(ptr, mapped);
+            else delete[] ptr;
+        }
+        ptr = nullptr;
+        n = mapped = 0;
+    }
     void alloc(size_t k) {
-        p.reset(new T[k ? k : 1]);
+        static_assert(std::is_trivial<T>::value, "RawBuf holds plain data");
+        release();
+        const size_t bytes = (k ? k : 1) * sizeof(T);
+        constexpr size_t HUGE = (size_t)2 << 20;
+        if (bytes >= 2 * HUGE) {
+            const size_t len = (bytes + HUGE - 1) & ~(HUGE - 1);
+            void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, len, MADV_HUGEPAGE);   // (a hint: without it the array works as before)
+                ptr = static_cast<T*>(m);
+                mapped = len;
+            }
+        }
+        if (!ptr) ptr = new T[k ? k : 1];
         n = k;
     }
-    T* data() const { return p.get(); }
+    T* data() const { return ptr; }
     size_t size() const { return n; }
 };
 

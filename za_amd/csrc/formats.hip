@@ -561,12 +561,20 @@ int witness_from_binwitness(Ctx* ctx, const std::vector<uint32_t>& var_of_signal
     if (count != var_of_signal.size() || len != 32 * (count + 1))
         return fail(ctx, ZG_E_BAD_FORMAT, "binwitness: %llu signals, the key describes %zu", (unsigned long long)count,
                     var_of_signal.size());
-    memset(witness_out, 0, (size_t)n_vars * 32);
-    for (uint64_t id = 0; id < count; id++) {
-        uint32_t v = var_of_signal[id];
-        if (v == UINT32_MAX) continue;
-        read_w32(bw + 32 * (id + 1), witness_out + 32 * (size_t)v);
-    }
+    // (268 MB touched for a 2^22 circuit: on a few threads -- the signals of a slice go to variables of their own)
+    constexpr size_t CH = (size_t)1 << 16;
+    host_par_for(((size_t)n_vars + CH - 1) / CH, [&](size_t t) {
+        const size_t lo = t * CH, hi = std::min<size_t>(n_vars, lo + CH);
+        memset(witness_out + 32 * lo, 0, 32 * (hi - lo));
+    });
+    host_par_for((size_t)((count + CH - 1) / CH), [&](size_t t) {
+        const uint64_t hi = std::min<uint64_t>(count, (uint64_t)(t + 1) * CH);
+        for (uint64_t id = (uint64_t)t * CH; id < hi; id++) {
+            const uint32_t v = var_of_signal[id];
+            if (v == UINT32_MAX) continue;
+            read_w32(bw + 32 * (id + 1), witness_out + 32 * (size_t)v);
+        }
+    });
     return ZG_OK;
 }
 

@@ -1426,28 +1426,6 @@ extern "C" int zg_h_scalars(zg_ctx* ctx, const uint8_t* a, const uint8_t* b, con
 }
 
 // ------------------------------------------------------------------------------------------------ R1CS
-// fn(0) .. fn(n_tasks - 1) on up to 16 host threads (the calling one among them); a single task runs in place.  fn must not throw.
-template <class Fn>
-static void host_par_for(size_t n_tasks, Fn fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    const size_t T = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n_tasks);
-    if (T <= 1) {
-        for (size_t i = 0; i < n_tasks; i++) fn(i);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    auto work = [&] {
-        for (;;) {
-            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_tasks) break;
-            fn(i);
-        }
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < T; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-}
 // rank[index[i]] = i (the inverse of a query's index list; the other entries stay ~0)
 __global__ void __launch_bounds__(256) k_rank_of_index(const uint32_t* __restrict__ index, uint32_t n, uint32_t* __restrict__ rank) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1644,6 +1622,9 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     pguard.release();
     *r1cs_out = r;
     *params_out = p;
+    if (trace_level() != 0)
+        fprintf(stderr, "[za_amd trace] pk_load: done +%.3f ms (walk %.3f, header + queries %.3f, constraints %.3f, R1CS %.3f)\n",
+                now_ms() - t_walk, walk_ms, ctx->load_timings[0] - walk_ms + ctx->load_timings[1], ctx->load_timings[2], ctx->load_timings[3]);
     return ZG_OK;
 } catch (...) {
     return zg::on_exception(ctx);

@@ -30,6 +30,7 @@
 #include <fstream>
 #include <new>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -352,13 +353,14 @@ static int prove_impl(const char* pk_path, const char* inputs, char* proof_buffe
     zg_r1cs_info(h.r1cs, inf);
     const size_t nv = (size_t)(inf[0] + inf[1]);
     t0 = now_s();
-    std::vector<uint8_t> w(nv * 32);
-    rc = zg_witness_from_binwitness(h.ctx, h.r1cs, bw.p, bw.n, w.data(), w.size());
+    std::unique_ptr<uint8_t[]> wbuf(new uint8_t[nv * 32]);   // (not zeroed here: zg_witness_from_binwitness writes all of it)
+    uint8_t* const w = wbuf.get();
+    rc = zg_witness_from_binwitness(h.ctx, h.r1cs, bw.p, bw.n, w, nv * 32);
     if (rc) return return_string(err_text(h.ctx, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     info("Witness read time: %.3fs\n", now_s() - t0);
     t0 = now_s();
     uint64_t bad = 0;
-    rc = zg_r1cs_check(h.ctx, h.r1cs, w.data(), &bad);
+    rc = zg_r1cs_check(h.ctx, h.r1cs, w, &bad);
     if (rc) return return_string(err_text(h.ctx, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     info("Constraint check time: %.3fs\n", now_s() - t0);
     if (bad != UINT64_MAX)   // the reference panics here: expect("check_constrains_eval_zero failed"), prover.rs:155-157
@@ -366,7 +368,7 @@ static int prove_impl(const char* pk_path, const char* inputs, char* proof_buffe
                              error_buffer, error_buffer_size, ERR_CUSTOM);
     t0 = now_s();
     uint8_t proof[256];
-    rc = zg_prove_random(h.ctx, h.params, h.r1cs, w.data(), proof);
+    rc = zg_prove_random(h.ctx, h.params, h.r1cs, w, proof);
     if (rc) return return_string(err_text(h.ctx, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     info("Proof generation time: %.3fs\n", now_s() - t0);
     t0 = now_s();
@@ -379,11 +381,11 @@ static int prove_impl(const char* pk_path, const char* inputs, char* proof_buffe
     if (rc) return return_string(err_text(nullptr, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     const size_t n_public = (size_t)inf[0] - 1;
     int ok = 0;
-    rc = zg_verify(vkb.data(), vkb.size(), proof, w.data() + 32, n_public, &ok);
+    rc = zg_verify(vkb.data(), vkb.size(), proof, w + 32, n_public, &ok);
     if (rc) return return_string(err_text(nullptr, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     if (!ok) return return_string("Unexpected(\"the proof does not verify against its own key\")", error_buffer, error_buffer_size, ERR_CUSTOM);
     std::string json(1024 + 90 * n_public, '\0');
-    rc = zg_proof_json(proof, w.data() + 32, n_public, &json[0], json.size());
+    rc = zg_proof_json(proof, w + 32, n_public, &json[0], json.size());
     if (rc) return return_string(err_text(nullptr, rc), error_buffer, error_buffer_size, ERR_CUSTOM);
     json.resize(strlen(json.c_str()));
     info("Proof verification time: %.3fs\n", now_s() - t0);
