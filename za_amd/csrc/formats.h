@@ -117,6 +117,7 @@ struct KeyQuery {
 // The host's part: the verifying key (parsed, validated and converted on the host: 6 points + ic), the walk over the five
 // length-prefixed queries (bounds only).  out receives the vk and ic; its query vectors stay empty.
 int parse_bellman_header(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, KeyQuery q[5], size_t* consumed);
+bool peek_bellman_counts(const uint8_t* buf, size_t len, uint32_t* n_ic, uint32_t* n_l);   // |ic|, |l| from the length prefixes
 struct KeyStage {   // the raw bytes' way through HBM: two chunk buffers used in turn
     static constexpr size_t CHUNK_BYTES = (size_t)64 << 20;
     DevBuf buf[2];

@@ -197,6 +197,20 @@ int parse_bellman_header(Ctx* ctx, const uint8_t* buf, size_t len, bool checked,
     return ZG_OK;
 }
 
+// |ic| and |l| of a Parameters body from its length prefixes alone (nothing validated; false: the body is too short for them)
+bool peek_bellman_counts(const uint8_t* buf, size_t len, uint32_t* n_ic, uint32_t* n_l) {
+    Reader rd{buf, len};
+    const uint8_t* b;
+    if (!rd.take(64 + 64 + 128 + 128 + 64 + 128, &b)) return false;
+    uint32_t n;
+    if (!rd.u32be(&n) || !rd.take((size_t)n * 64, &b)) return false;
+    *n_ic = n;
+    if (!rd.u32be(&n) || !rd.take((size_t)n * 64, &b)) return false;   // h
+    if (!rd.u32be(&n)) return false;
+    *n_l = n;
+    return true;
+}
+
 int parse_bellman_params(Ctx* ctx, const uint8_t* buf, size_t len, bool checked, ParsedParams* out, size_t* consumed) {
     KeyQuery q[5];
     ZG_TRY(parse_bellman_header(ctx, buf, len, checked, out, q, consumed));

@@ -1601,15 +1601,47 @@ extern "C" int zg_pk_load(zg_ctx* ctx, const uint8_t* pk, size_t len, int checke
     // the key itself tells how many public inputs (|ic| - 1) and aux variables (|l|) the circuit has
     ZG_HIP(ctx, hipSetDevice(ctx->device));
     if (world < 1 || rank < 0 || rank >= world) return ZG_E_INVALID_ARG;
+    // The constraint sections become CSR on host threads WHILE the queries are uploaded and checked on the device: the two
+    // are 70 ms and 60-100 ms of a 2^22 key's read and need nothing of each other beyond |ic| and |l|, which the body's length
+    // prefixes give.  (The helper reports into a context of its own: fail() writes the caller's error text.)
     ParsedParams pp;
     zg_params* p = nullptr;
-    ZG_TRY(params_load_impl(ctx, pk + off, len - off, checked != 0, rank, world, &p, nullptr, &pp));
-    std::unique_ptr<zg_params> pguard(p);
-    if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
     PkR1cs pr;
+    uint32_t peek_ic = 0, peek_l = 0;
+    const bool peeked = off <= len && peek_bellman_counts(pk + off, len - off, &peek_ic, &peek_l) && peek_ic > 0;
+    Ctx side_ctx;
+    double parse_ms = 0;
+    std::future<int> parsing;
+    if (peeked)
+        parsing = std::async(std::launch::async, [&]() -> int {
+            const double t = now_ms();
+            int rc = ZG_E_HIP;
+            try {
+                rc = parse_pk_r1cs(&side_ctx, pk, len, walk, peek_ic - 1, peek_l, &pr);
+            } catch (...) {
+                side_ctx.last_error = "out of host memory";
+                rc = ZG_E_IO;
+            }
+            parse_ms = now_ms() - t;
+            return rc;
+        });
+    int rc_params = params_load_impl(ctx, pk + off, len - off, checked != 0, rank, world, &p, nullptr, &pp);
+    std::unique_ptr<zg_params> pguard(p);
+    int rc_parse = parsing.valid() ? parsing.get() : ZG_OK;
+    ZG_TRY(rc_params);   // (the key's own errors first, as when the two ran one after the other)
+    if (pp.ic.empty()) return fail(ctx, ZG_E_MALFORMED_VERIFYING_KEY, "pk: empty ic");
+    if (peeked && (pp.ic.size() != peek_ic || p->q[1].total != peek_l)) return fail(ctx, ZG_E_BAD_FORMAT, "pk: inconsistent length prefixes");
+    if (peeked && rc_parse != ZG_OK) {
+        ctx->last_error = side_ctx.last_error;
+        return rc_parse;
+    }
+    if (!peeked) {
+        const double t = now_ms();
+        ZG_TRY(parse_pk_r1cs(ctx, pk, len, walk, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
+        parse_ms = now_ms() - t;
+    }
     double t0 = now_ms();
-    ZG_TRY(parse_pk_r1cs(ctx, pk, len, walk, (uint32_t)pp.ic.size() - 1, (uint32_t)p->q[1].total, &pr));
-    ctx->load_timings[2] = now_ms() - t0;
+    ctx->load_timings[2] = parse_ms;   // (beside [1] when the two overlapped)
     ctx->load_timings[0] += walk_ms;
     const uint64_t* rp[3] = {pr.row_ptr[0].data(), pr.row_ptr[1].data(), pr.row_ptr[2].data()};
     const uint32_t* cl[3] = {pr.col[0].data(), pr.col[1].data(), pr.col[2].data()};
