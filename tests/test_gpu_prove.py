@@ -643,6 +643,30 @@ def test_pk_load_rejects_inconsistent_containers(ctx):
     assert e.value.code == za_amd.ZG_E_BAD_FORMAT if hasattr(za_amd, "ZG_E_BAD_FORMAT") else True
 
 
+def test_pk_load_reports_the_key_before_the_constraints(ctx):
+    """zg_pk_load reads the constraint sections on a helper thread while the device checks the queries (round 6): a container
+    whose ignore_signals names a public signal is refused with the parser's message, and when the key is bad as well the
+    key's error comes first -- as when the two steps ran one after the other."""
+    import za_amd
+    fx = golden("proof_chain7.json")
+    pk = bytes.fromhex(fx["pk_container"])
+    qeqs, ignore, off = g.pk_container_read(pk)
+    assert 1 not in ignore
+    bad_ignore = g.pk_container_write(qeqs, [1] + list(ignore), pk[off:])
+    with pytest.raises(za_amd.ZaAmdError) as e:
+        ctx.pk_load(bad_ignore)
+    assert "public signal 1 is in ignore_signals" in ctx.lib.zg_last_error(ctx.h).decode(), str(e.value)
+    body = bytearray(pk[off:])
+    first_h = 64 + 64 + 128 + 128 + 64 + 128 + 4 + 64 * (fx["n_inputs"]) + 4   # vk, |ic|, ic, |h|
+    body[first_h + 40] ^= 1                                                       # a coordinate of the first h point
+    both = g.pk_container_write(qeqs, [1] + list(ignore), bytes(body))
+    with pytest.raises(za_amd.ZaAmdError):
+        ctx.pk_load(both)
+    assert ctx.lib.zg_last_error(ctx.h).decode().startswith("h: point is not on the curve")
+    R, P = ctx.pk_load(pk)   # ... and the context still loads the good container
+    assert R.n_constraints == len(fx["constraints"])
+
+
 @pytest.mark.parametrize("name", ["proof_factor.json", "proof_chain7.json"])
 def test_gpu_setup_reproduces_the_golden_key(ctx, name):
     """generate_parameters with the fixture's toxic waste gives the same
