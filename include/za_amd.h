@@ -54,7 +54,9 @@ typedef struct zg_r1cs zg_r1cs;
 /* ---- context ------------------------------------------------------------------------------
  * Replaces bellman's `Worker::new()` thread pool (implicit in create_random_proof,
  * prover/src/groth16/prover.rs:173).  `device` is the HIP device ordinal.  Fails with
- * ZG_E_NO_DEVICE when no GPU is visible: there is no CPU fallback. */
+ * ZG_E_NO_DEVICE when no GPU is visible: there is no CPU fallback.
+ * The context's eight side streams (the multiexps' queues) take 70-80 ms to create: zg_init starts that on a helper thread
+ * of its own and returns; the first multiexp batch (or zg_free) waits for it. */
 int zg_init(int device, zg_ctx** out);
 void zg_free(zg_ctx* ctx);
 const char* zg_strerror(int code);
