@@ -1,4 +1,4 @@
-"""Randomised parity sweep (GPU box, uses the C oracle): python tools/fuzz_prove.py [seconds].
+"""Randomised parity sweep (GPU box, uses the C oracle): python tools/fuzz_prove.py [seconds [seed]].
 Two families: (a) the synthetic config-4/5 generator with random size, bit share, inputs, table mask and h parts;
 (b) circuits whose H polynomial is PRESCRIBED coefficient by coefficient (oracle/circuits.py::prescribed_h_r1cs) with
 runs of 0, 1, r - 1 and random values -- the dense h multiexp never sees such scalars from family (a).  Family (b)
@@ -12,7 +12,7 @@ from za_amd import synth
 from oracle import coracle as co
 from util import download_params
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
-rng = random.Random(20261002)
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261002)   # (a second argument: another sequence of cases)
 ctx = za_amd.Context(0)
 t0, n_ok = time.time(), 0
 from oracle import bn254 as bn
