@@ -643,6 +643,50 @@ def test_pk_load_rejects_inconsistent_containers(ctx):
     assert e.value.code == za_amd.ZG_E_BAD_FORMAT if hasattr(za_amd, "ZG_E_BAD_FORMAT") else True
 
 
+def test_r1cs_load_host_passes_on_threads(ctx):
+    """zg_r1cs_load's host passes (range check, densities by mention, index lists, long rows) run on threads from 2^16 entries
+    (round 6): the first out-of-range column is reported in matrix, then entry order, whatever slice finds it first; the
+    densities and the evaluation of a 2^17-row circuit equal numpy's."""
+    import za_amd
+    rng = np.random.default_rng(5)
+    n_in, n_aux, nc = 3, 150_000, 1 << 17
+    nv = n_in + n_aux
+    row_ptr, col, coeff = [], [], []
+    for k in range(3):
+        per_row = rng.integers(0, 4, nc)
+        per_row[7] = 300                                   # a long row (evaluated by its own kernel)
+        rp = np.zeros(nc + 1, dtype=np.uint64)
+        rp[1:] = np.cumsum(per_row)
+        nnz = int(rp[-1])
+        c = rng.integers(0, nv // 2 if k == 1 else nv, nnz).astype(np.uint32)   # (b mentions only half of the variables)
+        v = np.zeros((nnz, 32), dtype=np.uint8)
+        v[:, 0] = rng.integers(1, 5, nnz)
+        row_ptr.append(rp); col.append(c); coeff.append(v.reshape(-1))
+    assert all(len(c) > (1 << 16) for c in col)
+    R = ctx.r1cs_load(n_in, n_aux, nc, row_ptr, col, coeff)
+    a_aux = np.unique(col[0][col[0] >= n_in]).size
+    b_in, b_aux = np.unique(col[1][col[1] < n_in]).size, np.unique(col[1][col[1] >= n_in]).size
+    assert (R.a_aux_total, R.b_input_total, R.b_aux_total) == (a_aux, b_in, b_aux)
+    w = np.zeros((nv, 32), dtype=np.uint8)
+    w[:, 0] = rng.integers(0, 3, nv)
+    w[0, 0] = 1
+    abc = R.eval(w.reshape(-1))
+    for k in range(3):
+        prod = coeff[k].reshape(-1, 32)[:, 0].astype(np.int64) * w[col[k], 0]
+        csum = np.concatenate(([0], np.cumsum(prod)))
+        want = csum[row_ptr[k][1:].astype(np.int64)] - csum[row_ptr[k][:-1].astype(np.int64)]
+        got = from_mont_bytes(abc[k], bn.R)[:nc]
+        assert got == [int(x) for x in want], k
+    # two offending columns: one deep inside matrix 2, one later in matrix 1 -- matrix 1's is the one reported
+    bad = [c.copy() for c in col]
+    bad[2][len(bad[2]) - 5] = nv + 9
+    bad[1][70_000] = nv + 3
+    bad[1][90_000] = nv + 4
+    with pytest.raises(za_amd.ZaAmdError):
+        ctx.r1cs_load(n_in, n_aux, nc, row_ptr, bad, coeff)
+    assert ctx.lib.zg_last_error(ctx.h).decode() == "matrix 1: variable index %d out of range" % (nv + 3)
+
+
 def test_pk_load_reports_the_key_before_the_constraints(ctx):
     """zg_pk_load reads the constraint sections on a helper thread while the device checks the queries (round 6): a container
     whose ignore_signals names a public signal is refused with the parser's message, and when the key is bad as well the
